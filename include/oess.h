@@ -1,0 +1,146 @@
+/*
+ * liboess -- C-ABI of the MI355X-native OpenESS hot path (gfx950, hand-written HIP).
+ *
+ * The reference (ldkong1205/OpenESS) is pure Python: it has no FFI.  Its "plugin surface" is a
+ * set of Python call contracts; each entry point below is what a ctypes binding
+ * inside the cited reference function would call instead of the NumPy / PyTorch-CPU body.
+ * INTEGRATION.md shows the stub for each.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in _host.
+ *   - stream-ordered: the call only ENQUEUES work on `stream` (a hipStream_t passed as void*);
+ *     the caller synchronises.  No hidden allocation: outputs and workspaces are caller-owned and
+ *     must stay alive until the stream has passed the call; sizes come from *_workspace_bytes().
+ *   - returns 0 on success, a negative OESS_E* code otherwise; no exceptions cross the boundary.
+ *   - no global mutable state; thread-safe for distinct streams/buffers.
+ */
+#ifndef OESS_H
+#define OESS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OESS_OK 0
+#define OESS_EINVAL (-22)   /* bad argument (shape, null pointer, unsupported size)            */
+#define OESS_ENOMEM (-12)   /* workspace too small                                             */
+#define OESS_ELAUNCH (-5)   /* hipGetLastError() != hipSuccess after a launch                  */
+
+typedef void* oess_stream_t; /* hipStream_t */
+
+/* Library / device identification.  oess_abi_version() changes when a signature changes. */
+int oess_abi_version(void);
+const char* oess_build_info(void);           /* "liboess <ver> gfx950 hipcc <ver>" */
+const char* oess_strerror(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  Tri-linear event voxelizer.
+ * Replaces VoxelGrid.convert (DSEC/dataset/representations.py:15-54), called once per segment
+ * (sub-window) from Sequence.generate_event_tensor (DSEC/dataset/sequence_ov.py:212-223).
+ *
+ * x,y,p,t: float32 SoA exactly as passed to VoxelGrid.convert (t already normalised to [0,1] by
+ * the caller, sequence_ov.py:155-156).  Segment s owns events [seg_offsets[s], seg_offsets[s+1])
+ * and writes output channels [s*C, (s+1)*C).  out is (n_seg*C) x (H-crop_rows) x W float32,
+ * every element written exactly once (no pre-zeroing needed).  crop_rows fuses the
+ * `event_tensor[:, :-40, :]` crop (sequence_ov.py:307).  count_mode != 0 replaces every weight by
+ * 1.0 (integer hit histogram; used by the bit-exact index tests).
+ * ------------------------------------------------------------------------------------------ */
+size_t oess_voxelize_workspace_bytes(int64_t n_events, int n_seg, int C, int H, int W, int crop_rows);
+
+int oess_voxelize_trilinear_f32(const float* x, const float* y, const float* p, const float* t,
+                                const int64_t* seg_offsets, int n_seg, int64_t max_seg_len,
+                                int C, int H, int W, int crop_rows, int count_mode,
+                                float* out, void* workspace, size_t workspace_bytes, oess_stream_t stream);
+
+/* Same, straight from raw DSEC event columns (events.h5 `events/{x,y,t,p}`, eventslicer.py:32-98):
+ * fuses rectify_events (sequence_ov.py:204-210: rectify_map[y, x] -> (x', y'), map is H x W x 2
+ * float32; seg_map[s] selects one of n_maps maps, one per sequence), the float64->float32 time
+ * normalisation of events_to_voxel_grid (sequence_ov.py:154-157) and K1. */
+int oess_voxelize_dsec_raw(const uint16_t* x, const uint16_t* y, const int64_t* t_us, const uint8_t* p,
+                           const float* rectify_maps, const int32_t* seg_map, int n_maps,
+                           const int64_t* seg_offsets, int n_seg, int64_t max_seg_len,
+                           int C, int H, int W, int crop_rows, int count_mode,
+                           float* out, void* workspace, size_t workspace_bytes, oess_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K1' Nearest-xy / linear-t voxelizer.
+ * Replaces generate_voxel_grid (datasets/data_util.py:51-117) called per chunk from
+ * DDD17Events.__getitem__ (datasets/ddd17_events_loader.py:161-173).
+ * events: [N x 4] rows (x, y, t, p), int64 (DDD17 memmap loader) or float64.
+ * Output channels per segment: separate_pol ? 2*nbins (pos then neg) : nbins (pos - neg).
+ * out is (n_seg*ch) x (H-crop_rows) x W float32.
+ * ------------------------------------------------------------------------------------------ */
+int oess_voxelize_nearest_i64(const int64_t* events, const int64_t* seg_offsets, int n_seg, int64_t max_seg_len,
+                              int nbins, int H, int W, int crop_rows, int separate_pol, int count_mode,
+                              float* out, void* workspace, size_t workspace_bytes, oess_stream_t stream);
+int oess_voxelize_nearest_f64(const double* events, const int64_t* seg_offsets, int n_seg, int64_t max_seg_len,
+                              int nbins, int H, int W, int crop_rows, int separate_pol, int count_mode,
+                              float* out, void* workspace, size_t workspace_bytes, oess_stream_t stream);
+
+/* generate_event_histogram (datasets/data_util.py:17-35): 2 x H x W [neg, pos] counts per segment.
+ * (The reference does no bounds check; out-of-range events are DROPPED here instead of raising.) */
+int oess_event_histogram_i64(const int64_t* events, const int64_t* seg_offsets, int n_seg, int64_t max_seg_len,
+                             int H, int W, float* out, oess_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2  Masked (non-zero) normalisation of a whole tensor.
+ * Replaces EventPreprocessor.__call__ normalisation (e2vid/utils/inference_utils.py:78-85) and
+ * normalize_voxel_grid (datasets/data_util.py:38-48).  in/out: n float32 (may alias).
+ * stats: 4 doubles of caller-owned device scratch {sum, sumsq, nnz, -}; zeroed by the call.
+ * No host sync: the "if num_nonzeros > 0" test happens on the device.
+ * ------------------------------------------------------------------------------------------ */
+int oess_masked_normalize_f32(const float* in, float* out, int64_t n, double* stats, oess_stream_t stream);
+/* Strided variant for a channel slice [B, c0:c0+Cs, H, W] of a [B, Ctot, H, W] tensor (the 5-bin
+ * sub-window slice event[:, 5i:5i+5], training/pretrain_trainer.py:437-440). out is dense B x Cs x HW. */
+int oess_masked_normalize_slice_f32(const float* in, float* out, int B, int Ctot, int c0, int Cs, int64_t HW,
+                                    double* stats, oess_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K7  Superpixel scatter-mean (segment mean) and its backward.
+ * Replaces the inline sparse one-hot matmul of training/pretrain_trainer.py:445-465.
+ * feat: pixel-major [P x Cf] (NHWC flattened, P = B*H*W), float32 or bf16 (is_bf16).
+ * ids: [P] int64 raw superpixel ids; the per-sample offset b*superpixel_size is added inside
+ * (pixels_per_sample = H*W).  k: [S x Cf] float32, count: [S] float32, both fully written.
+ * Pixels whose offset id is outside [0, S) are an error in the reference (S = max id + 1) and are
+ * ignored here.
+ * ------------------------------------------------------------------------------------------ */
+int oess_segment_mean_fwd(const void* feat, int is_bf16, const int64_t* ids, int64_t P, int64_t pixels_per_sample,
+                          int superpixel_size, int Cf, int S, float* k, float* count, oess_stream_t stream);
+/* grad_feat[p, :] = grad_k[id(p), :] / (count[id(p)] + 1e-6)  (float32 or bf16 output) */
+int oess_segment_mean_bwd(const float* grad_k, const float* count, const int64_t* ids, int64_t P,
+                          int64_t pixels_per_sample, int superpixel_size, int Cf, int S,
+                          void* grad_feat, int is_bf16, oess_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K9  TaskLoss = DiceLoss + CrossEntropyLoss(ignore_index) forward and backward.
+ * Replaces utils/loss_functions.py:17-24 (TaskLoss), :114-135 (DiceLoss), :80-90 (BinaryDiceLoss).
+ * logits element (pixel p, class c) lives at logits[p*stride_p + c*stride_c] within a sample of
+ * `pixels_per_sample` pixels whose base is b*stride_b (covers NCHW: stride_p=1, stride_c=HW,
+ * stride_b=K*HW; and NHWC: stride_p=K, stride_c=1, stride_b=HW*K).  float32 or bf16.
+ * target: [P] int64.  sums: (3*K+2) doubles scratch {inter[K], psq[K], ysum[K], ce_sum, n_valid},
+ * zeroed by the fwd call and consumed by the bwd call.  loss_out: 3 floats {total, dice, ce}.
+ * flags bit0 = dice, bit1 = cross-entropy.
+ * ------------------------------------------------------------------------------------------ */
+int oess_task_loss_fwd(const void* logits, int is_bf16, const int64_t* target, int64_t P, int64_t pixels_per_sample,
+                       int64_t stride_b, int64_t stride_p, int64_t stride_c, int K, int ignore_index, int flags,
+                       double* sums, float* loss_out, oess_stream_t stream);
+int oess_task_loss_bwd(const void* logits, int is_bf16, const int64_t* target, int64_t P, int64_t pixels_per_sample,
+                       int64_t stride_b, int64_t stride_p, int64_t stride_c, int K, int ignore_index, int flags,
+                       const double* sums, float grad_scale, const float* grad_scale_dev /* nullable: multiplies grad_scale */,
+                       void* grad_logits, int grad_is_bf16, oess_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K11 Confusion matrix (evaluation/metrics.py:4-23): conf[gt*K + pred] += 1 over gt != ignore.
+ * conf: K*K int64, ACCUMULATED into (caller zeroes once per validation epoch).
+ * ------------------------------------------------------------------------------------------ */
+int oess_confusion_accumulate(const int64_t* pred, const int64_t* label, int64_t n, int K, int ignore_label,
+                              int64_t* conf, oess_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OESS_H */

@@ -1,0 +1,76 @@
+"""ctypes binding of liboess.so (the C-ABI declared in include/oess.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent the
+import of any compute entry point raises.  Build it with ``python -c "import __graft_entry__ as g;
+g.build()"`` or ``make -C openess_amd/csrc``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboess.so")
+
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_f = ctypes.c_float
+c_vp = ctypes.c_void_p
+c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes).  Must list EVERY symbol of include/oess.h (tests/test_abi.py checks).
+SIGNATURES = {
+    "oess_abi_version": (c_int, []),
+    "oess_build_info": (ctypes.c_char_p, []),
+    "oess_strerror": (ctypes.c_char_p, [c_int]),
+    "oess_voxelize_workspace_bytes": (c_sz, [c_i64, c_int, c_int, c_int, c_int, c_int]),
+    "oess_voxelize_trilinear_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int, c_int,
+                                            c_int, c_vp, c_vp, c_sz, c_vp]),
+    "oess_voxelize_dsec_raw": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_i64, c_int, c_int,
+                                       c_int, c_int, c_int, c_vp, c_vp, c_sz, c_vp]),
+    "oess_voxelize_nearest_i64": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_vp,
+                                          c_vp, c_sz, c_vp]),
+    "oess_voxelize_nearest_f64": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_vp,
+                                          c_vp, c_sz, c_vp]),
+    "oess_event_histogram_i64": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_int, c_vp, c_vp]),
+    "oess_masked_normalize_f32": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "oess_masked_normalize_slice_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp]),
+    "oess_segment_mean_fwd": (c_int, [c_vp, c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "oess_segment_mean_bwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_int, c_vp]),
+    "oess_task_loss_fwd": (c_int, [c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp,
+                                   c_vp, c_vp]),
+    "oess_task_loss_bwd": (c_int, [c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp,
+                                   c_f, c_vp, c_vp, c_int, c_vp]),
+    "oess_confusion_accumulate": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
+}
+
+_lib = None
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load liboess.so and attach signatures.  Raises LibraryMissing (never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run __graft_entry__.build() "
+            "(or `make -C openess_amd/csrc`). There is no CPU fallback in the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise LibraryMissing(f"liboess.so lacks symbol {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().oess_strerror(code).decode()
+        raise RuntimeError(f"{what} failed: {msg} ({code})")

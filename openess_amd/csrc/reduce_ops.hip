@@ -1,0 +1,536 @@
+// HBM-bound reductions of the OpenESS hot path for gfx950:
+//   K2  masked (non-zero) normalisation        K7  superpixel scatter-mean fwd / bwd
+//   K9  Dice + cross-entropy fwd / bwd         K11 confusion matrix
+// All are single-pass-over-HBM streaming kernels: 16-byte loads per lane, wave-shuffle + LDS block
+// reductions, one global atomic per (workgroup, accumulator).  No MFMA (integer / byte / fp32 work).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "oess.h"
+#include "oess_common.h"
+
+namespace {
+using namespace oess;
+constexpr int THREADS = 256;
+
+__host__ int stream_grid(int64_t work_items, int per_block) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;          // 256 CUs x 8 resident workgroups; grid-stride the rest
+    return (int)g;
+}
+
+// block-wide sum of NV doubles per thread -> atomicAdd into dst[0..NV)
+template <int NV>
+__device__ __forceinline__ void block_atomic_add(double (&v)[NV], double* dst) {
+    __shared__ double red[THREADS / 64][NV];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double s = wave_sum(v[i]);
+        if (lane == 0) red[w][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0;
+        for (int k = 0; k < THREADS / 64; ++k) s += red[k][threadIdx.x];
+        if (s != 0.0) atomicAdd(&dst[threadIdx.x], s);
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------ K2
+// Tensor viewed as `nchunk` contiguous chunks of L floats; chunk j starts at in + in_off + j*in_stride,
+// out is dense.  (Dense tensor: nchunk = 1.)
+__global__ __launch_bounds__(THREADS) void norm_stats_kernel(const float* __restrict__ in, int64_t L, int64_t nchunk,
+                                                             int64_t in_stride, int64_t in_off, int vec,
+                                                             double* __restrict__ stats) {
+    double acc[3] = {0.0, 0.0, 0.0};
+    const int64_t tid = (int64_t)blockIdx.x * THREADS + threadIdx.x, nthr = (int64_t)gridDim.x * THREADS;
+    if (vec) {
+        const int64_t L4 = L >> 2, total = L4 * nchunk;
+        for (int64_t i = tid; i < total; i += nthr) {
+            const int64_t j = i / L4, r = i - j * L4;
+            const float4 v = *reinterpret_cast<const float4*>(in + in_off + j * in_stride + r * 4);
+            const float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double d = (double)a[k];
+                acc[0] += d; acc[1] += d * d; acc[2] += (a[k] != 0.0f) ? 1.0 : 0.0;
+            }
+        }
+    } else {
+        const int64_t total = L * nchunk;
+        for (int64_t i = tid; i < total; i += nthr) {
+            const int64_t j = i / L, r = i - j * L;
+            const float a = in[in_off + j * in_stride + r];
+            const double d = (double)a;
+            acc[0] += d; acc[1] += d * d; acc[2] += (a != 0.0f) ? 1.0 : 0.0;
+        }
+    }
+    block_atomic_add<3>(acc, stats);
+}
+
+__global__ __launch_bounds__(THREADS) void norm_apply_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             int64_t L, int64_t nchunk, int64_t in_stride,
+                                                             int64_t in_off, int vec, const double* __restrict__ stats) {
+    const double nnz = stats[2];
+    const bool active = nnz > 0.0;                    // inference_utils.py:80 `if num_nonzeros > 0`
+    // inference_utils.py:81-82 in float32: mean = sum/n ; std = sqrt(sum(x^2)/n - mean^2)
+    const float nf = (float)nnz;
+    const float mean = (float)stats[0] / nf;
+    const float var = __fsub_rn((float)stats[1] / nf, __fmul_rn(mean, mean));
+    const float stdv = sqrtf(var);
+    const int64_t tid = (int64_t)blockIdx.x * THREADS + threadIdx.x, nthr = (int64_t)gridDim.x * THREADS;
+    if (vec) {
+        const int64_t L4 = L >> 2, total = L4 * nchunk;
+        for (int64_t i = tid; i < total; i += nthr) {
+            const int64_t j = i / L4, r = i - j * L4;
+            float4 v = *reinterpret_cast<const float4*>(in + in_off + j * in_stride + r * 4);
+            if (active) {
+                float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    a[k] = __fmul_rn((a[k] != 0.0f) ? 1.0f : 0.0f, __fsub_rn(a[k], mean)) / stdv;
+                v = make_float4(a[0], a[1], a[2], a[3]);
+            }
+            *reinterpret_cast<float4*>(out + j * L + r * 4) = v;
+        }
+    } else {
+        const int64_t total = L * nchunk;
+        for (int64_t i = tid; i < total; i += nthr) {
+            const int64_t j = i / L, r = i - j * L;
+            float a = in[in_off + j * in_stride + r];
+            if (active) a = __fmul_rn((a != 0.0f) ? 1.0f : 0.0f, __fsub_rn(a, mean)) / stdv;
+            out[j * L + r] = a;
+        }
+    }
+}
+
+int run_normalize(const float* in, float* out, int64_t L, int64_t nchunk, int64_t in_stride, int64_t in_off,
+                  double* stats, hipStream_t st) {
+    if (!in || !out || !stats || L < 0 || nchunk < 0) return OESS_EINVAL;
+    OESS_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(double), st));
+    if (L * nchunk == 0) return OESS_OK;
+    const int vec = ((L & 3) == 0) && ((in_stride & 3) == 0) && ((in_off & 3) == 0) &&
+                    (((uintptr_t)in & 15) == 0) && (((uintptr_t)out & 15) == 0);
+    const int grid = stream_grid(L * nchunk / (vec ? 4 : 1), THREADS * 4);
+    hipLaunchKernelGGL(norm_stats_kernel, dim3(grid), dim3(THREADS), 0, st, in, L, nchunk, in_stride, in_off, vec, stats);
+    hipLaunchKernelGGL(norm_apply_kernel, dim3(grid), dim3(THREADS), 0, st, in, out, L, nchunk, in_stride, in_off, vec,
+                       stats);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+// ------------------------------------------------------------------------------------------ K7
+// Wavefront-segmented scatter-mean.  Feature rows are pixel-major [P][Cf].  A workgroup owns a run
+// of consecutive pixels and a 64-channel slice; lane = channel, the 4 waves take interleaved
+// sub-runs.  Superpixels are spatially coherent, so each lane keeps a RUN accumulator in a register
+// and only touches LDS (ds_add_f32) when the id changes; LDS holds [256 local ids][64 ch].  Touched
+// rows are flushed with one global atomic per (workgroup, id, channel).  Raw ids outside [0,256)
+// (the reference reads uint8 PNGs, so they do not occur there) take a direct global-atomic path.
+constexpr int SEG_CH = 64;
+constexpr int SEG_LOCAL = 256;
+constexpr int SEG_PIX_PER_WG = 4096;
+
+template <bool BF16>
+__device__ __forceinline__ float load_feat(const void* feat, int64_t idx) {
+    if (BF16) return bf16_to_f32(((const uint16_t*)feat)[idx]);
+    return ((const float*)feat)[idx];
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(THREADS) void segmean_fwd_kernel(const void* __restrict__ feat,
+                                                              const int64_t* __restrict__ ids, int64_t P, int64_t pps,
+                                                              int sps, int Cf, int S, float* __restrict__ k,
+                                                              float* __restrict__ count) {
+    __shared__ float acc[SEG_LOCAL][SEG_CH];
+    __shared__ int cnt[SEG_LOCAL];
+    __shared__ int touched[SEG_LOCAL];
+    const int slice = blockIdx.y;                        // 64-channel slice
+    const int c = slice * SEG_CH + (threadIdx.x & 63);
+    const bool c_ok = c < Cf;
+    const int wave = threadIdx.x >> 6;
+    // chunk never crosses a sample boundary: chunks are laid out per sample
+    const int64_t chunks_per_sample = (pps + SEG_PIX_PER_WG - 1) / SEG_PIX_PER_WG;
+    const int64_t b = blockIdx.x / chunks_per_sample, ch = blockIdx.x - b * chunks_per_sample;
+    const int64_t p_beg = b * pps + ch * SEG_PIX_PER_WG;
+    int64_t p_end = p_beg + SEG_PIX_PER_WG;
+    if (p_end > (b + 1) * pps) p_end = (b + 1) * pps;
+    if (p_end > P) p_end = P;
+    for (int i = threadIdx.x; i < SEG_LOCAL * SEG_CH; i += THREADS) (&acc[0][0])[i] = 0.0f;
+    for (int i = threadIdx.x; i < SEG_LOCAL; i += THREADS) { cnt[i] = 0; touched[i] = 0; }
+    __syncthreads();
+    const int64_t id_off = b * (int64_t)sps;
+    // each wave walks a contiguous quarter of the chunk so that runs stay long
+    const int64_t len = p_end - p_beg;
+    const int64_t q = (len + 3) / 4;
+    int64_t w_beg = p_beg + wave * q, w_end = w_beg + q;
+    if (w_end > p_end) w_end = p_end;
+    int64_t cur = -1;                                    // current raw id of the run (wave-uniform)
+    float run = 0.0f;
+    int run_n = 0;
+    const int lane = threadIdx.x & 63;
+    auto flush = [&]() {
+        if (run_n == 0) return;
+        if (cur >= 0 && cur < SEG_LOCAL) {
+            if (c_ok) atomicAdd(&acc[cur][lane], run);
+            if (lane == 0) { atomicAdd(&cnt[cur], run_n); touched[cur] = 1; }
+        } else {
+            const int64_t gid = cur + id_off;
+            if (gid >= 0 && gid < S) {
+                if (c_ok) atomicAdd(&k[gid * Cf + c], run);
+                if (lane == 0 && slice == 0) atomicAdd(&count[gid], (float)run_n);
+            }
+        }
+    };
+    constexpr int U = 16;                                // independent loads in flight per wave
+    for (int64_t p = w_beg; p < w_end; p += U) {
+        float v[U];
+        int64_t id[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t pu = p + u;
+            const bool ok = pu < w_end;
+            id[u] = ok ? ids[pu] : cur;                  // wave-uniform address -> scalar load
+            v[u] = (ok && c_ok) ? load_feat<BF16>(feat, pu * Cf + c) : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (p + u < w_end) {
+                if (id[u] != cur) { flush(); cur = id[u]; run = 0.0f; run_n = 0; }
+                run += v[u];
+                run_n += 1;
+            }
+        }
+    }
+    flush();
+    __syncthreads();
+    for (int i = wave; i < SEG_LOCAL; i += THREADS / 64) {
+        if (!touched[i]) continue;
+        const int64_t gid = i + id_off;
+        if (gid < 0 || gid >= S) continue;
+        if (c_ok) atomicAdd(&k[gid * Cf + c], acc[i][threadIdx.x & 63]);
+        if ((threadIdx.x & 63) == 0 && slice == 0) atomicAdd(&count[gid], (float)cnt[i]);
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void segmean_finalize_kernel(float* __restrict__ k, const float* __restrict__ count,
+                                                                   int S, int Cf) {
+    const int64_t n = (int64_t)S * Cf;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS)
+        k[i] = k[i] / __fadd_rn(count[i / Cf], 1e-6f);     // pretrain_trainer.py:462
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(THREADS) void segmean_bwd_kernel(const float* __restrict__ gk, const float* __restrict__ count,
+                                                              const int64_t* __restrict__ ids, int64_t P, int64_t pps,
+                                                              int sps, int Cf, int S, void* __restrict__ gfeat) {
+    // one thread per 4 channels of one pixel
+    const int cq = Cf >> 2;
+    const int64_t total = P * cq;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * THREADS) {
+        const int64_t p = i / cq;
+        const int c4 = (int)(i - p * cq) * 4;
+        const int64_t gid = ids[p] + (p / pps) * (int64_t)sps;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gid >= 0 && gid < S) {
+            const float d = __fadd_rn(count[gid], 1e-6f);
+            const float4 s = *reinterpret_cast<const float4*>(gk + gid * Cf + c4);
+            g = make_float4(s.x / d, s.y / d, s.z / d, s.w / d);
+        }
+        if (BF16) {
+            ushort4 o;
+            o.x = f32_to_bf16(g.x); o.y = f32_to_bf16(g.y); o.z = f32_to_bf16(g.z); o.w = f32_to_bf16(g.w);
+            *reinterpret_cast<ushort4*>((uint16_t*)gfeat + p * Cf + c4) = o;
+        } else {
+            *reinterpret_cast<float4*>((float*)gfeat + p * Cf + c4) = g;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ K9
+template <bool BF16>
+__device__ __forceinline__ float load_logit(const void* base, int64_t idx) {
+    if (BF16) return bf16_to_f32(((const uint16_t*)base)[idx]);
+    return ((const float*)base)[idx];
+}
+
+struct LossGeom { int64_t P, pps, sb, sp, sc; int K, ignore; };
+
+// sums layout: inter[K] psq[K] ysum[K] ce_sum n_valid
+template <int KMAX, bool BF16>
+__global__ __launch_bounds__(THREADS) void task_loss_fwd_kernel(const void* __restrict__ logits,
+                                                                const int64_t* __restrict__ target, LossGeom g,
+                                                                double* __restrict__ sums) {
+    float inter[KMAX], psq[KMAX], ysum[KMAX];
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) { inter[c] = 0.f; psq[c] = 0.f; ysum[c] = 0.f; }
+    float ce = 0.f, nvalid = 0.f;
+    for (int64_t p = (int64_t)blockIdx.x * THREADS + threadIdx.x; p < g.P; p += (int64_t)gridDim.x * THREADS) {
+        const int64_t t = target[p];
+        if (t == g.ignore) continue;                       // mask = target != ignore (loss_functions.py:115)
+        const int64_t b = p / g.pps, r = p - b * g.pps;
+        const int64_t base = b * g.sb + r * g.sp;
+        float z[KMAX];
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c)
+            if (c < g.K) { z[c] = load_logit<BF16>(logits, base + c * g.sc); m = fmaxf(m, z[c]); }
+        float den = 0.f, zt = 0.f;
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c)
+            if (c < g.K) { const float sh = z[c] - m; if (c == t) zt = sh; z[c] = expf(sh); den += z[c]; }
+        const float inv = 1.0f / den;
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c)
+            if (c < g.K) {
+                const float pr = z[c] * inv;
+                psq[c] += pr * pr;
+                if (c == t) { inter[c] += pr; ysum[c] += 1.0f; }
+            }
+        ce += logf(den) - zt;                              // -log_softmax(z)[t]
+        nvalid += 1.0f;
+    }
+    // block reduce in double, (3K+2) values
+    __shared__ double red[THREADS / 64][3 * KMAX + 2];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) {
+        double a = wave_sum((double)inter[c]), b2 = wave_sum((double)psq[c]), y = wave_sum((double)ysum[c]);
+        if (lane == 0) { red[w][c] = a; red[w][KMAX + c] = b2; red[w][2 * KMAX + c] = y; }
+    }
+    {
+        double a = wave_sum((double)ce), b2 = wave_sum((double)nvalid);
+        if (lane == 0) { red[w][3 * KMAX] = a; red[w][3 * KMAX + 1] = b2; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * KMAX + 2; i += THREADS) {
+        double s = 0;
+        for (int k2 = 0; k2 < THREADS / 64; ++k2) s += red[k2][i];
+        int dst;
+        if (i < 3 * KMAX) { const int grp = i / KMAX, c = i % KMAX; if (c >= g.K) continue; dst = grp * g.K + c; }
+        else dst = 3 * g.K + (i - 3 * KMAX);
+        if (s != 0.0) atomicAdd(&sums[dst], s);
+    }
+}
+
+__global__ void task_loss_finalize_kernel(const double* __restrict__ sums, int K, int ignore, int flags,
+                                          float* __restrict__ loss_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float dice = 0.f;
+    for (int c = 0; c < K; ++c) {
+        if (c == ignore) continue;                          // loss_functions.py:128
+        const float num = (float)sums[c] * 2.0f + 1.0f;     // BinaryDiceLoss: smooth = 1, p = 2
+        const float den = (float)sums[K + c] + (float)sums[2 * K + c] + 1.0f;
+        dice += 1.0f - num / den;
+    }
+    dice /= (float)K;                                       // total_loss / target.shape[1]
+    const float ce = (float)(sums[3 * K] / sums[3 * K + 1]);
+    float total = 0.f;
+    if (flags & 1) total += dice;
+    if (flags & 2) total += ce;
+    loss_out[0] = total; loss_out[1] = dice; loss_out[2] = ce;
+}
+
+template <int KMAX, bool BF16, bool GBF16>
+__global__ __launch_bounds__(THREADS) void task_loss_bwd_kernel(const void* __restrict__ logits,
+                                                                const int64_t* __restrict__ target, LossGeom g,
+                                                                const double* __restrict__ sums, int flags,
+                                                                float gscale_in, const float* __restrict__ gscale_dev,
+                                                                void* __restrict__ grad) {
+    const float gscale = gscale_dev ? gscale_in * gscale_dev[0] : gscale_in;
+    __shared__ float sN[KMAX], sD[KMAX];
+    if (threadIdx.x < KMAX) {
+        const int c = threadIdx.x;
+        if (c < g.K) {
+            sN[c] = (float)sums[c] * 2.0f + 1.0f;
+            sD[c] = (float)sums[g.K + c] + (float)sums[2 * g.K + c] + 1.0f;
+        }
+    }
+    __syncthreads();
+    const float inv_nvalid = (float)(1.0 / sums[3 * g.K + 1]);
+    const float invK = 1.0f / (float)g.K;
+    for (int64_t p = (int64_t)blockIdx.x * THREADS + threadIdx.x; p < g.P; p += (int64_t)gridDim.x * THREADS) {
+        const int64_t t = target[p];
+        const int64_t b = p / g.pps, r = p - b * g.pps;
+        const int64_t base = b * g.sb + r * g.sp;
+        float dz[KMAX];
+        if (t == g.ignore) {
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c) dz[c] = 0.f;
+        } else {
+            float z[KMAX];
+            float m = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c)
+                if (c < g.K) { z[c] = load_logit<BF16>(logits, base + c * g.sc); m = fmaxf(m, z[c]); }
+            float den = 0.f;
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c)
+                if (c < g.K) { z[c] = expf(z[c] - m); den += z[c]; }
+            const float inv = 1.0f / den;
+            float gp[KMAX];
+            float dot = 0.f;
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c)
+                if (c < g.K) {
+                    const float pr = z[c] * inv;
+                    z[c] = pr;
+                    float gg = 0.f;
+                    if ((flags & 1) && c != g.ignore) {
+                        const float y = (c == t) ? 1.0f : 0.0f;
+                        gg = invK * (2.0f * pr * sN[c] - 2.0f * y * sD[c]) / (sD[c] * sD[c]);
+                    }
+                    gp[c] = gg;
+                    dot += gg * pr;
+                }
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c)
+                if (c < g.K) {
+                    float d = z[c] * (gp[c] - dot);
+                    if (flags & 2) d += (z[c] - ((c == t) ? 1.0f : 0.0f)) * inv_nvalid;
+                    dz[c] = d * gscale;
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c)
+            if (c < g.K) {
+                if (GBF16) ((uint16_t*)grad)[base + c * g.sc] = f32_to_bf16(dz[c]);
+                else ((float*)grad)[base + c * g.sc] = dz[c];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ K11
+__global__ __launch_bounds__(THREADS) void confusion_kernel(const int64_t* __restrict__ pred,
+                                                            const int64_t* __restrict__ label, int64_t n, int K,
+                                                            int ignore, unsigned long long* __restrict__ conf) {
+    extern __shared__ unsigned int hist[];     // K*K
+    for (int i = threadIdx.x; i < K * K; i += THREADS) hist[i] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS) {
+        const int64_t l = label[i];
+        if (l == ignore) continue;
+        const int64_t x = pred[i] + (int64_t)K * l;          // metrics.py:19
+        if (x >= 0 && x < (int64_t)K * K) atomicAdd(&hist[x], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * K; i += THREADS)
+        if (hist[i]) atomicAdd(&conf[i], (unsigned long long)hist[i]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int oess_masked_normalize_f32(const float* in, float* out, int64_t n, double* stats, oess_stream_t stream) {
+    return run_normalize(in, out, n, 1, 0, 0, stats, (hipStream_t)stream);
+}
+
+int oess_masked_normalize_slice_f32(const float* in, float* out, int B, int Ctot, int c0, int Cs, int64_t HW,
+                                    double* stats, oess_stream_t stream) {
+    if (B <= 0 || Ctot <= 0 || Cs <= 0 || c0 < 0 || c0 + Cs > Ctot || HW <= 0) return OESS_EINVAL;
+    return run_normalize(in, out, (int64_t)Cs * HW, B, (int64_t)Ctot * HW, (int64_t)c0 * HW, stats, (hipStream_t)stream);
+}
+
+int oess_segment_mean_fwd(const void* feat, int is_bf16, const int64_t* ids, int64_t P, int64_t pixels_per_sample,
+                          int superpixel_size, int Cf, int S, float* k, float* count, oess_stream_t stream) {
+    if (!feat || !ids || !k || !count || P <= 0 || pixels_per_sample <= 0 || Cf <= 0 || S <= 0) return OESS_EINVAL;
+    if (P % pixels_per_sample != 0) return OESS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    OESS_HIP(hipMemsetAsync(k, 0, (size_t)S * Cf * sizeof(float), st));
+    OESS_HIP(hipMemsetAsync(count, 0, (size_t)S * sizeof(float), st));
+    const int64_t B = P / pixels_per_sample;
+    const int64_t chunks = (pixels_per_sample + SEG_PIX_PER_WG - 1) / SEG_PIX_PER_WG;
+    dim3 grid((unsigned)(B * chunks), (unsigned)((Cf + SEG_CH - 1) / SEG_CH));
+    if (is_bf16)
+        hipLaunchKernelGGL(segmean_fwd_kernel<true>, grid, dim3(THREADS), 0, st, feat, ids, P, pixels_per_sample,
+                           superpixel_size, Cf, S, k, count);
+    else
+        hipLaunchKernelGGL(segmean_fwd_kernel<false>, grid, dim3(THREADS), 0, st, feat, ids, P, pixels_per_sample,
+                           superpixel_size, Cf, S, k, count);
+    hipLaunchKernelGGL(segmean_finalize_kernel, dim3(stream_grid((int64_t)S * Cf, THREADS)), dim3(THREADS), 0, st, k,
+                       count, S, Cf);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_segment_mean_bwd(const float* grad_k, const float* count, const int64_t* ids, int64_t P,
+                          int64_t pixels_per_sample, int superpixel_size, int Cf, int S, void* grad_feat, int is_bf16,
+                          oess_stream_t stream) {
+    if (!grad_k || !count || !ids || !grad_feat || P <= 0 || pixels_per_sample <= 0 || Cf <= 0 || (Cf & 3) || S <= 0)
+        return OESS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = stream_grid(P * (Cf / 4), THREADS * 4);
+    if (is_bf16)
+        hipLaunchKernelGGL(segmean_bwd_kernel<true>, dim3(grid), dim3(THREADS), 0, st, grad_k, count, ids, P,
+                           pixels_per_sample, superpixel_size, Cf, S, grad_feat);
+    else
+        hipLaunchKernelGGL(segmean_bwd_kernel<false>, dim3(grid), dim3(THREADS), 0, st, grad_k, count, ids, P,
+                           pixels_per_sample, superpixel_size, Cf, S, grad_feat);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_task_loss_fwd(const void* logits, int is_bf16, const int64_t* target, int64_t P, int64_t pixels_per_sample,
+                       int64_t stride_b, int64_t stride_p, int64_t stride_c, int K, int ignore_index, int flags,
+                       double* sums, float* loss_out, oess_stream_t stream) {
+    if (!logits || !target || !sums || !loss_out || P <= 0 || pixels_per_sample <= 0 || K <= 0 || K > 32)
+        return OESS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    OESS_HIP(hipMemsetAsync(sums, 0, (size_t)(3 * K + 2) * sizeof(double), st));
+    LossGeom g{P, pixels_per_sample, stride_b, stride_p, stride_c, K, ignore_index};
+    const int grid = stream_grid(P, THREADS * 4);
+#define LAUNCH_FWD(KM)                                                                                              \
+    do {                                                                                                            \
+        if (is_bf16)                                                                                                \
+            hipLaunchKernelGGL((task_loss_fwd_kernel<KM, true>), dim3(grid), dim3(THREADS), 0, st, logits, target, g, sums); \
+        else                                                                                                        \
+            hipLaunchKernelGGL((task_loss_fwd_kernel<KM, false>), dim3(grid), dim3(THREADS), 0, st, logits, target, g, sums); \
+    } while (0)
+    if (K <= 8) LAUNCH_FWD(8); else if (K <= 16) LAUNCH_FWD(16); else LAUNCH_FWD(32);
+#undef LAUNCH_FWD
+    hipLaunchKernelGGL(task_loss_finalize_kernel, dim3(1), dim3(64), 0, st, sums, K, ignore_index, flags, loss_out);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_task_loss_bwd(const void* logits, int is_bf16, const int64_t* target, int64_t P, int64_t pixels_per_sample,
+                       int64_t stride_b, int64_t stride_p, int64_t stride_c, int K, int ignore_index, int flags,
+                       const double* sums, float grad_scale, const float* grad_scale_dev, void* grad_logits,
+                       int grad_is_bf16, oess_stream_t stream) {
+    if (!logits || !target || !sums || !grad_logits || P <= 0 || pixels_per_sample <= 0 || K <= 0 || K > 32)
+        return OESS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    LossGeom g{P, pixels_per_sample, stride_b, stride_p, stride_c, K, ignore_index};
+    const int grid = stream_grid(P, THREADS * 4);
+#define LAUNCH_BWD(KM, A, B)                                                                                   \
+    hipLaunchKernelGGL((task_loss_bwd_kernel<KM, A, B>), dim3(grid), dim3(THREADS), 0, st, logits, target, g, sums, \
+                       flags, grad_scale, grad_scale_dev, grad_logits)
+#define DISPATCH_BWD(KM)                                                       \
+    do {                                                                       \
+        if (is_bf16 && grad_is_bf16) LAUNCH_BWD(KM, true, true);               \
+        else if (is_bf16) LAUNCH_BWD(KM, true, false);                         \
+        else if (grad_is_bf16) LAUNCH_BWD(KM, false, true);                    \
+        else LAUNCH_BWD(KM, false, false);                                     \
+    } while (0)
+    if (K <= 8) DISPATCH_BWD(8); else if (K <= 16) DISPATCH_BWD(16); else DISPATCH_BWD(32);
+#undef DISPATCH_BWD
+#undef LAUNCH_BWD
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_confusion_accumulate(const int64_t* pred, const int64_t* label, int64_t n, int K, int ignore_label,
+                              int64_t* conf, oess_stream_t stream) {
+    if (!pred || !label || !conf || n < 0 || K <= 0 || K > 256) return OESS_EINVAL;
+    if (n == 0) return OESS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = stream_grid(n, THREADS * 8);
+    hipLaunchKernelGGL(confusion_kernel, dim3(grid), dim3(THREADS), (size_t)K * K * sizeof(unsigned int), st, pred,
+                       label, n, K, ignore_label, (unsigned long long*)conf);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+}  // extern "C"

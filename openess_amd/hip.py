@@ -1,0 +1,285 @@
+"""Thin tensor-level wrappers over the liboess C-ABI (include/oess.h).
+
+PyTorch is plumbing only here: device memory (tensors), the current HIP stream and autograd
+bookkeeping.  Every function enqueues hand-written HIP kernels on the CURRENT torch stream and
+raises if the library is missing or a tensor is not on the GPU -- there is no CPU/eager fallback.
+"""
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("openess_amd HIP path needs CUDA/HIP tensors (no CPU fallback)")
+
+
+_WS_CACHE = {}
+
+
+def _workspace(nbytes, device, tag="ws"):
+    key = (tag, device.index)
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _WS_CACHE[key] = ws
+    return ws
+
+
+def _seg_info(seg_offsets):
+    """seg_offsets: 1-D int64 (CPU or GPU). Returns (device tensor, n_seg, max_len) -- max_len is
+    computed on the host copy so that no device sync is needed when offsets come from the loader."""
+    if seg_offsets.is_cuda:
+        host = seg_offsets.cpu()
+        dev = seg_offsets
+    else:
+        host = seg_offsets
+        dev = None
+    host = host.to(torch.int64)
+    n_seg = host.numel() - 1
+    lens = host[1:] - host[:-1]
+    if n_seg < 1 or bool((lens < 0).any()):
+        raise ValueError("seg_offsets must be non-decreasing with at least 2 entries")
+    return host, dev, n_seg, int(lens.max().item()), int(host[-1].item())
+
+
+# ------------------------------------------------------------------------------------------ K1
+def voxelize_trilinear(x, y, p, t, seg_offsets, C, H, W, crop_rows=0, count_mode=False, out=None):
+    """Batched VoxelGrid.convert: returns (n_seg*C) x (H-crop_rows) x W float32 on the GPU."""
+    lib = _lib.load()
+    _need_gpu(x, y, p, t)
+    for a in (x, y, p, t):
+        if a.dtype != torch.float32 or not a.is_contiguous() or a.ndim != 1:
+            raise ValueError("x, y, p, t must be contiguous 1-D float32")
+    host, dev, n_seg, max_len, n_ev = _seg_info(seg_offsets)
+    if n_ev > x.numel():
+        raise ValueError("seg_offsets exceed the event arrays")
+    if dev is None:
+        dev = host.to(x.device, non_blocking=True)
+    if out is None:
+        out = torch.empty((n_seg * C, H - crop_rows, W), dtype=torch.float32, device=x.device)
+    nbytes = lib.oess_voxelize_workspace_bytes(x.numel(), n_seg, C, H, W, crop_rows)
+    ws = _workspace(nbytes, x.device)
+    _lib.check(lib.oess_voxelize_trilinear_f32(_ptr(x), _ptr(y), _ptr(p), _ptr(t), _ptr(dev), n_seg, max_len, C, H, W,
+                                               crop_rows, int(count_mode), _ptr(out), _ptr(ws), ws.numel(), _stream()),
+               "oess_voxelize_trilinear_f32")
+    return out
+
+
+def voxelize_dsec_raw(x, y, t_us, p, rectify_maps, seg_map, seg_offsets, C, H, W, crop_rows=0, count_mode=False,
+                      out=None):
+    """Raw DSEC columns (uint16 x,y; int64 t; uint8 p) + rectify maps [n_maps,H,W,2] -> voxel tensor."""
+    lib = _lib.load()
+    _need_gpu(x, y, t_us, p, rectify_maps, seg_map)
+    if x.dtype != torch.uint16 or y.dtype != torch.uint16 or t_us.dtype != torch.int64 or p.dtype != torch.uint8:
+        raise ValueError("raw DSEC dtypes are x,y:uint16  t:int64  p:uint8")
+    if rectify_maps.dtype != torch.float32 or rectify_maps.ndim != 4 or tuple(rectify_maps.shape[1:]) != (H, W, 2):
+        raise ValueError("rectify_maps must be float32 [n_maps, H, W, 2]")
+    host, dev, n_seg, max_len, n_ev = _seg_info(seg_offsets)
+    if n_ev > x.numel():
+        raise ValueError("seg_offsets exceed the event arrays")
+    if dev is None:
+        dev = host.to(x.device, non_blocking=True)
+    seg_map = seg_map.to(torch.int32)
+    if seg_map.numel() != n_seg:
+        raise ValueError("seg_map needs one entry per segment")
+    if out is None:
+        out = torch.empty((n_seg * C, H - crop_rows, W), dtype=torch.float32, device=x.device)
+    nbytes = lib.oess_voxelize_workspace_bytes(x.numel(), n_seg, C, H, W, crop_rows)
+    ws = _workspace(nbytes, x.device)
+    _lib.check(lib.oess_voxelize_dsec_raw(_ptr(x), _ptr(y), _ptr(t_us), _ptr(p), _ptr(rectify_maps.contiguous()),
+                                          _ptr(seg_map), rectify_maps.shape[0], _ptr(dev), n_seg, max_len, C, H, W,
+                                          crop_rows, int(count_mode), _ptr(out), _ptr(ws), ws.numel(), _stream()),
+               "oess_voxelize_dsec_raw")
+    return out
+
+
+def voxelize_nearest(events, seg_offsets, nbins, H, W, crop_rows=0, separate_pol=True, count_mode=False, out=None):
+    """Batched generate_voxel_grid over [N x 4] (x, y, t, p) int64 or float64 events."""
+    lib = _lib.load()
+    _need_gpu(events)
+    if events.ndim != 2 or events.shape[1] != 4 or not events.is_contiguous():
+        raise ValueError("events must be contiguous [N x 4]")
+    host, dev, n_seg, max_len, n_ev = _seg_info(seg_offsets)
+    if n_ev > events.shape[0]:
+        raise ValueError("seg_offsets exceed the event array")
+    if dev is None:
+        dev = host.to(events.device, non_blocking=True)
+    ch = 2 * nbins if separate_pol else nbins
+    if out is None:
+        out = torch.empty((n_seg * ch, H - crop_rows, W), dtype=torch.float32, device=events.device)
+    nbytes = lib.oess_voxelize_workspace_bytes(events.shape[0], n_seg, 2 * nbins, H, W, crop_rows)
+    ws = _workspace(nbytes, events.device)
+    if events.dtype == torch.int64:
+        fn, name = lib.oess_voxelize_nearest_i64, "oess_voxelize_nearest_i64"
+    elif events.dtype == torch.float64:
+        fn, name = lib.oess_voxelize_nearest_f64, "oess_voxelize_nearest_f64"
+    else:
+        raise ValueError("events must be int64 or float64")
+    _lib.check(fn(_ptr(events), _ptr(dev), n_seg, max_len, nbins, H, W, crop_rows, int(separate_pol), int(count_mode),
+                  _ptr(out), _ptr(ws), ws.numel(), _stream()), name)
+    return out
+
+
+def event_histogram(events, seg_offsets, H, W):
+    lib = _lib.load()
+    _need_gpu(events)
+    if events.dtype != torch.int64 or events.ndim != 2 or events.shape[1] != 4 or not events.is_contiguous():
+        raise ValueError("events must be contiguous int64 [N x 4]")
+    host, dev, n_seg, max_len, _ = _seg_info(seg_offsets)
+    if dev is None:
+        dev = host.to(events.device, non_blocking=True)
+    out = torch.empty((n_seg * 2, H, W), dtype=torch.float32, device=events.device)
+    _lib.check(lib.oess_event_histogram_i64(_ptr(events), _ptr(dev), n_seg, max_len, H, W, _ptr(out), _stream()),
+               "oess_event_histogram_i64")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ K2
+def masked_normalize(x, out=None):
+    """EventPreprocessor / normalize_voxel_grid on a dense float32 tensor (whole-tensor statistics)."""
+    lib = _lib.load()
+    _need_gpu(x)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("masked_normalize needs a contiguous float32 tensor")
+    if out is None:
+        out = torch.empty_like(x)
+    stats = torch.empty(4, dtype=torch.float64, device=x.device)
+    _lib.check(lib.oess_masked_normalize_f32(_ptr(x), _ptr(out), x.numel(), _ptr(stats), _stream()),
+               "oess_masked_normalize_f32")
+    return out
+
+
+def masked_normalize_slice(x, c0, cs, out=None):
+    """Normalise the channel slice x[:, c0:c0+cs] of a contiguous [B, C, H, W] float32 tensor."""
+    lib = _lib.load()
+    _need_gpu(x)
+    if x.dtype != torch.float32 or not x.is_contiguous() or x.ndim != 4:
+        raise ValueError("needs contiguous float32 [B, C, H, W]")
+    B, Ct, H, W = x.shape
+    if out is None:
+        out = torch.empty((B, cs, H, W), dtype=torch.float32, device=x.device)
+    stats = torch.empty(4, dtype=torch.float64, device=x.device)
+    _lib.check(lib.oess_masked_normalize_slice_f32(_ptr(x), _ptr(out), B, Ct, c0, cs, H * W, _ptr(stats), _stream()),
+               "oess_masked_normalize_slice_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ K7
+class _SegmentMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat_pm, ids, pps, sps, S):
+        lib = _lib.load()
+        P, Cf = feat_pm.shape
+        k = torch.empty((S, Cf), dtype=torch.float32, device=feat_pm.device)
+        cnt = torch.empty((S,), dtype=torch.float32, device=feat_pm.device)
+        is_bf16 = int(feat_pm.dtype == torch.bfloat16)
+        _lib.check(lib.oess_segment_mean_fwd(_ptr(feat_pm), is_bf16, _ptr(ids), P, pps, sps, Cf, S, _ptr(k), _ptr(cnt),
+                                             _stream()), "oess_segment_mean_fwd")
+        ctx.save_for_backward(ids, cnt)
+        ctx.meta = (P, Cf, pps, sps, S, feat_pm.dtype)
+        return k
+
+    @staticmethod
+    def backward(ctx, gk):
+        lib = _lib.load()
+        ids, cnt = ctx.saved_tensors
+        P, Cf, pps, sps, S, dtype = ctx.meta
+        gk = gk.contiguous().float()
+        gfeat = torch.empty((P, Cf), dtype=dtype, device=gk.device)
+        _lib.check(lib.oess_segment_mean_bwd(_ptr(gk), _ptr(cnt), _ptr(ids), P, pps, sps, Cf, S, _ptr(gfeat),
+                                             int(dtype == torch.bfloat16), _stream()), "oess_segment_mean_bwd")
+        return gfeat, None, None, None, None
+
+
+def segment_mean(feat_pm, ids, pixels_per_sample, superpixel_size, S):
+    """Superpixel scatter-mean.  feat_pm: pixel-major [P, Cf] (fp32/bf16); ids: [P] int64 raw ids."""
+    _need_gpu(feat_pm, ids)
+    if feat_pm.dtype not in (torch.float32, torch.bfloat16) or not feat_pm.is_contiguous() or feat_pm.ndim != 2:
+        raise ValueError("feat must be contiguous [P, Cf] float32/bfloat16")
+    if feat_pm.shape[1] % 4:
+        raise ValueError("channel count must be a multiple of 4")
+    ids = ids.reshape(-1).contiguous().to(torch.int64)
+    return _SegmentMean.apply(feat_pm, ids, int(pixels_per_sample), int(superpixel_size), int(S))
+
+
+def superpixel_pool(feat_nchw, superpixels, superpixel_size, S=None):
+    """Drop-in for the inline block of training/pretrain_trainer.py:445-465.  feat_nchw is logically
+    B x C x H x W (any memory format; channels_last is free), superpixels B x H x W int64."""
+    B, C, H, W = feat_nchw.shape
+    if S is None:   # data-dependent size exactly like sparse_coo_tensor (costs one device sync)
+        off = torch.arange(0, B * superpixel_size, superpixel_size, device=superpixels.device)[:, None, None]
+        S = int((superpixels + off).max().item()) + 1
+    pm = feat_nchw.permute(0, 2, 3, 1).contiguous().view(B * H * W, C)
+    return segment_mean(pm, superpixels, H * W, superpixel_size, S)
+
+
+# ------------------------------------------------------------------------------------------ K9
+class _TaskLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, K, ignore_index, flags, strides):
+        lib = _lib.load()
+        P, pps, sb, sp, sc = strides
+        sums = torch.empty(3 * K + 2, dtype=torch.float64, device=logits.device)
+        loss = torch.empty(3, dtype=torch.float32, device=logits.device)
+        is_bf16 = int(logits.dtype == torch.bfloat16)
+        _lib.check(lib.oess_task_loss_fwd(_ptr(logits), is_bf16, _ptr(target), P, pps, sb, sp, sc, K, ignore_index,
+                                          flags, _ptr(sums), _ptr(loss), _stream()), "oess_task_loss_fwd")
+        ctx.save_for_backward(logits, target, sums)
+        ctx.meta = (K, ignore_index, flags, strides)
+        return loss[0], loss[1:].clone()
+
+    @staticmethod
+    def backward(ctx, g_total, _g_parts):
+        lib = _lib.load()
+        logits, target, sums = ctx.saved_tensors
+        K, ignore_index, flags, (P, pps, sb, sp, sc) = ctx.meta
+        grad = torch.empty_like(logits)
+        gdev = g_total.reshape(1).float().contiguous()          # device scalar: no host sync
+        _lib.check(lib.oess_task_loss_bwd(_ptr(logits), int(logits.dtype == torch.bfloat16), _ptr(target), P, pps, sb,
+                                          sp, sc, K, ignore_index, flags, _ptr(sums), 1.0, _ptr(gdev), _ptr(grad),
+                                          int(grad.dtype == torch.bfloat16), _stream()), "oess_task_loss_bwd")
+        return grad, None, None, None, None, None
+
+
+def task_loss(logits, target, num_classes, ignore_index=255, losses=("dice", "cross_entropy")):
+    """TaskLoss (Dice + CE).  logits: logically B x K x H x W, contiguous either as NCHW or as
+    channels_last (NHWC); float32 or bfloat16.  Returns (total, [dice, ce])."""
+    _need_gpu(logits, target)
+    B, K, H, W = logits.shape
+    if K != num_classes:
+        raise ValueError("logits channel count != num_classes")
+    if logits.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("logits must be float32 or bfloat16")
+    if logits.is_contiguous():
+        strides = (B * H * W, H * W, K * H * W, 1, H * W)
+    elif logits.is_contiguous(memory_format=torch.channels_last):
+        strides = (B * H * W, H * W, H * W * K, K, 1)
+    else:
+        logits = logits.contiguous()
+        strides = (B * H * W, H * W, K * H * W, 1, H * W)
+    target = target.reshape(-1).contiguous().to(torch.int64)
+    flags = (1 if "dice" in losses else 0) | (2 if "cross_entropy" in losses else 0)
+    return _TaskLoss.apply(logits, target, K, int(ignore_index), flags, strides)
+
+
+# ------------------------------------------------------------------------------------------ K11
+def confusion_accumulate(pred, label, num_classes, ignore_label, conf):
+    lib = _lib.load()
+    _need_gpu(pred, label, conf)
+    pred = pred.reshape(-1).contiguous().to(torch.int64)
+    label = label.reshape(-1).contiguous().to(torch.int64)
+    if conf.dtype != torch.int64 or conf.numel() != num_classes * num_classes or not conf.is_contiguous():
+        raise ValueError("conf must be contiguous int64 K*K")
+    _lib.check(lib.oess_confusion_accumulate(_ptr(pred), _ptr(label), pred.numel(), num_classes, ignore_label,
+                                             _ptr(conf), _stream()), "oess_confusion_accumulate")
+    return conf

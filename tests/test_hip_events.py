@@ -1,0 +1,194 @@
+"""GPU parity: HIP voxelizers / normaliser (through the C-ABI) vs the oracle and the committed
+golden vectors.  Indices are checked bit-exactly (count mode, integer-coordinate fixtures);
+float values within an absolute tolerance that covers only the LDS-atomic summation order."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import events as oe
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+ATOL = 2e-5      # |sum| stays O(10) at these densities; fp32 order-of-summation noise only
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def seg(*lens):
+    return torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int64)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_trilinear_golden(golden_events, tag):
+    from openess_amd import hip
+    g = golden_events
+    C, H, W = (int(v) for v in g[f"tri_{tag}_chw"])
+    x, y, p, t = (dev(g[f"tri_{tag}_{k}"]) for k in "xypt")
+    out = hip.voxelize_trilinear(x, y, p, t, seg(x.numel()), C, H, W).cpu().numpy()
+    np.testing.assert_allclose(out, g[f"tri_{tag}_out_norm0"], rtol=0, atol=ATOL)
+    # indices: count mode vs oracle count mode, exact
+    cnt = hip.voxelize_trilinear(x, y, p, t, seg(x.numel()), C, H, W, count_mode=True).cpu().numpy()
+    ref = oe.voxelgrid_trilinear(g[f"tri_{tag}_x"], g[f"tri_{tag}_y"], g[f"tri_{tag}_p"], g[f"tri_{tag}_t"], C, H, W,
+                                 count_mode=True)
+    assert np.array_equal(cnt, ref)
+
+
+def test_trilinear_integer_coords_bit_exact(golden_events):
+    from openess_amd import hip
+    g = golden_events
+    C, H, W = (int(v) for v in g["tri_int_chw"])
+    x, y, p, t = (dev(g[f"tri_int_{k}"]) for k in "xypt")
+    out = hip.voxelize_trilinear(x, y, p, t, seg(x.numel()), C, H, W).cpu().numpy()
+    assert np.array_equal(out, g["tri_int_out"])
+
+
+def test_trilinear_segments_crop_and_edges():
+    """Ragged segments incl. empty, single-event (0/0 -> NaN time -> nothing) and all-equal timestamps."""
+    from openess_amd import hip
+    rng = np.random.default_rng(3)
+    C, H, W, crop = 5, 70, 150, 6
+    lens = [4000, 0, 1, 2500, 37, 3000]
+    N = sum(lens)
+    x = rng.uniform(-2, W + 1, N).astype(np.float32)
+    y = rng.uniform(-2, H + 1, N).astype(np.float32)
+    p = rng.integers(0, 2, N).astype(np.float32)
+    t = np.empty(N, np.float32)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for i, n in enumerate(lens):
+        if n:
+            tt = np.sort(rng.uniform(0, 1, n)).astype(np.float32)
+            tt[0], tt[-1] = 0, 1 if n > 1 else 0
+            t[off[i]:off[i + 1]] = tt
+    t[off[4]:off[5]] = 0.25          # all-equal timestamps in segment 4
+    for cm in (False, True):
+        out = hip.voxelize_trilinear(dev(x), dev(y), dev(p), dev(t), seg(*lens), C, H, W, crop_rows=crop,
+                                     count_mode=cm).cpu().numpy()
+        assert out.shape == (len(lens) * C, H - crop, W)
+        for i, n in enumerate(lens):
+            s, e = off[i], off[i + 1]
+            ref = np.zeros((C, H, W), np.float32) if n == 0 else \
+                oe.voxelgrid_trilinear(x[s:e], y[s:e], p[s:e], t[s:e], C, H, W, count_mode=cm)
+            ref = ref[:, :H - crop]
+            got = out[i * C:(i + 1) * C]
+            if cm:
+                assert np.array_equal(got, ref), i
+            else:
+                np.testing.assert_allclose(got, ref, rtol=0, atol=ATOL)
+    assert not out[C:2 * C].any() and not out[2 * C:3 * C].any() and not out[4 * C:5 * C].any()
+
+
+def test_dsec_raw_matches_oracle_full_sensor():
+    """Raw uint16/int64/uint8 columns + rectify map, DSEC sensor size, 2 samples x 3 sub-windows."""
+    from openess_amd import hip
+    C, H, W, crop, nwin, n_per = 5, 480, 640, 40, 3, 30000
+    rmap = synth.rectify_map(H, W)
+    outs_ref, xs, ys, ts, ps = [], [], [], [], []
+    for b in range(2):
+        x, y, t, p = synth.dsec_raw_events(nwin * n_per, H, W, seed=1205 + b)
+        xs.append(x); ys.append(y); ts.append(t); ps.append(p)
+    maps = dev(np.stack([rmap, synth.rectify_map(H, W, seed=9)]))
+    seg_map = torch.tensor([0] * nwin + [1] * nwin, dtype=torch.int32).cuda()
+    so = seg(*([n_per] * (2 * nwin)))
+    args = (dev(np.concatenate(xs)), dev(np.concatenate(ys)), dev(np.concatenate(ts)), dev(np.concatenate(ps)), maps,
+            seg_map, so, C, H, W)
+    for cm in (True, False):
+        out = hip.voxelize_dsec_raw(*args, crop_rows=crop, count_mode=cm).cpu().numpy()
+        for b in range(2):
+            ref = oe.dsec_event_tensor(xs[b], ys[b], ts[b], ps[b], maps[b].cpu().numpy(), nwin, C, H, W, crop,
+                                       count_mode=cm)
+            got = out[b * nwin * C:(b + 1) * nwin * C]
+            if cm:
+                assert np.array_equal(got, ref)
+            else:
+                np.testing.assert_allclose(got, ref, rtol=0, atol=ATOL)
+
+
+def test_trilinear_full_batch_properties():
+    """BASELINE size (8 samples x 20 sub-windows x 100k events, 640x480): size-independent properties."""
+    from openess_amd import hip
+    C, H, W, crop, nwin, n_per, B = 5, 480, 640, 40, 20, 100000, 8
+    rng = np.random.default_rng(5)
+    N = B * nwin * n_per
+    x = torch.from_numpy(rng.uniform(0, W - 1, N).astype(np.float32)).cuda()
+    y = torch.from_numpy(rng.uniform(0, H - 1, N).astype(np.float32)).cuda()
+    p = torch.from_numpy(rng.integers(0, 2, N).astype(np.float32)).cuda()
+    tt = np.sort(rng.uniform(0, 1, (B * nwin, n_per)).astype(np.float32), axis=1)
+    tt[:, 0], tt[:, -1] = 0, 1
+    t = torch.from_numpy(tt.reshape(-1)).cuda()
+    so = seg(*([n_per] * (B * nwin)))
+    out = hip.voxelize_trilinear(x, y, p, t, so, C, H, W, crop_rows=crop)
+    assert out.shape == (B * nwin * C, H - crop, W)
+    # (1) antisymmetry under polarity flip: value -> -value, same indices
+    out_neg = hip.voxelize_trilinear(x, y, 1 - p, t, so, C, H, W, crop_rows=crop)
+    assert float((out + out_neg).abs().max()) <= 1e-4
+    # (2) partition of unity: with all-positive polarity and in-range coordinates, every event deposits
+    #     exactly weight 1 in total over the UNCROPPED grid -> per-segment sum == event count
+    full = hip.voxelize_trilinear(x, y, torch.ones_like(p), t, so, C, H, W, crop_rows=0)
+    sums = full.view(B * nwin, -1).double().sum(1).cpu().numpy()
+    np.testing.assert_allclose(sums, n_per, rtol=2e-5)
+    # (3) the cropped result is the row-slice of the uncropped one (same kernel, different tiling)
+    full_c = hip.voxelize_trilinear(x, y, p, t, so, C, H, W, crop_rows=0)
+    assert float((full_c[:, :H - crop] - out).abs().max()) <= 1e-4
+    # (4) count mode: integer grid whose total equals the number of in-grid corners (8 per interior event)
+    cnt = hip.voxelize_trilinear(x, y, p, t, so, C, H, W, crop_rows=0, count_mode=True)
+    assert bool((cnt == cnt.round()).all())
+    t_norm = (4 * t.view(B * nwin, n_per))
+    n_t = torch.where(t_norm.int() + 1 < C, 2, 1).sum().item()     # t0+1 == C is masked out
+    assert int(cnt.double().sum().item()) == 4 * n_t
+
+
+@pytest.mark.parametrize("bins", [5, 2, 1])
+@pytest.mark.parametrize("sp", [0, 1])
+def test_nearest_golden(golden_events, bins, sp):
+    from openess_amd import hip
+    g = golden_events
+    H, W = (int(v) for v in g["near_hw"])
+    ev = dev(g["near_ev"])
+    out = hip.voxelize_nearest(ev, seg(ev.shape[0]), bins, H, W, separate_pol=bool(sp)).cpu().numpy()
+    np.testing.assert_allclose(out, g[f"near_out_b{bins}_sp{sp}"], rtol=0, atol=ATOL)
+    cnt = hip.voxelize_nearest(ev, seg(ev.shape[0]), bins, H, W, separate_pol=bool(sp), count_mode=True).cpu().numpy()
+    assert np.array_equal(cnt, oe.voxelgrid_nearest(g["near_ev"], (H, W), bins, bool(sp), count_mode=True))
+
+
+def test_nearest_edge_cases(golden_events):
+    from openess_amd import hip
+    g = golden_events
+    H, W = (int(v) for v in g["near_hw"])
+    for key, outk, sp in (("near_evf", "near_outf_b5_sp0", False), ("near_ev0", "near_out0_b5_sp0", False),
+                          ("near_ev1", "near_out1_b5_sp1", True)):
+        ev = dev(g[key])
+        out = hip.voxelize_nearest(ev, seg(ev.shape[0]), 5, H, W, separate_pol=sp).cpu().numpy()
+        np.testing.assert_allclose(out, g[outk], rtol=0, atol=ATOL)
+
+
+def test_nearest_ddd17_sample():
+    """DDD17-shaped sample: 20 chunks x 32000 events on 260x346, crop 60 rows (config 1 plumbing)."""
+    from openess_amd import hip
+    H, W, nchunk, n_per = 260, 346, 20, 32000
+    ev = synth.ddd17_events(nchunk * n_per, H, W, seed=11)
+    so = seg(*([n_per] * nchunk))
+    for bins, sp in ((5, False), (2, True)):
+        out = hip.voxelize_nearest(dev(ev), so, bins, H, W, crop_rows=60, separate_pol=sp).cpu().numpy()
+        ref = oe.ddd17_event_tensor(ev, nchunk, (H, W), bins, sp, crop_rows=60)
+        np.testing.assert_allclose(out, ref, rtol=0, atol=ATOL)
+        cnt = hip.voxelize_nearest(dev(ev), so, bins, H, W, crop_rows=60, separate_pol=sp, count_mode=True).cpu().numpy()
+        assert np.array_equal(cnt, oe.ddd17_event_tensor(ev, nchunk, (H, W), bins, sp, crop_rows=60, count_mode=True))
+
+
+def test_histogram_and_normalize(golden_events):
+    from openess_amd import hip
+    g = golden_events
+    H, W = (int(v) for v in g["near_hw"])
+    ev = dev(g["hist_ev"])
+    out = hip.event_histogram(ev, seg(ev.shape[0]), H, W).cpu().numpy()
+    assert np.array_equal(out, g["hist_out"])
+    n = hip.masked_normalize(dev(g["norm_in"])).cpu().numpy()
+    np.testing.assert_allclose(n, g["norm_out"], rtol=2e-5, atol=2e-6)
+    z = hip.masked_normalize(torch.zeros(2, 3, 4, device="cuda")).cpu().numpy()
+    assert np.array_equal(z, g["norm_zero_out"])
+    # slice variant == dense variant on the sliced copy, and == oracle
+    x = torch.randn(2, 10, 6, 8, device="cuda") * (torch.rand(2, 10, 6, 8, device="cuda") > 0.6)
+    a = hip.masked_normalize_slice(x, 5, 5).cpu().numpy()
+    np.testing.assert_allclose(a, oe.masked_normalize(x[:, 5:10].cpu().numpy()), rtol=2e-5, atol=2e-6)

@@ -1,0 +1,106 @@
+"""GPU parity: fused Dice+CE, superpixel scatter-mean (fwd+bwd) and confusion matrix vs golden
+vectors produced by the reference (fp32 tolerance stated per check; integers exact)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import losses as ol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tag,K", [("a", 11), ("b", 6)])
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_task_loss_golden(golden_losses, tag, K, layout):
+    from openess_amd import hip
+    g = golden_losses
+    lg = torch.from_numpy(g[f"task_{tag}_logits"]).cuda()
+    if layout == "nhwc":
+        lg = lg.contiguous(memory_format=torch.channels_last)
+    lg.requires_grad_(True)
+    tgt = torch.from_numpy(g[f"task_{tag}_target"]).cuda()
+    total, parts = hip.task_loss(lg, tgt, K)
+    (total * 1.0).backward()
+    np.testing.assert_allclose(total.item(), g[f"task_{tag}_loss"], rtol=2e-6)
+    np.testing.assert_allclose(parts[0].item(), g[f"dice_{tag}_loss"], rtol=2e-6)
+    np.testing.assert_allclose(lg.grad.cpu().numpy(), g[f"task_{tag}_grad"], rtol=1e-4, atol=1e-8)
+    lg2 = torch.from_numpy(g[f"task_{tag}_logits"]).cuda().requires_grad_(True)
+    d, _ = hip.task_loss(lg2, tgt, K, losses=("dice",))
+    (3.0 * d).backward()            # upstream scale goes through the device scalar
+    np.testing.assert_allclose(lg2.grad.cpu().numpy(), 3.0 * g[f"dice_{tag}_grad"], rtol=1e-4, atol=1e-8)
+
+
+def test_task_loss_full_size_vs_oracle():
+    """DSEC size 2 x 11 x 440 x 640 (bf16 NHWC logits as produced by the decoder) vs fp32 oracle."""
+    from openess_amd import hip
+    torch.manual_seed(0)
+    B, K, H, W = 2, 11, 440, 640
+    lg = (torch.randn(B, K, H, W) * 3).bfloat16()
+    tgt = torch.randint(0, K, (B, H, W))
+    tgt[torch.rand(B, H, W) < 0.05] = 255
+    ref_in = lg.float().requires_grad_(True)
+    ref = ol.task_loss(ref_in, tgt, K)
+    ref.backward()
+    x = lg.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    total, _ = hip.task_loss(x, tgt.cuda(), K)
+    total.backward()
+    np.testing.assert_allclose(total.item(), ref.item(), rtol=1e-5)
+    # gradient is stored as bf16: 2^-8 relative
+    np.testing.assert_allclose(x.grad.float().cpu().numpy(), ref_in.grad.numpy(), rtol=1e-2, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_superpixel_pool_golden(golden_losses, tag):
+    from openess_amd import hip
+    g = golden_losses
+    fk = torch.from_numpy(g[f"sp_{tag}_feat_k"]).cuda().requires_grad_(True)
+    fq = torch.from_numpy(g[f"sp_{tag}_feat_q"]).cuda().requires_grad_(True)
+    ids = torch.from_numpy(g[f"sp_{tag}_ids"]).cuda()
+    sps = int(g[f"sp_{tag}_size"])
+    k = hip.superpixel_pool(fk, ids, sps)
+    q = hip.superpixel_pool(fq, ids, sps)
+    assert tuple(k.shape) == g[f"sp_{tag}_k"].shape          # S = max id + 1, data dependent
+    np.testing.assert_allclose(k.detach().cpu().numpy(), g[f"sp_{tag}_k"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(q.detach().cpu().numpy(), g[f"sp_{tag}_q"], rtol=1e-5, atol=1e-6)
+    w = torch.from_numpy(g[f"sp_{tag}_w"]).cuda()
+    ((k * w).sum() + (q * w.flip(0)).sum()).backward()
+    np.testing.assert_allclose(fk.grad.cpu().numpy(), g[f"sp_{tag}_gk"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(fq.grad.cpu().numpy(), g[f"sp_{tag}_gq"], rtol=1e-5, atol=1e-7)
+
+
+def test_superpixel_pool_full_size():
+    """B=2 x 256 ch x 440 x 640, 10x10 block superpixels + ids > superpixel_size collisions."""
+    from openess_amd import hip
+    torch.manual_seed(1)
+    B, C, H, W, sps = 2, 256, 440, 640, 100
+    feat = torch.randn(B, C, H, W)
+    yy = (torch.arange(H) * 10 // H)[:, None]
+    xx = (torch.arange(W) * 10 // W)[None, :]
+    ids = (yy * 10 + xx)[None].repeat(B, 1, 1).long()
+    ids[1, :40, :64] = 130                                   # id >= superpixel_size: collides across samples
+    ref = ol.superpixel_pool(feat, ids, sps)
+    for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 1e-2)):
+        f = feat.to(dt).cuda().contiguous(memory_format=torch.channels_last)
+        k = hip.superpixel_pool(f, ids.cuda(), sps)
+        assert k.shape == ref.shape
+        refd = ol.superpixel_pool(feat.to(dt).float(), ids, sps)
+        np.testing.assert_allclose(k.cpu().numpy(), refd.numpy(), rtol=tol, atol=tol * 1e-2)
+
+
+def test_confusion_matrix(golden_losses):
+    from openess_amd import hip
+    g = golden_losses
+    conf = torch.zeros(121, dtype=torch.int64, device="cuda")
+    for p, t in zip(g["met_pred"], g["met_gt"]):
+        hip.confusion_accumulate(torch.from_numpy(p).cuda(), torch.from_numpy(t).cuda(), 11, 255, conf)
+    cm = conf.view(11, 11).cpu().numpy()
+    assert np.array_equal(cm, g["met_cm"])
+    miou, _, acc = ol.miou_acc(cm)
+    assert miou == pytest.approx(float(g["met_miou"]), rel=1e-12)
+    # full-size: 8 x 440 x 640
+    pred = torch.randint(0, 11, (8, 440, 640), device="cuda")
+    gt = torch.randint(0, 11, (8, 440, 640), device="cuda")
+    gt[torch.rand(8, 440, 640, device="cuda") < 0.05] = 255
+    conf.zero_()
+    hip.confusion_accumulate(pred, gt, 11, 255, conf)
+    assert np.array_equal(conf.view(11, 11).cpu().numpy(), ol.confusion_matrix(pred.cpu().numpy(), gt.cpu().numpy(), 11))
