@@ -49,7 +49,10 @@ const char* oess_strerror(int code);
  * `event_tensor[:, :-40, :]` crop (sequence_ov.py:307).  count_mode != 0 replaces every weight by
  * 1.0 (integer hit histogram; used by the bit-exact index tests).
  * ------------------------------------------------------------------------------------------ */
-size_t oess_voxelize_workspace_bytes(int64_t n_events, int n_seg, int C, int H, int W, int crop_rows);
+/* Workspace for any voxelizer call with at most n_events events in n_seg segments of at most
+ * max_seg_len events each (C = accumulated channels: bins for tri-linear, 2*bins for nearest). */
+size_t oess_voxelize_workspace_bytes(int64_t n_events, int n_seg, int64_t max_seg_len, int C, int H, int W,
+                                     int crop_rows);
 
 int oess_voxelize_trilinear_f32(const float* x, const float* y, const float* p, const float* t,
                                 const int64_t* seg_offsets, int n_seg, int64_t max_seg_len,

@@ -21,7 +21,7 @@ SIGNATURES = {
     "oess_abi_version": (c_int, []),
     "oess_build_info": (ctypes.c_char_p, []),
     "oess_strerror": (ctypes.c_char_p, [c_int]),
-    "oess_voxelize_workspace_bytes": (c_sz, [c_i64, c_int, c_int, c_int, c_int, c_int]),
+    "oess_voxelize_workspace_bytes": (c_sz, [c_i64, c_int, c_i64, c_int, c_int, c_int, c_int]),
     "oess_voxelize_trilinear_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int, c_int,
                                             c_int, c_vp, c_vp, c_sz, c_vp]),
     "oess_voxelize_dsec_raw": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_i64, c_int, c_int,

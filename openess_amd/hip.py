@@ -67,7 +67,7 @@ def voxelize_trilinear(x, y, p, t, seg_offsets, C, H, W, crop_rows=0, count_mode
         dev = host.to(x.device, non_blocking=True)
     if out is None:
         out = torch.empty((n_seg * C, H - crop_rows, W), dtype=torch.float32, device=x.device)
-    nbytes = lib.oess_voxelize_workspace_bytes(x.numel(), n_seg, C, H, W, crop_rows)
+    nbytes = lib.oess_voxelize_workspace_bytes(x.numel(), n_seg, max_len, C, H, W, crop_rows)
     ws = _workspace(nbytes, x.device)
     _lib.check(lib.oess_voxelize_trilinear_f32(_ptr(x), _ptr(y), _ptr(p), _ptr(t), _ptr(dev), n_seg, max_len, C, H, W,
                                                crop_rows, int(count_mode), _ptr(out), _ptr(ws), ws.numel(), _stream()),
@@ -94,7 +94,7 @@ def voxelize_dsec_raw(x, y, t_us, p, rectify_maps, seg_map, seg_offsets, C, H, W
         raise ValueError("seg_map needs one entry per segment")
     if out is None:
         out = torch.empty((n_seg * C, H - crop_rows, W), dtype=torch.float32, device=x.device)
-    nbytes = lib.oess_voxelize_workspace_bytes(x.numel(), n_seg, C, H, W, crop_rows)
+    nbytes = lib.oess_voxelize_workspace_bytes(x.numel(), n_seg, max_len, C, H, W, crop_rows)
     ws = _workspace(nbytes, x.device)
     _lib.check(lib.oess_voxelize_dsec_raw(_ptr(x), _ptr(y), _ptr(t_us), _ptr(p), _ptr(rectify_maps.contiguous()),
                                           _ptr(seg_map), rectify_maps.shape[0], _ptr(dev), n_seg, max_len, C, H, W,
@@ -117,7 +117,7 @@ def voxelize_nearest(events, seg_offsets, nbins, H, W, crop_rows=0, separate_pol
     ch = 2 * nbins if separate_pol else nbins
     if out is None:
         out = torch.empty((n_seg * ch, H - crop_rows, W), dtype=torch.float32, device=events.device)
-    nbytes = lib.oess_voxelize_workspace_bytes(events.shape[0], n_seg, 2 * nbins, H, W, crop_rows)
+    nbytes = lib.oess_voxelize_workspace_bytes(events.shape[0], n_seg, max_len, 2 * nbins, H, W, crop_rows)
     ws = _workspace(nbytes, events.device)
     if events.dtype == torch.int64:
         fn, name = lib.oess_voxelize_nearest_i64, "oess_voxelize_nearest_i64"

@@ -38,9 +38,9 @@ def test_workspace_query_and_argument_validation():
     """Host-only entry points / argument checks (return before any launch)."""
     from openess_amd import _lib
     lib = _lib.load()
-    n = lib.oess_voxelize_workspace_bytes(1000, 4, 5, 48, 64, 8)
+    n = lib.oess_voxelize_workspace_bytes(1000, 4, 250, 5, 48, 64, 8)
     assert n >= 1000 * 4 * 16
-    assert lib.oess_voxelize_workspace_bytes(-1, 4, 5, 48, 64, 8) == 0
+    assert lib.oess_voxelize_workspace_bytes(-1, 4, 250, 5, 48, 64, 8) == 0
     # null pointers / bad shapes are rejected with OESS_EINVAL without touching the device
     assert lib.oess_voxelize_trilinear_f32(None, None, None, None, None, 1, 0, 5, 48, 64, 0, 0, None, None, 0, None) == -22
     assert lib.oess_task_loss_fwd(None, 0, None, 10, 10, 0, 0, 0, 11, 255, 3, None, None, None) == -22
