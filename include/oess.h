@@ -143,6 +143,27 @@ int oess_task_loss_bwd(const void* logits, int is_bf16, const int64_t* target, i
 int oess_confusion_accumulate(const int64_t* pred, const int64_t* label, int64_t n, int K, int ignore_label,
                               int64_t* conf, oess_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * MFMA implicit-GEMM convolution (bf16 in, fp32 accumulate), NHWC with explicit pixel strides.
+ * Replaces the ATen/cuDNN conv2d calls behind nn.Conv2d in e2vid/model/submodules.py:7-31,175-214
+ * (ConvLayer, ConvLSTM.Gates), models/_resnet.py:74-114 (Bottleneck), models/deeplabv3.py:295-348
+ * (ASPP) and models/style_networks.py:252-289 (ReLUINSConv2d / INSResBlock).
+ *
+ * oess_conv2d_pack_weight: OIHW fp32 (Conv2d.weight) -> packed bf16 [Npad][Kpad], K = (r, s, ci);
+ *   flip_for_dgrad != 0 packs the data-gradient operator (taps rotated 180 deg, in/out swapped) so
+ *   that dX = conv(dY, packed, pad = dil*(R-1) - pad) for stride-1 convolutions.
+ * oess_conv2d_fwd_bf16: out = act(conv(in, w) + bias [+ residual]); Cin must be a multiple of 8
+ *   (pad the channel dimension; padded weights are zero).  Exactly one of out_bf16 / out_f32 is used
+ *   (out_f32 wins when non-null).  Pixel strides are in ELEMENTS.
+ * ------------------------------------------------------------------------------------------ */
+size_t oess_conv2d_packed_bytes(int Cout, int Cin, int R, int S, int flip_for_dgrad);
+int oess_conv2d_pack_weight(const float* w_oihw, int Cout, int Cin, int R, int S, int flip_for_dgrad, void* packed,
+                            size_t packed_bytes, oess_stream_t stream);
+int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int Cin, const void* w_packed,
+                         const float* bias, int Cout, int R, int S, int stride, int pad, int dil, int relu,
+                         const void* residual, long long res_pix_stride, void* out_bf16, float* out_f32,
+                         long long out_pix_stride, oess_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

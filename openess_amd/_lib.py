@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liboess.so")
 
 c_i64 = ctypes.c_int64
+c_ll = ctypes.c_longlong
 c_int = ctypes.c_int
 c_f = ctypes.c_float
 c_vp = ctypes.c_void_p
@@ -40,6 +41,10 @@ SIGNATURES = {
     "oess_task_loss_bwd": (c_int, [c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp,
                                    c_f, c_vp, c_vp, c_int, c_vp]),
     "oess_confusion_accumulate": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
+    "oess_conv2d_packed_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
+    "oess_conv2d_pack_weight": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
+    "oess_conv2d_fwd_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                                     c_int, c_int, c_int, c_vp, c_ll, c_vp, c_vp, c_ll, c_vp]),
 }
 
 _lib = None

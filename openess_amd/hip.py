@@ -283,3 +283,64 @@ def confusion_accumulate(pred, label, num_classes, ignore_label, conf):
     _lib.check(lib.oess_confusion_accumulate(_ptr(pred), _ptr(label), pred.numel(), num_classes, ignore_label,
                                              _ptr(conf), _stream()), "oess_confusion_accumulate")
     return conf
+
+
+# ------------------------------------------------------------------------------------------ conv
+def _nhwc_geom(x):
+    """x: bf16 [B, H, W, C] view whose last dim is dense and whose pixels are equally spaced."""
+    if x.dtype != torch.bfloat16 or x.ndim != 4 or x.stride(3) != 1:
+        raise ValueError("expected bf16 NHWC tensor with dense channels")
+    B, H, W, C = x.shape
+    ps = x.stride(2)
+    if x.stride(1) != W * ps or (B > 1 and x.stride(0) != H * W * ps):
+        raise ValueError("NHWC tensor must have uniformly strided pixels")
+    return B, H, W, C, ps
+
+
+def conv_packed_bytes(Cout, Cin, R, S, flip=False):
+    return _lib.load().oess_conv2d_packed_bytes(Cout, Cin, R, S, int(flip))
+
+
+def pack_conv_weight(w, flip=False):
+    """Conv2d.weight (OIHW, any float dtype) -> packed bf16 operand for conv2d_nhwc.
+    flip=True packs the data-gradient operator of a stride-1 convolution."""
+    lib = _lib.load()
+    _need_gpu(w)
+    w = w.detach().float().contiguous()
+    Cout, Cin, R, S = w.shape
+    nbytes = lib.oess_conv2d_packed_bytes(Cout, Cin, R, S, int(flip))
+    packed = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
+    _lib.check(lib.oess_conv2d_pack_weight(_ptr(w), Cout, Cin, R, S, int(flip), _ptr(packed), nbytes, _stream()),
+               "oess_conv2d_pack_weight")
+    return packed
+
+
+def conv2d_nhwc(x, packed, bias, Cout, R, S, stride=1, pad=0, dil=1, relu=False, residual=None, out=None,
+                out_f32=False):
+    """out = act(conv(x, w) + bias [+ residual]) on NHWC bf16 views (channel slices of wider buffers are fine).
+    x's channel count must be a multiple of 8 (zero-padded channels; packed weights are zero there)."""
+    lib = _lib.load()
+    _need_gpu(x, packed)
+    B, H, W, Cin, ps_in = _nhwc_geom(x)
+    Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (S - 1) - 1) // stride + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    if out.dtype == torch.float32:
+        if out.stride(3) != 1:
+            raise ValueError("fp32 output must have dense channels")
+        ps_out, o_bf16, o_f32 = out.stride(2), None, _ptr(out)
+    else:
+        _, _, _, _, ps_out = _nhwc_geom(out)
+        o_bf16, o_f32 = _ptr(out), None
+    if tuple(out.shape) != (B, Ho, Wo, Cout):
+        raise ValueError(f"bad output shape {tuple(out.shape)} != {(B, Ho, Wo, Cout)}")
+    ps_res = 0
+    if residual is not None:
+        _, _, _, _, ps_res = _nhwc_geom(residual)
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
+        bias = bias.float().contiguous()
+    _lib.check(lib.oess_conv2d_fwd_bf16(_ptr(x), ps_in, B, H, W, Cin, _ptr(packed), _ptr(bias), Cout, R, S, stride, pad,
+                                        dil, int(relu), _ptr(residual), ps_res, o_bf16, o_f32, ps_out, _stream()),
+               "oess_conv2d_fwd_bf16")
+    return out

@@ -1,0 +1,94 @@
+"""GPU parity of the MFMA implicit-GEMM convolution vs a plain PyTorch fp32 conv2d of the same
+bf16-rounded operands.  Tolerance: the kernel accumulates in fp32 and rounds the result to bf16
+once (rel 2^-8); fp32 accumulation order differs from the library conv."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_conv(x_nhwc, w, bias, stride, pad, dil):
+    x = x_nhwc.float().permute(0, 3, 1, 2)
+    y = F.conv2d(x, w.bfloat16().float(), bias, stride=stride, padding=pad, dilation=dil)
+    return y.permute(0, 2, 3, 1)
+
+
+CASES = [
+    # B, H, W, Cin, Cout, R, stride, pad, dil
+    (2, 20, 24, 16, 40, 3, 1, 1, 1),
+    (1, 33, 47, 8, 32, 5, 1, 2, 1),        # E2VID head shape class (5->8 padded channels, Cout=32 tile)
+    (2, 30, 42, 32, 64, 5, 2, 2, 1),       # E2VID encoder 5x5 stride 2 (Cout=64 tile)
+    (2, 17, 19, 64, 256, 1, 1, 0, 1),      # bottleneck 1x1
+    (1, 25, 31, 24, 136, 3, 1, 2, 2),      # dilated 3x3, ragged Cout tile
+    (1, 28, 40, 128, 128, 3, 1, 6, 6),     # ASPP rate 6
+    (3, 9, 11, 256, 512, 3, 1, 1, 1),      # ConvLSTM gates class
+    (1, 64, 96, 8, 64, 7, 2, 3, 1),        # ResNet conv1 (3->8 padded)
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_matches_torch(case):
+    from openess_amd import hip
+    B, H, W, Cin, Cout, R, stride, pad, dil = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(B, H, W, Cin, device="cuda").bfloat16()
+    w = torch.randn(Cout, Cin, R, R, device="cuda") / np.sqrt(Cin * R * R)
+    b = torch.randn(Cout, device="cuda")
+    packed = hip.pack_conv_weight(w)
+    y = hip.conv2d_nhwc(x, packed, b, Cout, R, R, stride, pad, dil)
+    ref = ref_conv(x, w, b, stride, pad, dil)
+    assert y.shape == ref.shape
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=1e-2)
+    # relu + fp32 output path
+    y32 = hip.conv2d_nhwc(x, packed, b, Cout, R, R, stride, pad, dil, relu=True, out_f32=True)
+    np.testing.assert_allclose(y32.cpu().numpy(), ref.clamp_min(0).cpu().numpy(), rtol=2e-3, atol=2e-3)
+
+
+def test_conv_small_cout_f32_logits_and_residual():
+    from openess_amd import hip
+    torch.manual_seed(7)
+    B, H, W, Cin, Cout = 2, 23, 29, 64, 11
+    x = torch.randn(B, H, W, Cin, device="cuda").bfloat16()
+    w = torch.randn(Cout, Cin, 1, 1, device="cuda") / 8
+    y = hip.conv2d_nhwc(x, hip.pack_conv_weight(w), None, Cout, 1, 1, out_f32=True)
+    np.testing.assert_allclose(y.cpu().numpy(), ref_conv(x, w, None, 1, 0, 1).cpu().numpy(), rtol=2e-3, atol=2e-3)
+    # residual add + relu (INSResBlock / Bottleneck tail), 3x3
+    w3 = torch.randn(64, 64, 3, 3, device="cuda") / 24
+    res = torch.randn(B, H, W, 64, device="cuda").bfloat16()
+    y = hip.conv2d_nhwc(x, hip.pack_conv_weight(w3), None, 64, 3, 3, 1, 1, 1, relu=True, residual=res)
+    ref = (ref_conv(x, w3, None, 1, 1, 1).bfloat16().float() + res.float()).clamp_min(0)
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=2e-2)
+
+
+def test_conv_channel_slices_of_concat_buffers():
+    """Input read from, and output written into, channel slices of wider NHWC buffers (ConvLSTM cat(x,h))."""
+    from openess_amd import hip
+    torch.manual_seed(9)
+    B, H, W = 2, 14, 18
+    buf_in = torch.randn(B, H, W, 96, device="cuda").bfloat16()
+    buf_out = torch.zeros(B, H, W, 160, device="cuda").bfloat16()
+    w = torch.randn(64, 32, 3, 3, device="cuda") / 17
+    x = buf_in[..., 32:64]
+    out = buf_out[..., 96:160]
+    hip.conv2d_nhwc(x, hip.pack_conv_weight(w), None, 64, 3, 3, 1, 1, 1, out=out)
+    ref = ref_conv(x, w, None, 1, 1, 1)
+    np.testing.assert_allclose(buf_out[..., 96:160].float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=1e-2)
+    assert float(buf_out[..., :96].abs().max()) == 0.0
+
+
+def test_conv_dgrad_operator():
+    """flip packing: dX of a stride-1 conv computed with the forward kernel == autograd's input gradient."""
+    from openess_amd import hip
+    torch.manual_seed(11)
+    B, H, W, Cin, Cout, R, pad, dil = 2, 16, 21, 32, 48, 3, 2, 2
+    x = torch.randn(B, Cin, H, W, device="cuda", requires_grad=True)
+    w = (torch.randn(Cout, Cin, R, R, device="cuda") / 17).bfloat16().float()
+    y = F.conv2d(x, w, padding=pad, dilation=dil)
+    gy = torch.randn_like(y).bfloat16().float()
+    y.backward(gy)
+    gy_nhwc = gy.permute(0, 2, 3, 1).contiguous().bfloat16()
+    gx = hip.conv2d_nhwc(gy_nhwc, hip.pack_conv_weight(w, flip=True), None, Cin, R, R, 1, dil * (R - 1) - pad, dil,
+                         out_f32=True)
+    np.testing.assert_allclose(gx.permute(0, 3, 1, 2).cpu().numpy(), x.grad.cpu().numpy(), rtol=2e-3, atol=2e-3)
