@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: event-frames/s of one full hot-path step (BASELINE.json metric).
+
+One "step" = one batch of B=8 synthetic DSEC-shaped samples per GPU, ENTIRELY inside the timed region:
+  raw events (uint16 x,y / int64 t / uint8 p, resident in HBM) -> rectify + tri-linear voxelizer
+  (8 x 100 x 440 x 640) -> frozen dilated-ResNet-50 teacher forward -> 20 recurrent E2VID encoder steps
+  (EventPreprocessor + ConvLSTM) -> SemSegE2VID forward + Dice/CE pixel distillation -> backward ->
+  2 x AdamW      (= BASELINE configs[1]: DSEC 640x480, 5-bin voxel, pixel-distill only, batch 8;
+                  reference: config/pretrain/DSEC/frame2voxel_*.yaml with if_spatial_contrastive: False).
+Random-init weights of the reference architectures, synthetic data (no network / datasets here).
+N > 1: one process per GPU (torch.distributed nccl = RCCL), per-rank batch 8 (weak scaling), gradient
+all-reduce of the trainable parameters, max-over-ranks timing.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+C, H_SENSOR, W_SENSOR, CROP, NWIN, N_PER, B = 5, 480, 640, 40, 20, 100000, 8
+H_NET = H_SENSOR - CROP
+PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def make_inputs(rank, device, workload):
+    from tests import synth
+    xs, ys, ts, ps = [], [], [], []
+    for b in range(B):
+        x, y, t, p = synth.dsec_raw_events(NWIN * N_PER, H_SENSOR, W_SENSOR, seed=1205 + rank * B + b)
+        xs.append(x); ys.append(y); ts.append(t); ps.append(p)
+    ev = dict(x=torch.from_numpy(np.concatenate(xs)).to(device), y=torch.from_numpy(np.concatenate(ys)).to(device),
+              t=torch.from_numpy(np.concatenate(ts)).to(device), p=torch.from_numpy(np.concatenate(ps)).to(device),
+              maps=torch.from_numpy(synth.rectify_map(H_SENSOR, W_SENSOR)[None]).to(device),
+              seg_map=torch.zeros(B * NWIN, dtype=torch.int32, device=device),
+              seg=torch.arange(0, (B * NWIN + 1) * N_PER, N_PER, dtype=torch.int64))
+    g = torch.Generator().manual_seed(99 + rank)
+    frame = torch.rand(B, 3, H_NET, W_SENSOR, generator=g).to(device)
+    pl = torch.randint(0, 11, (B, H_NET, W_SENSOR), generator=g)
+    pl[torch.rand(B, H_NET, W_SENSOR, generator=g) < 0.05] = 255
+    yy = (torch.arange(H_NET) * 10 // H_NET)[:, None]
+    xx = (torch.arange(W_SENSOR) * 10 // W_SENSOR)[None, :]
+    sp = (yy * 10 + xx)[None].repeat(B, 1, 1).long()
+    return ev, frame, pl.to(device), sp.to(device), (B - 1) * 100 + 100
+
+
+class GradAllReduce:
+    """One bucketed all-reduce (mean) of the trainable parameters' gradients per step."""
+
+    def __init__(self, params, world):
+        self.params = [p for p in params if p.requires_grad]
+        self.world = world
+
+    def __call__(self):
+        grads = [p.grad for p in self.params if p.grad is not None]
+        if not grads or self.world == 1:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat)
+        flat /= self.world
+        off = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n
+
+
+def cpu_baseline(sample_events, rectify_map):
+    """Oracle (CPU port) timed on this host: ONE sample (= 1 event-frame) through the NumPy voxelizer and
+    the fp32 PyTorch-CPU fwd+bwd+AdamW step (B=1), all host cores."""
+    from oracle.step import OracleStep, voxelize_sample
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    torch.manual_seed(1205)
+    step = OracleStep('frame2voxel', 11, NWIN, C, False)
+    x, y, t, p = sample_events
+    g = torch.Generator().manual_seed(5)
+    frame = torch.rand(1, 3, H_NET, W_SENSOR, generator=g)
+    pl = torch.randint(0, 11, (1, H_NET, W_SENSOR), generator=g)
+    t0 = time.perf_counter()
+    ev = voxelize_sample(x, y, t, p, rectify_map, NWIN, C, H_SENSOR, W_SENSOR, CROP)[None]
+    t_vox = time.perf_counter() - t0
+    step.train_step((ev, None, frame, pl))
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "event-frames/s", "cores": ncores, "kind": "port",
+            "sample": f"1 sample (2M events -> 100x440x640 voxels, voxelizer {t_vox:.2f}s of {dt:.2f}s) + B=1 fp32 "
+                      f"fwd+bwd+AdamW of the same frame2voxel step, torch CPU {ncores} threads, single run"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="frame2voxel_pixel_distill",
+                    choices=["frame2voxel_pixel_distill", "frame2voxel_full", "frame2recon_full"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from openess_amd import hip
+    from openess_amd.training.pretrain_step import PretrainStep
+
+    contrastive = a.workload != "frame2voxel_pixel_distill"
+    option = "frame2recon" if a.workload.startswith("frame2recon") else "frame2voxel"
+    step = PretrainStep(config_option=option, img_size=(H_NET, W_SENSOR), nr_events_data=NWIN, nr_temporal_bins=C,
+                        if_spatial_contrastive=contrastive, superpixel_size=100, device=device)
+    if world > 1:      # identical initial weights on every rank
+        for m in step.models_dict.values():
+            for t in list(m.parameters()) + list(m.buffers()):
+                dist.broadcast(t.data, 0)
+    trainable = [p for m in step.models_dict.values() for p in m.parameters()]
+    reducer = GradAllReduce(trainable, world)
+    ev, frame, pl, sp, S = make_inputs(rank, device, a.workload)
+    voxels = torch.empty((B, NWIN * C, H_NET, W_SENSOR), dtype=torch.float32, device=device)
+
+    def one_step():
+        hip.voxelize_dsec_raw(ev["x"], ev["y"], ev["t"], ev["p"], ev["maps"], ev["seg_map"], ev["seg"], C, H_SENSOR,
+                              W_SENSOR, crop_rows=CROP, out=voxels.view(B * NWIN * C, H_NET, W_SENSOR))
+        first = frame if option == "frame2recon" else voxels
+        batch = (first, None, frame, pl, sp, S)
+        for opt in step.optimizers_dict.values():
+            opt.zero_grad()
+        t_loss, losses, _ = step.task_train_step(batch)
+        t_loss.backward()
+        reducer()
+        for opt in step.optimizers_dict.values():
+            opt.step()
+        return t_loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        one_step()
+    hip.conv_timing_begin()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = one_step()
+    fence()
+    dt = time.perf_counter() - t0
+    conv_stats = hip.conv_timing_end()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        value = world * B * a.steps / dt
+        roof = None
+        if conv_stats and conv_stats["ms"] > 0:
+            ach = conv_stats["flops"] / (conv_stats["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "conv_fwd_kernel<128> (implicit-GEMM bf16 MFMA, fwd + dgrad launches)",
+                    "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": conv_stats["launches"] // a.steps,
+                    "avg_launch_us": round(conv_stats["ms"] * 1e3 / max(conv_stats["launches"], 1), 2),
+                    "share_of_step_time": round(conv_stats["ms"] / (dt * 1e3), 3)}
+        out = {"metric": "event-frames/sec fwd+bwd @640x480 B=8", "value": round(value, 2), "unit": "event-frames/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+               "data": "synthetic", "loss": round(float(loss), 4),
+               "config": {"workload": f"DSEC 640x480 5-bin x20 voxelizer + {a.workload} pre-train step "
+                                      f"(E2VID-recurrent encoder x20, SemSegE2VID decoder, dilated-R50 teacher, Dice+CE), "
+                                      f"batch {B}/GPU, random-init weights", "global_batch": world * B,
+                          "parallelism": f"dp{world}"},
+               "roofline": roof}
+        if not a.no_cpu_baseline and world == 1:
+            from tests import synth
+            sample = synth.dsec_raw_events(NWIN * N_PER, H_SENSOR, W_SENSOR, seed=1205)
+            try:
+                out["cpu_baseline"] = cpu_baseline(sample, synth.rectify_map(H_SENSOR, W_SENSOR))
+            except Exception as e:      # the baseline must never cost the GPU number
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

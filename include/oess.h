@@ -164,6 +164,23 @@ int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, 
                          const void* residual, long long res_pix_stride, void* out_bf16, float* out_f32,
                          long long out_pix_stride, oess_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * ConvLSTM gate fusion.  Replaces the chunk/sigmoid/tanh/mul/add tail of ConvLSTM.forward
+ * (e2vid/model/submodules.py:205-212).  gates: [P x 4C] bf16 (in, remember, out, cell blocks);
+ * cell state fp32 [P x C] (prev_cell may be null = zero state; cell may alias prev_cell);
+ * hidden bf16 with its own pixel stride (a channel slice of the cat(x, h) buffer).
+ * ------------------------------------------------------------------------------------------ */
+int oess_convlstm_gates_bf16(const void* gates, long long gates_pix_stride, const float* prev_cell, float* cell,
+                             void* hidden, long long hidden_pix_stride, long long n_pixels, int C, oess_stream_t stream);
+
+/* Statistics of a channel slice without the apply pass (first half of K2): stats = {sum, sumsq, nnz, -}. */
+int oess_masked_stats_slice_f32(const float* in, int B, int Ctot, int c0, int Cs, int64_t HW, double* stats,
+                                oess_stream_t stream);
+/* EventPreprocessor apply (e2vid/utils/inference_utils.py:80-85) fused with the NCHW fp32 -> NHWC bf16
+ * (8 channels, zero padded) re-layout that feeds the E2VID head conv.  normalize == 0 only re-lays out. */
+int oess_event_slice_to_nhwc8_bf16(const float* in, int B, int Ctot, int c0, int Cs, long long HW, const double* stats,
+                                   int normalize, void* out_nhwc8, oess_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,9 @@ SIGNATURES = {
     "oess_task_loss_bwd": (c_int, [c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp,
                                    c_f, c_vp, c_vp, c_int, c_vp]),
     "oess_confusion_accumulate": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
+    "oess_convlstm_gates_bf16": (c_int, [c_vp, c_ll, c_vp, c_vp, c_vp, c_ll, c_ll, c_int, c_vp]),
+    "oess_masked_stats_slice_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp]),
+    "oess_event_slice_to_nhwc8_bf16": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_ll, c_vp, c_int, c_vp, c_vp]),
     "oess_conv2d_packed_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     "oess_conv2d_pack_weight": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
     "oess_conv2d_fwd_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,

@@ -433,6 +433,19 @@ int oess_masked_normalize_slice_f32(const float* in, float* out, int B, int Ctot
     return run_normalize(in, out, (int64_t)Cs * HW, B, (int64_t)Ctot * HW, (int64_t)c0 * HW, stats, (hipStream_t)stream);
 }
 
+int oess_masked_stats_slice_f32(const float* in, int B, int Ctot, int c0, int Cs, int64_t HW, double* stats,
+                                oess_stream_t stream) {
+    if (!in || !stats || B <= 0 || Ctot <= 0 || Cs <= 0 || c0 < 0 || c0 + Cs > Ctot || HW <= 0) return OESS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    OESS_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(double), st));
+    const int64_t L = (int64_t)Cs * HW, in_stride = (int64_t)Ctot * HW, in_off = (int64_t)c0 * HW;
+    const int vec = ((L & 3) == 0) && ((in_stride & 3) == 0) && ((in_off & 3) == 0) && (((uintptr_t)in & 15) == 0);
+    const int grid = stream_grid(L * B / (vec ? 4 : 1), THREADS * 4);
+    hipLaunchKernelGGL(norm_stats_kernel, dim3(grid), dim3(THREADS), 0, st, in, L, (int64_t)B, in_stride, in_off, vec, stats);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
 int oess_segment_mean_fwd(const void* feat, int is_bf16, const int64_t* ids, int64_t P, int64_t pixels_per_sample,
                           int superpixel_size, int Cf, int S, float* k, float* count, oess_stream_t stream) {
     if (!feat || !ids || !k || !count || P <= 0 || pixels_per_sample <= 0 || Cf <= 0 || S <= 0) return OESS_EINVAL;

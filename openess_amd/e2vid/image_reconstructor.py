@@ -1,0 +1,38 @@
+"""Mirror of e2vid/image_reconstructor.py:ImageReconstructor (:18-123) for the training path:
+preprocess -> pad -> recurrent model step -> keep state.  No CudaTimer syncs in the hot loop."""
+from types import SimpleNamespace
+
+import torch
+
+from .utils.inference_utils import CropParameters, EventPreprocessor
+
+
+class ImageReconstructor:
+    def __init__(self, model, height, width, num_bins, device, options=None, augmentation=False, standardization=False):
+        options = options if options is not None else SimpleNamespace()
+        self.model = model
+        self.device = device
+        self.height, self.width, self.num_bins = height, width, num_bins
+        if augmentation or standardization:
+            raise NotImplementedError("augmentation / standardization act on the discarded image output")
+        self.no_recurrent = bool(getattr(options, 'no_recurrent', False))
+        self.crop = CropParameters(self.width, self.height, self.model.num_encoders)
+        self.last_states_for_each_channel = {'grayscale': None}
+        self.event_preprocessor = EventPreprocessor(options)
+
+    def update_reconstruction(self, event_tensor, event_tensor_id=None, stamp=None, channel_slice=None):
+        """event_tensor: fp32 [B, num_bins, H, W] (reference contract), or -- fused form -- the whole
+        [B, C_total, H, W] event tensor plus channel_slice=(c0, cs) so that the slice, the normalisation
+        and the NHWC re-layout are one kernel.  Returns (None, states, latent)."""
+        with torch.no_grad():
+            if channel_slice is None:
+                events = event_tensor.to(self.device).float().contiguous()
+                c0, cs = 0, events.shape[1]
+            else:
+                events, (c0, cs) = event_tensor, channel_slice
+            x = self.event_preprocessor.slice_to_nhwc8(events, c0, cs)
+            if self.crop.needs_pad:
+                x = self.crop.pad(x.float()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            _, states, latent = self.model(x, self.last_states_for_each_channel['grayscale'])
+            self.last_states_for_each_channel['grayscale'] = None if self.no_recurrent else states
+        return None, states, latent

@@ -1,0 +1,138 @@
+"""Host-side mirror of e2vid/model/submodules.py (reference lines cited per class).  Parameter names
+and shapes are identical to the reference so its checkpoints load unchanged; forward passes run on the
+HIP kernels (MFMA conv + fused gate kernel).  Inference only: the reference keeps E2VID frozen and runs
+it under no_grad (e2vid/image_reconstructor.py:81)."""
+import torch
+import torch.nn as nn
+
+from ... import engine, hip
+
+
+class ConvLayer(nn.Module):
+    """e2vid/model/submodules.py:7-31.  conv -> (BN | IN) -> activation.  BN is folded into the packed
+    weights (module is in eval mode on this path); ReLU is fused in the conv epilogue."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, activation='relu', norm=None):
+        super().__init__()
+        bias = False if norm == 'BN' else True
+        self.conv2d = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=bias)
+        self.activation_name = activation
+        self.norm = norm
+        if norm == 'BN':
+            self.norm_layer = nn.BatchNorm2d(out_channels)
+        elif norm == 'IN':
+            self.norm_layer = nn.InstanceNorm2d(out_channels, track_running_stats=True)
+        self._pw = engine.PackedWeight()
+
+    def forward(self, x, out=None):
+        if self.activation_name not in (None, 'relu'):
+            raise NotImplementedError("only relu / None activations are on the hot path")
+        if self.norm == 'IN':
+            raise NotImplementedError("norm='IN' E2VID variants are not on the hot path")
+        if self.norm == 'BN' and self.norm_layer.training:
+            raise RuntimeError("E2VID front end is frozen/eval on this path (pretrain_trainer.py:370-373)")
+        c = self.conv2d
+        pw = self._pw.get(c.weight, c.bias, self.norm_layer if self.norm == 'BN' else None, cin_pad=x.shape[1])
+        return engine.conv2d_infer(x, pw, c.out_channels, c.kernel_size[0], c.stride[0], c.padding[0], 1,
+                                   relu=self.activation_name == 'relu', out=out)
+
+
+class TransposedConvLayer(nn.Module):
+    """e2vid/model/submodules.py:34-62 -- parameter container only: the decoders are dead code for the
+    latents this path consumes (unet.py:163-170)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, activation='relu', norm=None):
+        super().__init__()
+        bias = False if norm == 'BN' else True
+        self.transposed_conv2d = nn.ConvTranspose2d(in_channels, out_channels, kernel_size, stride=2, padding=padding,
+                                                    output_padding=1, bias=bias)
+        self.norm = norm
+        if norm == 'BN':
+            self.norm_layer = nn.BatchNorm2d(out_channels)
+        elif norm == 'IN':
+            self.norm_layer = nn.InstanceNorm2d(out_channels, track_running_stats=True)
+
+
+class UpsampleConvLayer(nn.Module):
+    """e2vid/model/submodules.py:65-93 -- parameter container only (see TransposedConvLayer)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, activation='relu', norm=None):
+        super().__init__()
+        bias = False if norm == 'BN' else True
+        self.conv2d = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=bias)
+        self.norm = norm
+        if norm == 'BN':
+            self.norm_layer = nn.BatchNorm2d(out_channels)
+        elif norm == 'IN':
+            self.norm_layer = nn.InstanceNorm2d(out_channels, track_running_stats=True)
+
+
+class ResidualBlock(nn.Module):
+    """e2vid/model/submodules.py:140-172 -- parameter container only (runs after the latents are taken)."""
+
+    def __init__(self, in_channels, out_channels, stride=1, downsample=None, norm=None):
+        super().__init__()
+        bias = False if norm == 'BN' else True
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=stride, padding=1, bias=bias)
+        self.norm = norm
+        if norm == 'BN':
+            self.bn1 = nn.BatchNorm2d(out_channels)
+            self.bn2 = nn.BatchNorm2d(out_channels)
+        elif norm == 'IN':
+            self.bn1 = nn.InstanceNorm2d(out_channels)
+            self.bn2 = nn.InstanceNorm2d(out_channels)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=bias)
+
+
+class ConvLSTM(nn.Module):
+    """e2vid/model/submodules.py:175-214.  State = (hidden, cell).  Here the state lives in two buffers:
+    `xh` = the cat(x, h) NHWC bf16 buffer read by the Gates conv (x written by the encoder conv, h by the
+    fused gate kernel -> no torch.cat), and `cell` in fp32."""
+
+    def __init__(self, input_size, hidden_size, kernel_size):
+        super().__init__()
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        pad = kernel_size // 2
+        self.Gates = nn.Conv2d(input_size + hidden_size, 4 * hidden_size, kernel_size, padding=pad)
+        self._pw = engine.PackedWeight()
+
+    def step(self, state):
+        """state: dict(xh=[B, Cin+Ch, H, W] cl bf16 with x already written, cell=fp32 [B,H,W,Ch], fresh=bool)."""
+        g = self.Gates
+        pw = self._pw.get(g.weight, g.bias, None, cin_pad=state['xh'].shape[1])
+        gates = engine.conv2d_infer(state['xh'], pw, g.out_channels, g.kernel_size[0], 1, g.padding[0], 1,
+                                    out=state.get('gates'))
+        state['gates'] = gates
+        h_view = state['xh'][:, self.input_size:]
+        hip.convlstm_gates(engine.nhwc(gates), state['cell'], engine.nhwc(h_view), prev_cell_is_zero=state['fresh'])
+        state['fresh'] = False
+        return h_view
+
+
+class RecurrentConvLayer(nn.Module):
+    """e2vid/model/submodules.py:96-115."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=0,
+                 recurrent_block_type='convlstm', activation='relu', norm=None):
+        super().__init__()
+        assert recurrent_block_type == 'convlstm', "only ConvLSTM is used by E2VID_lightweight"
+        self.recurrent_block_type = recurrent_block_type
+        self.conv = ConvLayer(in_channels, out_channels, kernel_size, stride, padding, activation, norm)
+        self.recurrent_block = ConvLSTM(input_size=out_channels, hidden_size=out_channels, kernel_size=3)
+
+    def new_state(self, x):
+        B, _, H, W = x.shape
+        c = self.conv.conv2d
+        Ho = (H + 2 * c.padding[0] - c.kernel_size[0]) // c.stride[0] + 1
+        Wo = (W + 2 * c.padding[0] - c.kernel_size[0]) // c.stride[0] + 1
+        Co = c.out_channels
+        return {'xh': engine.zeros_cl(B, 2 * Co, Ho, Wo, x.device),
+                'cell': torch.empty((B, Ho, Wo, Co), dtype=torch.float32, device=x.device), 'fresh': True}
+
+    def forward(self, x, prev_state):
+        state = prev_state if prev_state is not None else self.new_state(x)
+        Co = self.conv.conv2d.out_channels
+        self.conv(x, out=state['xh'][:, :Co])         # x -> first half of the cat(x, h) buffer
+        h = self.recurrent_block.step(state)
+        return h, state

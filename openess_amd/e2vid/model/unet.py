@@ -1,0 +1,51 @@
+"""Mirror of e2vid/model/unet.py:UNetRecurrent (lines 118-170): head conv + recurrent encoders.
+The residual blocks, decoders and prediction layer are constructed (identical state_dict) but not
+executed: the hot path only consumes `latent` (unet.py:163), exactly as the reference's callers do
+(`_, _, latent = update_reconstruction(...)`, pretrain_trainer.py:441)."""
+import torch.nn as nn
+
+from .submodules import ConvLayer, RecurrentConvLayer, ResidualBlock, TransposedConvLayer, UpsampleConvLayer
+
+
+class UNetRecurrent(nn.Module):
+    def __init__(self, num_input_channels, num_output_channels=1, skip_type='sum', recurrent_block_type='convlstm',
+                 activation='sigmoid', num_encoders=4, base_num_channels=32, num_residual_blocks=2, norm=None,
+                 use_upsample_conv=True):
+        super().__init__()
+        self.num_input_channels = num_input_channels
+        self.num_output_channels = num_output_channels
+        self.skip_type = skip_type
+        self.norm = norm
+        self.num_encoders = num_encoders
+        self.base_num_channels = base_num_channels
+        self.num_residual_blocks = num_residual_blocks
+        self.max_num_channels = base_num_channels * pow(2, num_encoders)
+        enc_in = [base_num_channels * pow(2, i) for i in range(num_encoders)]
+        enc_out = [base_num_channels * pow(2, i + 1) for i in range(num_encoders)]
+        self.head = ConvLayer(num_input_channels, base_num_channels, kernel_size=5, stride=1, padding=2)
+        self.encoders = nn.ModuleList([
+            RecurrentConvLayer(i, o, kernel_size=5, stride=2, padding=2, recurrent_block_type=recurrent_block_type, norm=norm)
+            for i, o in zip(enc_in, enc_out)])
+        self.resblocks = nn.ModuleList([ResidualBlock(self.max_num_channels, self.max_num_channels, norm=norm)
+                                        for _ in range(num_residual_blocks)])
+        Up = UpsampleConvLayer if use_upsample_conv else TransposedConvLayer
+        self.decoders = nn.ModuleList([
+            Up(s if skip_type == 'sum' else 2 * s, s // 2, kernel_size=5, padding=2, norm=norm) for s in reversed(enc_out)])
+        self.pred = ConvLayer(base_num_channels if skip_type == 'sum' else 2 * base_num_channels, num_output_channels, 1,
+                              activation=None, norm=norm)
+
+    def forward(self, x, prev_states):
+        """x: logical [B, 8, H, W] channels_last bf16 (bins zero-padded to 8).  Returns (None, states, latent)."""
+        x = self.head(x)
+        head = x
+        if prev_states is None:
+            prev_states = [None] * self.num_encoders
+        blocks, states = [], []
+        for i, encoder in enumerate(self.encoders):
+            x, state = encoder(x, prev_states[i])
+            blocks.append(x)
+            states.append(state)
+        latent = {1: head}
+        for i, b in enumerate(blocks):
+            latent[2 ** (i + 1)] = b
+        return None, states, latent

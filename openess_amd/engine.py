@@ -1,0 +1,150 @@
+"""NHWC / bf16 execution helpers shared by the host-side model mirrors.
+
+Convention: inside the engine every activation is a torch tensor that is LOGICALLY B x C x H x W
+(so module signatures read like the reference's) but PHYSICALLY channels_last bf16, i.e. NHWC with a
+uniform pixel stride; `nhwc(x)` is a free view.  Convolutions run on the hand-written MFMA kernel
+(openess_amd/csrc/conv_fwd.hip); master weights stay fp32 nn.Parameters and are packed to the
+kernel's bf16 operand format lazily (re-packed when the parameter's version counter changes).
+"""
+import torch
+import torch.nn.functional as F
+
+from . import hip
+
+
+def nhwc(x):
+    """Logical NCHW tensor (channels_last or a channel slice of one) -> [B, H, W, C] view."""
+    return x.permute(0, 2, 3, 1)
+
+
+def from_nhwc(y):
+    return y.permute(0, 3, 1, 2)
+
+
+def to_cl_bf16(x, pad_to=8):
+    """Any NCHW float tensor -> channels_last bf16 with the channel count padded (zeros) to a multiple
+    of `pad_to` (the conv kernel gathers 16-byte = 8-channel chunks)."""
+    B, C, H, W = x.shape
+    Cp = (C + pad_to - 1) // pad_to * pad_to
+    if Cp == C and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last):
+        return x
+    out = torch.zeros((B, H, W, Cp), dtype=torch.bfloat16, device=x.device)
+    out[..., :C] = x.permute(0, 2, 3, 1)
+    return from_nhwc(out)
+
+
+def empty_cl(B, C, H, W, device, dtype=torch.bfloat16):
+    return from_nhwc(torch.empty((B, H, W, C), dtype=dtype, device=device))
+
+
+def zeros_cl(B, C, H, W, device, dtype=torch.bfloat16):
+    return from_nhwc(torch.zeros((B, H, W, C), dtype=dtype, device=device))
+
+
+class PackedWeight:
+    """bf16 packed operand of a conv weight (optionally with an eval-mode BatchNorm folded in),
+    cached per (parameter versions)."""
+
+    def __init__(self):
+        self.key = None
+        self.packed = None
+        self.bias = None
+        self.packed_flip = None
+
+    def flip(self):
+        """Packed data-gradient operator of the currently packed weight (stride-1 convs)."""
+        if self.packed_flip is None:
+            self.packed_flip = hip.pack_conv_weight(self._w_for_flip, flip=True)
+        return self.packed_flip
+
+    def get(self, weight, bias=None, bn=None, need_flip=False, cin_pad=None, ver=None):
+        key = (weight._version if ver is None else ver, None if bias is None else bias._version,
+               None if bn is None else (bn.weight._version, bn.bias._version, bn.running_mean._version,
+                                        bn.running_var._version), cin_pad)
+        if key != self.key:
+            with torch.no_grad():
+                w = weight.detach().float()
+                b = None if bias is None else bias.detach().float()
+                if bn is not None:     # y = gamma*(conv(x)-mu)/sqrt(var+eps)+beta  (BatchNorm2d in eval mode)
+                    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+                    w = w * scale[:, None, None, None]
+                    b0 = torch.zeros_like(scale) if b is None else b
+                    b = (b0 - bn.running_mean.detach().float()) * scale + bn.bias.detach().float()
+                if cin_pad is not None and cin_pad != w.shape[1]:
+                    w = F.pad(w, (0, 0, 0, 0, 0, cin_pad - w.shape[1]))
+                self.packed = hip.pack_conv_weight(w)
+                self.packed_flip = None
+                self._w_for_flip = w
+                self.bias = None if b is None else b.contiguous()
+            self.key = key
+        if need_flip and self.packed_flip is None:
+            self.packed_flip = hip.pack_conv_weight(self._w_for_flip, flip=True)
+        return self
+
+
+def conv2d_infer(x, pw, Cout, k, stride=1, pad=0, dil=1, relu=False, residual=None, out=None, out_f32=False):
+    """Inference conv on logical-NCHW channels_last tensors.  Returns logical NCHW."""
+    y = hip.conv2d_nhwc(nhwc(x), pw.packed, pw.bias, Cout, k, k, stride, pad, dil, relu=relu,
+                        residual=None if residual is None else nhwc(residual),
+                        out=None if out is None else nhwc(out), out_f32=out_f32)
+    return from_nhwc(y)
+
+
+class _ConvTrainFn(torch.autograd.Function):
+    """Trainable conv: forward and data-gradient on the HIP MFMA kernel (dgrad = forward kernel on the
+    rotated / transposed packed weight); weight- and bias-gradient still come from ATen's
+    convolution_backward (library call) until the hand-written wgrad kernel lands."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pw, k, stride, pad, dil, out_f32):
+        Cout = weight.shape[0]
+        y = conv2d_infer(x, pw, Cout, k, stride, pad, dil, out_f32=out_f32)
+        ctx.save_for_backward(x, weight)
+        ctx.meta = (pw, k, stride, pad, dil, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        pw, k, stride, pad, dil, has_bias = ctx.meta
+        gy = gy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        gx = gw = gb = None
+        Cin_x = x.shape[1]
+        if ctx.needs_input_grad[0]:
+            if stride == 1:
+                gy8 = gy if gy.shape[1] % 8 == 0 else to_cl_bf16(gy)
+                gx = hip.conv2d_nhwc(nhwc(gy8), pw.flip(), None, Cin_x, k, k, 1, dil * (k - 1) - pad, dil)
+                gx = from_nhwc(gx)
+            else:
+                gx = torch.ops.aten.convolution_backward(gy, x, weight.to(x.dtype), None, [stride, stride], [pad, pad],
+                                                         [dil, dil], False, [0, 0], 1, [True, False, False])[0]
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            xin = x[:, :weight.shape[1]] if Cin_x != weight.shape[1] else x
+            res = torch.ops.aten.convolution_backward(gy, xin, weight.to(x.dtype), [weight.shape[0]] if has_bias else None,
+                                                      [stride, stride], [pad, pad], [dil, dil], False, [0, 0], 1,
+                                                      [False, True, has_bias])
+            gw = res[1].float()
+            gb = res[2].float() if has_bias else None
+        return gx, gw, gb, None, None, None, None, None, None
+
+
+def conv2d_train(x, weight, bias, pw, k, stride=1, pad=0, dil=1, out_f32=False, ver=None):
+    """`ver`: explicit cache key for weights DERIVED from parameters (their own _version is always 0)."""
+    cin_pad = x.shape[1]
+    pw.get(weight, bias, None, cin_pad=cin_pad, ver=ver)
+    if not x.is_contiguous(memory_format=torch.channels_last) and x.stride(1) != 1:
+        x = x.contiguous(memory_format=torch.channels_last)
+    return _ConvTrainFn.apply(x, weight, bias, pw, k, stride, pad, dil, out_f32)
+
+
+def batch_norm_act(x, bn, relu=False, residual=None):
+    """BatchNorm2d (+ residual add + ReLU) on a channels_last bf16 tensor, honouring bn.training exactly
+    like nn.BatchNorm2d (batch statistics + running-stat update in train mode).  Still an ATen call; the
+    fused stats-in-conv-epilogue kernel is the next step."""
+    y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training,
+                     0.0 if bn.momentum is None else bn.momentum, bn.eps)
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y

@@ -344,3 +344,78 @@ def conv2d_nhwc(x, packed, bias, Cout, R, S, stride=1, pad=0, dil=1, relu=False,
                                         dil, int(relu), _ptr(residual), ps_res, o_bf16, o_f32, ps_out, _stream()),
                "oess_conv2d_fwd_bf16")
     return out
+
+
+# ------------------------------------------------------------------------------------------ pointwise
+def convlstm_gates(gates, cell, hidden_out, prev_cell_is_zero=False):
+    """gates: bf16 NHWC [B,H,W,4C]; cell: fp32 [B,H,W,C] (updated in place); hidden_out: bf16 NHWC view
+    [B,H,W,C] (may be a channel slice)."""
+    lib = _lib.load()
+    _need_gpu(gates, cell, hidden_out)
+    B, H, W, C4, gs = _nhwc_geom(gates)
+    C = C4 // 4
+    _, _, _, Ch, hs = _nhwc_geom(hidden_out)
+    if Ch != C or cell.dtype != torch.float32 or not cell.is_contiguous() or cell.numel() != B * H * W * C:
+        raise ValueError("convlstm_gates: shape mismatch")
+    _lib.check(lib.oess_convlstm_gates_bf16(_ptr(gates), gs, None if prev_cell_is_zero else _ptr(cell), _ptr(cell),
+                                            _ptr(hidden_out), hs, B * H * W, C, _stream()), "oess_convlstm_gates_bf16")
+    return hidden_out
+
+
+def event_slice_to_nhwc8(events, c0, cs, normalize=True, out=None):
+    """events: contiguous fp32 [B, Ctot, H, W]; returns logical [B, 8, H, W] channels_last bf16 holding the
+    (optionally EventPreprocessor-normalised) slice events[:, c0:c0+cs], zero padded to 8 channels."""
+    lib = _lib.load()
+    _need_gpu(events)
+    if events.dtype != torch.float32 or not events.is_contiguous() or events.ndim != 4:
+        raise ValueError("needs contiguous float32 [B, C, H, W]")
+    B, Ct, H, W = events.shape
+    if out is None:
+        out = torch.empty((B, H, W, 8), dtype=torch.bfloat16, device=events.device)
+    stats = None
+    if normalize:
+        stats = torch.empty(4, dtype=torch.float64, device=events.device)
+        _lib.check(lib.oess_masked_stats_slice_f32(_ptr(events), B, Ct, c0, cs, H * W, _ptr(stats), _stream()),
+                   "oess_masked_stats_slice_f32")
+    _lib.check(lib.oess_event_slice_to_nhwc8_bf16(_ptr(events), B, Ct, c0, cs, H * W, _ptr(stats), int(normalize),
+                                                  _ptr(out), _stream()), "oess_event_slice_to_nhwc8_bf16")
+    return out.permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------------------------------ timing hooks
+_CONV_TIMING = None
+
+
+def conv_timing_begin():
+    """bench.py: bracket every launch of the dominant kernel (conv_fwd_kernel<128>, i.e. Cout > 64) with HIP
+    events on the launch stream; resolved after the timed region (no sync inside it)."""
+    global _CONV_TIMING
+    _CONV_TIMING = {"events": [], "flops": 0.0}
+
+
+def conv_timing_end():
+    global _CONV_TIMING
+    t = _CONV_TIMING
+    _CONV_TIMING = None
+    if not t:
+        return None
+    torch.cuda.synchronize()
+    ms = sum(a.elapsed_time(b) for a, b in t["events"])
+    return {"ms": ms, "flops": t["flops"], "launches": len(t["events"])}
+
+
+_conv2d_nhwc_raw = conv2d_nhwc
+
+
+def conv2d_nhwc(x, packed, bias, Cout, R, S, stride=1, pad=0, dil=1, relu=False, residual=None, out=None,
+                out_f32=False):
+    t = _CONV_TIMING
+    if t is None or Cout <= 64:
+        return _conv2d_nhwc_raw(x, packed, bias, Cout, R, S, stride, pad, dil, relu, residual, out, out_f32)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    y = _conv2d_nhwc_raw(x, packed, bias, Cout, R, S, stride, pad, dil, relu, residual, out, out_f32)
+    e1.record()
+    t["events"].append((e0, e1))
+    t["flops"] += 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * Cout * x.shape[3] * R * S
+    return y

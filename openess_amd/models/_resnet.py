@@ -1,0 +1,136 @@
+"""Mirror of models/_resnet.py (ResNet :117-209, Bottleneck :74-114, resnet50) with the convolutions
+on the HIP MFMA kernel.  state_dict keys equal torchvision's / the reference's."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import engine
+
+
+class HipConv2d(nn.Conv2d):
+    """nn.Conv2d (bias-free in ResNet) executed by the MFMA kernel; differentiable when its weight
+    requires grad, plain inference otherwise."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._pw = engine.PackedWeight()
+
+    def forward(self, x):
+        if x.shape[1] % 8:
+            x = engine.to_cl_bf16(x)
+        k, s, p, d = self.kernel_size[0], self.stride[0], self.padding[0], self.dilation[0]
+        if torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad):
+            return engine.conv2d_train(x, self.weight, self.bias, self._pw, k, s, p, d)
+        pw = self._pw.get(self.weight, self.bias, None, cin_pad=x.shape[1])
+        return engine.conv2d_infer(x, pw, self.out_channels, k, s, p, d)
+
+
+def conv3x3(in_planes, out_planes, stride=1, groups=1, dilation=1):
+    assert groups == 1
+    return HipConv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=dilation, bias=False, dilation=dilation)
+
+
+def conv1x1(in_planes, out_planes, stride=1):
+    return HipConv2d(in_planes, out_planes, kernel_size=1, stride=stride, bias=False)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1, norm_layer=None):
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2d
+        width = int(planes * (base_width / 64.)) * groups
+        self.conv1 = conv1x1(inplanes, width)
+        self.bn1 = norm_layer(width)
+        self.conv2 = conv3x3(width, width, stride, groups, dilation)
+        self.bn2 = norm_layer(width)
+        self.conv3 = conv1x1(width, planes * self.expansion)
+        self.bn3 = norm_layer(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x
+        out = engine.batch_norm_act(self.conv1(x), self.bn1, relu=True)
+        out = engine.batch_norm_act(self.conv2(out), self.bn2, relu=True)
+        out = self.conv3(out)
+        if self.downsample is not None:
+            identity = engine.batch_norm_act(self.downsample[0](x), self.downsample[1])
+        return engine.batch_norm_act(out, self.bn3, relu=True, residual=identity)
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, layers, num_classes=1000, zero_init_residual=False, groups=1, width_per_group=64,
+                 replace_stride_with_dilation=None, norm_layer=None):
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2d
+        self._norm_layer = norm_layer
+        self.inplanes = 64
+        self.dilation = 1
+        if replace_stride_with_dilation is None:
+            replace_stride_with_dilation = [False, False, False]
+        if len(replace_stride_with_dilation) != 3:
+            raise ValueError("replace_stride_with_dilation should be None or a 3-element tuple")
+        self.groups = groups
+        self.base_width = width_per_group
+        self.conv1 = HipConv2d(3, self.inplanes, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = norm_layer(self.inplanes)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2, dilate=replace_stride_with_dilation[0])
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2, dilate=replace_stride_with_dilation[1])
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2, dilate=replace_stride_with_dilation[2])
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    nn.init.constant_(m.bn3.weight, 0)
+
+    def _make_layer(self, block, planes, blocks, stride=1, dilate=False):
+        norm_layer = self._norm_layer
+        downsample = None
+        previous_dilation = self.dilation
+        if dilate:
+            self.dilation *= stride
+            stride = 1
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(conv1x1(self.inplanes, planes * block.expansion, stride),
+                                       norm_layer(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample, self.groups, self.base_width, previous_dilation, norm_layer)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes, groups=self.groups, base_width=self.base_width,
+                                dilation=self.dilation, norm_layer=norm_layer))
+        return nn.Sequential(*layers)
+
+    def stem(self, x):
+        x = engine.batch_norm_act(self.conv1(x), self.bn1, relu=True)
+        return self.maxpool(x)
+
+    def features(self, x):
+        x = self.stem(x)
+        x = self.layer1(x)
+        x = self.layer2(x)
+        x = self.layer3(x)
+        return self.layer4(x)
+
+    def forward(self, x):
+        x = self.features(x)
+        x = torch.flatten(self.avgpool(x.float()), 1)
+        return self.fc(x)
+
+
+def resnet50(pretrained=False, progress=True, **kwargs):
+    if pretrained:
+        raise NotImplementedError("no network access: load weights with load_state_dict")
+    return ResNet(Bottleneck, [3, 4, 6, 3], **kwargs)

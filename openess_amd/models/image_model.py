@@ -1,0 +1,50 @@
+"""Mirror of models/image_model.py:DilationFeatureExtractor (:90-143) and
+models/modules/resnet_encoder.py:ResNetEncoder (:8-38): frozen dilated ResNet-50 (output stride 4),
+trainable 1x1 decoder, x4 bilinear (align_corners=True), L2 normalisation over channels."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import engine
+from ._resnet import Bottleneck, HipConv2d, ResNet
+
+
+class ResNetEncoder(ResNet):
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        del self.fc
+        del self.avgpool
+
+    def forward(self, x):
+        return self.features(x)
+
+    def load_state_dict(self, state_dict, **kwargs):
+        state_dict.pop("fc.bias", None)
+        state_dict.pop("fc.weight", None)
+        return super().load_state_dict(state_dict, **kwargs)
+
+
+class DilationFeatureExtractor(nn.Module):
+    def __init__(self, image_weights=None, preprocessing=None):
+        super().__init__()
+        if image_weights not in (None, '', 'none', 'random'):
+            # the reference downloads SSL checkpoints over HTTP (image_model.py:38-42); no network here
+            print(f"[openess_amd] image_weights='{image_weights}' not loaded (no network): load a state_dict instead")
+        self.encoder = ResNetEncoder(block=Bottleneck, layers=[3, 4, 6, 3], replace_stride_with_dilation=[True, True, True])
+        for p in self.encoder.parameters():
+            p.requires_grad = False
+        self.decoder = nn.Sequential(HipConv2d(2048, 256, 1), nn.Upsample(scale_factor=4, mode="bilinear", align_corners=True))
+        self.preprocessing = preprocessing
+        self.normalize_feature = True
+
+    def forward(self, x):
+        if self.preprocessing:
+            x = self.preprocessing(x)
+        x = engine.to_cl_bf16(x)
+        with torch.no_grad():                      # encoder params are frozen (image_model.py:113-114)
+            x = self.encoder(x)
+        x = self.decoder[0](x)
+        x = F.interpolate(x, scale_factor=4, mode="bilinear", align_corners=True)
+        if self.normalize_feature:
+            x = F.normalize(x, p=2, dim=1)
+        return x

@@ -1,0 +1,134 @@
+"""Stage-1 (pre-training) step of the `frame2voxel` and `frame2recon` options, restated from
+training/pretrain_trainer.py: buildModels (:107-208), createOptimizerDict (:211-274), train_step
+(:324-361) and task_train_step (:364-534).  This is the self-contained step object used by bench.py,
+smoke() and the trainer classes; it owns the models_dict / optimizers_dict with the reference's key names.
+"""
+import math
+
+import torch
+
+from .. import hip
+from ..e2vid.image_reconstructor import ImageReconstructor
+from ..e2vid.model.model import E2VID_LIGHTWEIGHT_CONFIG, E2VIDRecurrent
+from ..models.deeplabv3 import deeplabv3_resnet50
+from ..models.image_model import DilationFeatureExtractor
+from ..models.style_networks import SemSegE2VID
+from ..utils.loss_functions import NCELoss, TaskLoss
+
+
+class PretrainStep:
+    def __init__(self, config_option='frame2voxel', num_classes=11, img_size=(440, 640), nr_events_data=20,
+                 nr_temporal_bins=5, if_spatial_contrastive=False, if_dense_clip_supervision=True, superpixel_size=100,
+                 lr=5e-4, weight_task_loss=1.0, task_loss=('dice', 'cross_entropy'), output_stride=32, device='cuda',
+                 e2vid_config=None, text_embeddings=None, seed=1205):
+        self.config_option = config_option
+        self.device = torch.device(device)
+        self.nr_events_data, self.bins = nr_events_data, nr_temporal_bins
+        self.if_spatial_contrastive = if_spatial_contrastive
+        self.if_dense_clip_supervision = if_dense_clip_supervision
+        self.superpixel_size = superpixel_size
+        self.weight_task_loss = weight_task_loss
+        torch.manual_seed(seed)
+        self.models_dict = {}
+        if config_option == 'frame2voxel':
+            self.front_end_sensor_b = E2VIDRecurrent(e2vid_config or E2VID_LIGHTWEIGHT_CONFIG)
+            for p in self.front_end_sensor_b.parameters():
+                p.requires_grad = False
+            self.front_end_sensor_b.eval()
+            self.input_height = math.ceil(img_size[0] / 8.0) * 8
+            self.input_width = math.ceil(img_size[1] / 8.0) * 8
+            self.models_dict['front_sensor_b'] = self.front_end_sensor_b
+            self.task_backend = SemSegE2VID(input_c=256, output_c=num_classes, skip_connect=True, skip_type='concat',
+                                            text_embeddings_path='', materialize_ch256=if_spatial_contrastive)
+            self.models_dict['back_end'] = self.task_backend
+        elif config_option == 'frame2recon':
+            self.model_recon = deeplabv3_resnet50(num_classes=num_classes, text_embeddings_path='',
+                                                  output_stride=output_stride, pretrained_backbone='')
+            self.models_dict['model_recon'] = self.model_recon
+        else:
+            raise NotImplementedError(config_option)
+        self.model_frame = DilationFeatureExtractor(image_weights=None)
+        self.models_dict['model_frame'] = self.model_frame
+        if text_embeddings is not None:
+            tgt = self.task_backend if config_option == 'frame2voxel' else self.model_recon.classifier
+            tgt.text_embeddings.copy_(text_embeddings)
+        for m in self.models_dict.values():
+            m.to(self.device)
+        if config_option == 'frame2voxel':
+            self.reconstructor = ImageReconstructor(self.front_end_sensor_b, self.input_height, self.input_width,
+                                                    nr_temporal_bins, self.device)
+        self.task_loss = TaskLoss(losses=list(task_loss), gamma=2.0, num_classes=num_classes, ignore_index=255)
+        self.nce_loss = NCELoss(temperature=0.07)
+        # createOptimizerDict (pretrain_trainer.py:225-259)
+        params_frame = [p for p in self.model_frame.parameters() if p.requires_grad]
+        if config_option == 'frame2voxel':
+            params_voxel = [p for p in self.task_backend.parameters() if p.requires_grad]
+            params_voxel = [p for p in self.front_end_sensor_b.parameters() if p.requires_grad] + params_voxel
+            self.optimizers_dict = {'optimizer_voxel': torch.optim.AdamW(params_voxel, lr=lr),
+                                    'optimizer_frame': torch.optim.AdamW(params_frame, lr=lr)}
+        else:
+            params_recon = [p for p in self.model_recon.parameters() if p.requires_grad]
+            self.optimizers_dict = {'optimizer_recon': torch.optim.AdamW(params_recon, lr=lr),
+                                    'optimizer_frame': torch.optim.AdamW(params_frame, lr=lr)}
+
+    # ------------------------------------------------------------------ pretrain_trainer.py:364-534
+    def _set_modes(self):
+        for name, m in self.models_dict.items():
+            m.train()
+            if name == 'front_sensor_b':
+                m.eval()                       # unfrozen_e2vid: False in every pre-training YAML
+
+    def _pool(self, feat, superpixels, S):
+        return hip.superpixel_pool(feat, superpixels, self.superpixel_size, S=S)
+
+    def task_train_step(self, batch):
+        """batch: (event | frame, label, frame | recon, pl, superpixels) already on the device.
+        `superpixel_rows` (optional 6th item) = max offset id + 1 computed by the loader on the host."""
+        losses = {}
+        t_loss = 0.
+        self._set_modes()
+        S = batch[5] if len(batch) > 5 else None
+        if self.config_option == 'frame2voxel':
+            event, frame, pl = batch[0], batch[2], batch[3]
+            feat_frame = self.model_frame(frame)
+            self.reconstructor.last_states_for_each_channel = {'grayscale': None}
+            for i in range(self.nr_events_data):
+                _, _, latent_real = self.reconstructor.update_reconstruction(
+                    event, channel_slice=(i * self.bins, self.bins))
+            content = {k: v.detach() for k, v in latent_real.items()}          # trainTaskStepPretrain (:550-562)
+            pred, feat_voxel = self.task_backend(content)
+            loss_dense = self.task_loss(pred[1], pl) * self.weight_task_loss
+            losses['dense_clip_loss'] = loss_dense.detach()
+            if self.if_spatial_contrastive:
+                k = self._pool(feat_voxel, batch[4], S)
+                q = self._pool(feat_frame, batch[4], S)
+                loss_nce = self.nce_loss(k, q)
+                losses['contrastive_nce_loss'] = loss_nce.detach()
+                t_loss = t_loss + loss_nce
+            if self.if_dense_clip_supervision:
+                t_loss = t_loss + loss_dense
+        else:                                                                   # frame2recon (:475-529)
+            frame, recon, pl = batch[0], batch[2], batch[3]
+            feat_frame = self.model_frame(frame)
+            logits_recon, feat_recon = self.model_recon(recon)
+            if self.if_spatial_contrastive:
+                k = self._pool(feat_recon, batch[4], S)
+                q = self._pool(feat_frame, batch[4], S)
+                loss_nce = self.nce_loss(k, q)
+                losses['contrastive_nce_loss'] = loss_nce.detach()
+                t_loss = t_loss + loss_nce
+            if self.if_dense_clip_supervision:
+                loss_dense = self.task_loss(logits_recon, pl) * self.weight_task_loss
+                losses['dense_clip_loss'] = loss_dense.detach()
+                t_loss = t_loss + loss_dense
+        return t_loss, losses, {}
+
+    # ------------------------------------------------------------------ pretrain_trainer.py:324-361
+    def train_step(self, batch):
+        for opt in self.optimizers_dict.values():
+            opt.zero_grad()
+        t_loss, losses, outputs = self.task_train_step(batch)
+        t_loss.backward()
+        for opt in self.optimizers_dict.values():
+            opt.step()
+        return losses, outputs, t_loss.detach()

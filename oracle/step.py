@@ -1,0 +1,85 @@
+"""Oracle (test infrastructure): CPU restatement of one frame2voxel / frame2recon pre-training step
+(training/pretrain_trainer.py:324-361, 364-534, 550-562) built from oracle.events / oracle.nets /
+oracle.losses.  Used as the parity reference of the GPU step and as bench.py's `cpu_baseline`."""
+import torch
+
+from . import events as oe
+from . import losses as ol
+from . import nets as on
+
+E2VID_LIGHTWEIGHT_CONFIG = {'num_bins': 5, 'skip_type': 'sum', 'recurrent_block_type': 'convlstm', 'num_encoders': 3,
+                            'base_num_channels': 32, 'num_residual_blocks': 2, 'use_upsample_conv': False, 'norm': 'BN'}
+
+
+class OracleStep:
+    def __init__(self, config_option='frame2voxel', num_classes=11, nr_events_data=20, bins=5,
+                 if_spatial_contrastive=False, superpixel_size=100, lr=5e-4, output_stride=32):
+        self.opt, self.K, self.nwin, self.bins = config_option, num_classes, nr_events_data, bins
+        self.contr, self.sps = if_spatial_contrastive, superpixel_size
+        self.model_frame = on.DilationFeatureExtractor()
+        if config_option == 'frame2voxel':
+            self.front = on.E2VIDRecurrent(E2VID_LIGHTWEIGHT_CONFIG).eval()
+            for p in self.front.parameters():
+                p.requires_grad = False
+            self.back_end = on.SemSegE2VID(256, num_classes)
+            trainable = [p for p in self.back_end.parameters() if p.requires_grad]
+        else:
+            self.model_recon = on.DeepLabV3(num_classes, output_stride)
+            trainable = [p for p in self.model_recon.parameters() if p.requires_grad]
+        self.opt_a = torch.optim.AdamW(trainable, lr=lr)
+        self.opt_b = torch.optim.AdamW([p for p in self.model_frame.parameters() if p.requires_grad], lr=lr)
+
+    def modules(self):
+        d = {'model_frame': self.model_frame}
+        if self.opt == 'frame2voxel':
+            d.update(front_sensor_b=self.front, back_end=self.back_end)
+        else:
+            d.update(model_recon=self.model_recon)
+        return d
+
+    def loss(self, batch):
+        self.model_frame.train()
+        t_loss, losses = 0., {}
+        if self.opt == 'frame2voxel':
+            event, frame, pl = batch[0], batch[2], batch[3]
+            self.back_end.train()
+            feat_frame = self.model_frame(frame)
+            states = None
+            with torch.no_grad():
+                for i in range(self.nwin):
+                    x = on.event_preprocess(event[:, i * self.bins:(i + 1) * self.bins])
+                    _, states, latent = self.front(x, states)
+            pred, feat_voxel = self.back_end({k: v.detach() for k, v in latent.items()})
+            dense = ol.task_loss(pred[1], pl, self.K)
+            losses['dense_clip_loss'] = dense.detach()
+            if self.contr:
+                nce = ol.nce_loss(ol.superpixel_pool(feat_voxel, batch[4], self.sps), ol.superpixel_pool(feat_frame, batch[4], self.sps))
+                losses['contrastive_nce_loss'] = nce.detach()
+                t_loss = t_loss + nce
+            t_loss = t_loss + dense
+        else:
+            frame, recon, pl = batch[0], batch[2], batch[3]
+            self.model_recon.train()
+            feat_frame = self.model_frame(frame)
+            logits, feat_recon = self.model_recon(recon)
+            if self.contr:
+                nce = ol.nce_loss(ol.superpixel_pool(feat_recon, batch[4], self.sps), ol.superpixel_pool(feat_frame, batch[4], self.sps))
+                losses['contrastive_nce_loss'] = nce.detach()
+                t_loss = t_loss + nce
+            dense = ol.task_loss(logits, pl, self.K)
+            losses['dense_clip_loss'] = dense.detach()
+            t_loss = t_loss + dense
+        return t_loss, losses
+
+    def train_step(self, batch):
+        self.opt_a.zero_grad()
+        self.opt_b.zero_grad()
+        t_loss, losses = self.loss(batch)
+        t_loss.backward()
+        self.opt_a.step()
+        self.opt_b.step()
+        return losses, t_loss.detach()
+
+
+def voxelize_sample(x, y, t, p, rectify_map, nwin, C, H, W, crop):
+    return torch.from_numpy(oe.dsec_event_tensor(x, y, t, p, rectify_map, nwin, C, H, W, crop))
