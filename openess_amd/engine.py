@@ -28,6 +28,8 @@ def to_cl_bf16(x, pad_to=8):
     Cp = (C + pad_to - 1) // pad_to * pad_to
     if Cp == C and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last):
         return x
+    if Cp == C:
+        return x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     out = torch.zeros((B, H, W, Cp), dtype=torch.bfloat16, device=x.device)
     out[..., :C] = x.permute(0, 2, 3, 1)
     return from_nhwc(out)

@@ -16,8 +16,10 @@ class HipConv2d(nn.Conv2d):
         self._pw = engine.PackedWeight()
 
     def forward(self, x):
-        if x.shape[1] % 8:
+        if x.shape[1] % 8 or x.dtype != torch.bfloat16:
             x = engine.to_cl_bf16(x)
+        elif x.stride(1) != 1:                       # e.g. torch.cat of an expanded tensor: make it NHWC
+            x = x.contiguous(memory_format=torch.channels_last)
         k, s, p, d = self.kernel_size[0], self.stride[0], self.padding[0], self.dilation[0]
         if torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad):
             return engine.conv2d_train(x, self.weight, self.bias, self._pw, k, s, p, d)

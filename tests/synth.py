@@ -33,3 +33,93 @@ def ddd17_events(n, H, W, seed, span_us=50000):
     p = rng.integers(0, 2, n)
     t = np.sort(rng.integers(0, span_us, n)) + 5_000_000
     return np.stack([x, y, t, p], -1).astype(np.int64)
+
+
+def seeded_state(module, seed):
+    """Deterministic weights keyed by parameter NAME (sorted), so that the reference module (golden
+    generation), the oracle and the product module -- which share state_dict keys -- are filled
+    identically without shipping weight files.  Returns a dict of torch tensors."""
+    import torch
+    sd = module.state_dict()
+    out = {}
+    for i, k in enumerate(sorted(sd.keys())):
+        v = sd[k]
+        rng = np.random.default_rng([seed, i])
+        if not v.dtype.is_floating_point:
+            out[k] = v.clone()
+            continue
+        shp = tuple(v.shape)
+        if k.endswith("running_var"):
+            a = rng.uniform(0.5, 1.5, shp)
+        elif k.endswith("running_mean"):
+            a = rng.normal(0, 0.1, shp)
+        elif k.endswith("text_embeddings"):
+            a = rng.normal(0, 1.0, shp)
+            a /= np.linalg.norm(a, axis=1, keepdims=True)
+        elif v.ndim >= 2:
+            fan_in = int(np.prod(shp[1:]))
+            a = rng.normal(0, 1.0 / np.sqrt(fan_in), shp)
+        elif k.endswith("weight"):
+            a = rng.uniform(0.5, 1.5, shp)
+        else:
+            a = rng.normal(0, 0.1, shp)
+        out[k] = torch.from_numpy(np.asarray(a, dtype=np.float32)).reshape(v.shape)
+    return out
+
+
+def fill_by_name(module, seed, reference_keys=None):
+    """Load seeded weights into `module`.  If the module has FEWER keys than the reference (oracle restates
+    only executed layers), pass the reference's sorted key list so that indices -- and hence values -- match."""
+    import torch
+    sd = module.state_dict()
+    keys = sorted(reference_keys) if reference_keys is not None else sorted(sd.keys())
+    new = {}
+    for i, k in enumerate(keys):
+        if k not in sd:
+            continue
+        class _M:      # tiny shim: reuse seeded_state's value rule for a single key at index i
+            pass
+        v = sd[k]
+        rng = np.random.default_rng([seed, i])
+        if not v.dtype.is_floating_point:
+            new[k] = v.clone()
+            continue
+        shp = tuple(v.shape)
+        if k.endswith("running_var"):
+            a = rng.uniform(0.5, 1.5, shp)
+        elif k.endswith("running_mean"):
+            a = rng.normal(0, 0.1, shp)
+        elif k.endswith("text_embeddings"):
+            a = rng.normal(0, 1.0, shp)
+            a /= np.linalg.norm(a, axis=1, keepdims=True)
+        elif v.ndim >= 2:
+            fan_in = int(np.prod(shp[1:]))
+            a = rng.normal(0, 1.0 / np.sqrt(fan_in), shp)
+        elif k.endswith("weight"):
+            a = rng.uniform(0.5, 1.5, shp)
+        else:
+            a = rng.normal(0, 0.1, shp)
+        new[k] = torch.from_numpy(np.asarray(a, dtype=np.float32)).reshape(v.shape)
+    module.load_state_dict(new, strict=False)
+    return module
+
+
+def compact(a, n=8192):
+    """Large golden tensors are stored as a strided sample + sum + abs-sum (keeps fixtures small)."""
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    stride = max(1, a.size // n)
+    return a[::stride][:n].astype(np.float32), np.array(a.sum()), np.array(np.abs(a).sum())
+
+
+def check_compact(g, key, arr, rtol, atol):
+    """Compare `arr` with golden entry `key` (full array or compact form)."""
+    arr = np.asarray(arr, dtype=np.float64)
+    if key in g:
+        np.testing.assert_allclose(arr, g[key], rtol=rtol, atol=atol)
+        return
+    assert tuple(g[key + "__shape"]) == arr.shape, (key, arr.shape)
+    sub, _, _ = compact(arr)
+    np.testing.assert_allclose(sub, g[key + "__sub"], rtol=rtol, atol=atol)
+    scale = float(g[key + "__abs"])
+    assert abs(arr.sum() - float(g[key + "__sum"])) <= rtol * scale + atol * arr.size, key
+    assert abs(np.abs(arr).sum() - scale) <= rtol * scale + atol * arr.size, key
