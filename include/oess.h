@@ -181,6 +181,34 @@ int oess_masked_stats_slice_f32(const float* in, int B, int Ctot, int c0, int Cs
 int oess_event_slice_to_nhwc8_bf16(const float* in, int B, int Ctot, int c0, int Cs, long long HW, const double* stats,
                                    int normalize, void* out_nhwc8, oess_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Normalisation and resampling on NHWC bf16 (pixel strides in elements, C % 8 == 0).
+ * Replace nn.BatchNorm2d (train-mode batch statistics; models/_resnet.py:74-114, image_model.py:130-143),
+ * nn.InstanceNorm2d + ReLU (models/style_networks.py:252-289), F.interpolate(nearest, x2)
+ * (style_networks.py:148-160) and nn.Upsample(x4, bilinear, align_corners=True) + F.normalize
+ * (image_model.py:121-143).  G groups of pixels_per_group pixels: G = 1 BatchNorm, G = B InstanceNorm.
+ * ------------------------------------------------------------------------------------------ */
+int oess_norm_stats_nhwc_bf16(const void* x, long long x_pix_stride, int G, long long pixels_per_group, int C,
+                              float* sum, float* sumsq, oess_stream_t stream);
+/* mean/rstd/scale/shift are [G x C]; gamma/beta/running_* nullable; running stats updated when G == 1 */
+int oess_norm_finalize(const float* sum, const float* sumsq, int G, int C, float count, float eps, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, float momentum, float* mean,
+                       float* rstd, float* scale, float* shift, oess_stream_t stream);
+/* out = act(x*scale + shift [+ residual]) */
+int oess_norm_apply_nhwc_bf16(const void* x, long long x_pix_stride, const float* scale, const float* shift,
+                              const void* residual, long long res_pix_stride, int relu, int G, long long pixels_per_group,
+                              int C, void* out, long long out_pix_stride, oess_stream_t stream);
+/* affine-free InstanceNorm (+ReLU) backward; s1/s2 are [G x C] scratch */
+int oess_instnorm_bwd_nhwc_bf16(const void* x, long long x_pix_stride, const void* dy, long long dy_pix_stride,
+                                const float* mean, const float* rstd, int relu, int G, long long pixels_per_group, int C,
+                                float* s1, float* s2, void* dx, long long dx_pix_stride, oess_stream_t stream);
+int oess_upsample_nearest2x_nhwc_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int C, void* out,
+                                      long long out_pix_stride, oess_stream_t stream);
+int oess_downsample_sum2x_nhwc_bf16(const void* gout, long long gout_pix_stride, int B, int H, int W, int C, void* gin,
+                                    long long gin_pix_stride, oess_stream_t stream);
+int oess_bilinear_l2norm_nhwc_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int C, int scale,
+                                   int normalize, void* out, long long out_pix_stride, oess_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,363 @@
+// Normalisation / resampling kernels on NHWC bf16 activations for gfx950 (all HBM-bound streaming
+// kernels: 16-byte accesses, fp32 statistics, one atomic per (workgroup, channel)).
+//   - per-channel statistics over G groups (G = 1: BatchNorm batch statistics; G = B: InstanceNorm)
+//   - finalize (mean / rstd / affine -> scale, shift; BatchNorm running-stat update)
+//   - apply  y = act(x*scale + shift [+ residual])
+//   - InstanceNorm(+ReLU) backward: statistics pass + apply pass
+//   - nearest x2 upsample into a channel slice (fwd) and its adjoint (2x2 sum)
+//   - bilinear x4 (align_corners=True) fused with the L2 channel normalisation of the teacher head
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "oess.h"
+#include "oess_common.h"
+
+namespace {
+using namespace oess;
+constexpr int THREADS = 256;
+constexpr int PIX_PER_WG = 1024;
+
+union Pack8 { uint4 q; uint16_t h[8]; };
+
+// ---------------------------------------------------------------------------------------------
+// statistics: sum[g][c], sumsq[g][c] over the pixels of group g.  grid = (chunks, G).
+// thread layout: cl = C/8 channel-lanes per pixel (power of two not required), rows = THREADS/cl pixels in flight.
+// MODE 0: plain sums of x.   MODE 1 (InstanceNorm backward): s1 = sum g, s2 = sum g*xhat with
+//         xhat = (x-mean)*rstd, g = dy * (relu ? xhat > 0 : 1).
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(THREADS) void stats_kernel(const uint16_t* __restrict__ x, int64_t xps,
+                                                        const uint16_t* __restrict__ dy, int64_t dps,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        int relu, int64_t ppg, int C, float* __restrict__ o1,
+                                                        float* __restrict__ o2) {
+    extern __shared__ float red[];                 // [rows][C][2]
+    const int cl = C >> 3;
+    const int rows = THREADS / cl;
+    const int lane_c = threadIdx.x % cl, row = threadIdx.x / cl;
+    const int g = blockIdx.y;
+    const int64_t p_beg = (int64_t)blockIdx.x * PIX_PER_WG;
+    int64_t p_end = p_beg + PIX_PER_WG;
+    if (p_end > ppg) p_end = ppg;
+    float a1[8], a2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a1[k] = 0.f; a2[k] = 0.f; }
+    float mu[8], rs[8];
+    if (MODE == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { mu[k] = mean[(int64_t)g * C + lane_c * 8 + k]; rs[k] = rstd[(int64_t)g * C + lane_c * 8 + k]; }
+    }
+    if (row < rows) {
+        for (int64_t p = p_beg + row; p < p_end; p += rows) {
+            const int64_t pix = (int64_t)g * ppg + p;
+            Pack8 v;
+            v.q = *reinterpret_cast<const uint4*>(x + pix * xps + lane_c * 8);
+            if (MODE == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float f = bf16_to_f32(v.h[k]); a1[k] += f; a2[k] += f * f; }
+            } else {
+                Pack8 d;
+                d.q = *reinterpret_cast<const uint4*>(dy + pix * dps + lane_c * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float xh = (bf16_to_f32(v.h[k]) - mu[k]) * rs[k];
+                    float gg = bf16_to_f32(d.h[k]);
+                    if (relu && !(xh > 0.f)) gg = 0.f;
+                    a1[k] += gg; a2[k] += gg * xh;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            red[(row * C + lane_c * 8 + k) * 2 + 0] = a1[k];
+            red[(row * C + lane_c * 8 + k) * 2 + 1] = a2[k];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += THREADS) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int r = 0; r < rows; ++r) { s1 += red[(r * C + c) * 2]; s2 += red[(r * C + c) * 2 + 1]; }
+        atomicAdd(&o1[(int64_t)g * C + c], s1);
+        atomicAdd(&o2[(int64_t)g * C + c], s2);
+    }
+}
+
+// mean / rstd / (scale, shift) per (group, channel); optional BatchNorm running-stat update (G == 1).
+__global__ void finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, int G, int C, float count,
+                                float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                                float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ scale,
+                                float* __restrict__ shift) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * C) return;
+    const int c = i % C;
+    const float m = sum[i] / count;
+    float var = sumsq[i] / count - m * m;        // biased variance (normalisation uses it in BN and IN)
+    if (var < 0.f) var = 0.f;
+    const float r = rsqrtf(var + eps);
+    mean_out[i] = m; rstd_out[i] = r;
+    const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+    scale[i] = ga * r;
+    shift[i] = be - m * ga * r;
+    if (running_mean && G == 1) {                // nn.BatchNorm2d: running_var uses the UNBIASED estimate
+        const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void apply_kernel(const uint16_t* __restrict__ x, int64_t xps,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        const uint16_t* __restrict__ res, int64_t rps, int relu,
+                                                        int64_t ppg, int G, int C, uint16_t* __restrict__ out, int64_t ops) {
+    const int cl = C >> 3;
+    const int64_t total = (int64_t)G * ppg * cl;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * THREADS) {
+        const int64_t pix = i / cl;
+        const int c0 = (int)(i - pix * cl) * 8;
+        const int64_t g = pix / ppg;
+        Pack8 v, r, o;
+        v.q = *reinterpret_cast<const uint4*>(x + pix * xps + c0);
+        if (res) r.q = *reinterpret_cast<const uint4*>(res + pix * rps + c0);
+        const float4 s0 = *reinterpret_cast<const float4*>(scale + g * C + c0), s1 = *reinterpret_cast<const float4*>(scale + g * C + c0 + 4);
+        const float4 h0 = *reinterpret_cast<const float4*>(shift + g * C + c0), h1 = *reinterpret_cast<const float4*>(shift + g * C + c0 + 4);
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float f = bf16_to_f32(v.h[k]) * sc[k] + sh[k];
+            if (res) f += bf16_to_f32(r.h[k]);
+            if (relu) f = fmaxf(f, 0.f);
+            o.h[k] = f32_to_bf16(f);
+        }
+        *reinterpret_cast<uint4*>(out + pix * ops + c0) = o.q;
+    }
+}
+
+// InstanceNorm (affine-free) backward: dx = rstd * (g - s1/N - xhat * s2/N)
+__global__ __launch_bounds__(THREADS) void in_bwd_apply_kernel(const uint16_t* __restrict__ x, int64_t xps,
+                                                               const uint16_t* __restrict__ dy, int64_t dps,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ s1, const float* __restrict__ s2,
+                                                               int relu, int64_t ppg, int G, int C,
+                                                               uint16_t* __restrict__ dx, int64_t gps) {
+    const int cl = C >> 3;
+    const float invn = 1.0f / (float)ppg;
+    const int64_t total = (int64_t)G * ppg * cl;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * THREADS) {
+        const int64_t pix = i / cl;
+        const int c0 = (int)(i - pix * cl) * 8;
+        const int64_t g = pix / ppg;
+        Pack8 v, d, o;
+        v.q = *reinterpret_cast<const uint4*>(x + pix * xps + c0);
+        d.q = *reinterpret_cast<const uint4*>(dy + pix * dps + c0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t gc = g * C + c0 + k;
+            const float r = rstd[gc];
+            const float xh = (bf16_to_f32(v.h[k]) - mean[gc]) * r;
+            float gg = bf16_to_f32(d.h[k]);
+            if (relu && !(xh > 0.f)) gg = 0.f;
+            o.h[k] = f32_to_bf16(r * (gg - s1[gc] * invn - xh * s2[gc] * invn));
+        }
+        *reinterpret_cast<uint4*>(dx + pix * gps + c0) = o.q;
+    }
+}
+
+// nearest x2: out[b, 2y+dy, 2x+dx, :] = in[b, y, x, :]   (F.interpolate(scale_factor=2, mode='nearest'))
+__global__ __launch_bounds__(THREADS) void up2_kernel(const uint16_t* __restrict__ in, int64_t ips, int B, int H, int W,
+                                                      int C, uint16_t* __restrict__ out, int64_t ops) {
+    const int cl = C >> 3;
+    const int64_t total = (int64_t)B * (2 * H) * (2 * W) * cl;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * THREADS) {
+        const int64_t opix = i / cl;
+        const int c0 = (int)(i - opix * cl) * 8;
+        const int ox = (int)(opix % (2 * W));
+        const int64_t t = opix / (2 * W);
+        const int oy = (int)(t % (2 * H));
+        const int64_t b = t / (2 * H);
+        const int64_t ipix = (b * H + (oy >> 1)) * W + (ox >> 1);
+        *reinterpret_cast<uint4*>(out + opix * ops + c0) = *reinterpret_cast<const uint4*>(in + ipix * ips + c0);
+    }
+}
+
+// adjoint: gin[b, y, x, :] = sum of the 2x2 block of gout
+__global__ __launch_bounds__(THREADS) void down2_sum_kernel(const uint16_t* __restrict__ gout, int64_t gps, int B, int H, int W,
+                                                            int C, uint16_t* __restrict__ gin, int64_t ips) {
+    const int cl = C >> 3;
+    const int64_t total = (int64_t)B * H * W * cl;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * THREADS) {
+        const int64_t ipix = i / cl;
+        const int c0 = (int)(i - ipix * cl) * 8;
+        const int x = (int)(ipix % W);
+        const int64_t t = ipix / W;
+        const int y = (int)(t % H);
+        const int64_t b = t / H;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int64_t opix = (b * 2 * H + 2 * y + dy) * (2 * W) + 2 * x + dx;
+                Pack8 v;
+                v.q = *reinterpret_cast<const uint4*>(gout + opix * gps + c0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += bf16_to_f32(v.h[k]);
+            }
+        Pack8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o.h[k] = f32_to_bf16(acc[k]);
+        *reinterpret_cast<uint4*>(gin + ipix * ips + c0) = o.q;
+    }
+}
+
+// bilinear upsample by `scale` with align_corners=True, then L2-normalise over channels (eps 1e-12):
+// nn.Upsample(scale_factor=4, bilinear, align_corners=True) + F.normalize(p=2, dim=1)  (image_model.py:121-143)
+// one wave per output pixel, lane handles C/64 channels (C = 256 -> 4).
+__global__ __launch_bounds__(THREADS) void bilinear_l2_kernel(const uint16_t* __restrict__ in, int64_t ips, int B, int H,
+                                                              int W, int C, int scale, int normalize,
+                                                              uint16_t* __restrict__ out, int64_t ops) {
+    const int Ho = H * scale, Wo = W * scale;
+    const float ry = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float rx = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cpl = C >> 6;                        // channels per lane (C % 64 == 0, cpl <= 8)
+    const int64_t total = (int64_t)B * Ho * Wo;
+    for (int64_t opix = (int64_t)blockIdx.x * (THREADS / 64) + wave; opix < total; opix += (int64_t)gridDim.x * (THREADS / 64)) {
+        const int ox = (int)(opix % Wo);
+        const int64_t t = opix / Wo;
+        const int oy = (int)(t % Ho);
+        const int64_t b = t / Ho;
+        const float fy = ry * oy, fx = rx * ox;
+        int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = (y0 < H - 1) ? y0 + 1 : y0, x1 = (x0 < W - 1) ? x0 + 1 : x0;
+        const float wy = fy - y0, wx = fx - x0;
+        const uint16_t* p00 = in + ((b * H + y0) * W + x0) * ips + lane * cpl;
+        const uint16_t* p01 = in + ((b * H + y0) * W + x1) * ips + lane * cpl;
+        const uint16_t* p10 = in + ((b * H + y1) * W + x0) * ips + lane * cpl;
+        const uint16_t* p11 = in + ((b * H + y1) * W + x1) * ips + lane * cpl;
+        float v[8];
+        float ss = 0.f;
+        for (int k = 0; k < cpl; ++k) {
+            const float a = bf16_to_f32(p00[k]), bb = bf16_to_f32(p01[k]), c = bf16_to_f32(p10[k]), d = bf16_to_f32(p11[k]);
+            const float top = a + (bb - a) * wx, bot = c + (d - c) * wx;
+            v[k] = top + (bot - top) * wy;
+            ss += v[k] * v[k];
+        }
+        float inv = 1.0f;
+        if (normalize) {
+            ss = wave_sum(ss);
+            inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        }
+        uint16_t* o = out + opix * ops + lane * cpl;
+        for (int k = 0; k < cpl; ++k) o[k] = f32_to_bf16(v[k] * inv);
+    }
+}
+
+int grid_for(int64_t work) {
+    int64_t g = (work + THREADS - 1) / THREADS;
+    if (g < 1) g = 1;
+    if (g > 8192) g = 8192;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int oess_norm_stats_nhwc_bf16(const void* x, long long x_pix_stride, int G, long long pixels_per_group, int C,
+                              float* sum, float* sumsq, oess_stream_t stream) {
+    if (!x || !sum || !sumsq || G <= 0 || pixels_per_group <= 0 || C <= 0 || (C & 7) || C > 2048 || (x_pix_stride & 7))
+        return OESS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    OESS_HIP(hipMemsetAsync(sum, 0, (size_t)G * C * sizeof(float), st));
+    OESS_HIP(hipMemsetAsync(sumsq, 0, (size_t)G * C * sizeof(float), st));
+    const int cl = C >> 3;
+    if (cl > THREADS) return OESS_EINVAL;
+    const int rows = THREADS / cl;
+    const size_t lds = (size_t)rows * C * 2 * sizeof(float);
+    dim3 grid((unsigned)((pixels_per_group + PIX_PER_WG - 1) / PIX_PER_WG), (unsigned)G);
+    hipLaunchKernelGGL(stats_kernel<0>, grid, dim3(THREADS), lds, st, (const uint16_t*)x, (int64_t)x_pix_stride, nullptr,
+                       (int64_t)0, nullptr, nullptr, 0, (int64_t)pixels_per_group, C, sum, sumsq);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_norm_finalize(const float* sum, const float* sumsq, int G, int C, float count, float eps, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, float momentum, float* mean,
+                       float* rstd, float* scale, float* shift, oess_stream_t stream) {
+    if (!sum || !sumsq || !mean || !rstd || !scale || !shift || G <= 0 || C <= 0 || count <= 0.f) return OESS_EINVAL;
+    hipLaunchKernelGGL(finalize_kernel, dim3((G * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sum, sumsq, G, C, count,
+                       eps, gamma, beta, running_mean, running_var, momentum, mean, rstd, scale, shift);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_norm_apply_nhwc_bf16(const void* x, long long x_pix_stride, const float* scale, const float* shift,
+                              const void* residual, long long res_pix_stride, int relu, int G, long long pixels_per_group,
+                              int C, void* out, long long out_pix_stride, oess_stream_t stream) {
+    if (!x || !scale || !shift || !out || G <= 0 || pixels_per_group <= 0 || C <= 0 || (C & 7) || (x_pix_stride & 7) ||
+        (out_pix_stride & 7) || (residual && (res_pix_stride & 7)))
+        return OESS_EINVAL;
+    hipLaunchKernelGGL(apply_kernel, dim3(grid_for((int64_t)G * pixels_per_group * (C >> 3))), dim3(THREADS), 0,
+                       (hipStream_t)stream, (const uint16_t*)x, (int64_t)x_pix_stride, scale, shift, (const uint16_t*)residual,
+                       (int64_t)res_pix_stride, relu, (int64_t)pixels_per_group, G, C, (uint16_t*)out, (int64_t)out_pix_stride);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_instnorm_bwd_nhwc_bf16(const void* x, long long x_pix_stride, const void* dy, long long dy_pix_stride,
+                                const float* mean, const float* rstd, int relu, int G, long long pixels_per_group, int C,
+                                float* s1, float* s2, void* dx, long long dx_pix_stride, oess_stream_t stream) {
+    if (!x || !dy || !mean || !rstd || !s1 || !s2 || !dx || G <= 0 || pixels_per_group <= 0 || C <= 0 || (C & 7) ||
+        C > 2048 || (x_pix_stride & 7) || (dy_pix_stride & 7) || (dx_pix_stride & 7))
+        return OESS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    OESS_HIP(hipMemsetAsync(s1, 0, (size_t)G * C * sizeof(float), st));
+    OESS_HIP(hipMemsetAsync(s2, 0, (size_t)G * C * sizeof(float), st));
+    const int cl = C >> 3;
+    if (cl > THREADS) return OESS_EINVAL;
+    const int rows = THREADS / cl;
+    const size_t lds = (size_t)rows * C * 2 * sizeof(float);
+    dim3 grid((unsigned)((pixels_per_group + PIX_PER_WG - 1) / PIX_PER_WG), (unsigned)G);
+    hipLaunchKernelGGL(stats_kernel<1>, grid, dim3(THREADS), lds, st, (const uint16_t*)x, (int64_t)x_pix_stride,
+                       (const uint16_t*)dy, (int64_t)dy_pix_stride, mean, rstd, relu, (int64_t)pixels_per_group, C, s1, s2);
+    hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(grid_for((int64_t)G * pixels_per_group * cl)), dim3(THREADS), 0, st,
+                       (const uint16_t*)x, (int64_t)x_pix_stride, (const uint16_t*)dy, (int64_t)dy_pix_stride, mean, rstd, s1,
+                       s2, relu, (int64_t)pixels_per_group, G, C, (uint16_t*)dx, (int64_t)dx_pix_stride);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_upsample_nearest2x_nhwc_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int C, void* out,
+                                      long long out_pix_stride, oess_stream_t stream) {
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || (in_pix_stride & 7) || (out_pix_stride & 7))
+        return OESS_EINVAL;
+    hipLaunchKernelGGL(up2_kernel, dim3(grid_for((int64_t)B * 4 * H * W * (C >> 3))), dim3(THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)in, (int64_t)in_pix_stride, B, H, W, C, (uint16_t*)out, (int64_t)out_pix_stride);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_downsample_sum2x_nhwc_bf16(const void* gout, long long gout_pix_stride, int B, int H, int W, int C, void* gin,
+                                    long long gin_pix_stride, oess_stream_t stream) {
+    if (!gout || !gin || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || (gout_pix_stride & 7) || (gin_pix_stride & 7))
+        return OESS_EINVAL;
+    hipLaunchKernelGGL(down2_sum_kernel, dim3(grid_for((int64_t)B * H * W * (C >> 3))), dim3(THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)gout, (int64_t)gout_pix_stride, B, H, W, C, (uint16_t*)gin, (int64_t)gin_pix_stride);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_bilinear_l2norm_nhwc_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int C, int scale,
+                                   int normalize, void* out, long long out_pix_stride, oess_stream_t stream) {
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 63) || C > 512 || scale <= 0) return OESS_EINVAL;
+    const int64_t total = (int64_t)B * H * scale * W * scale;
+    int64_t g = (total + 3) / 4;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(bilinear_l2_kernel, dim3((unsigned)g), dim3(THREADS), 0, (hipStream_t)stream, (const uint16_t*)in,
+                       (int64_t)in_pix_stride, B, H, W, C, scale, normalize, (uint16_t*)out, (int64_t)out_pix_stride);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+}  // extern "C"

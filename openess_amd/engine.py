@@ -143,6 +143,13 @@ def batch_norm_act(x, bn, relu=False, residual=None):
     """BatchNorm2d (+ residual add + ReLU) on a channels_last bf16 tensor, honouring bn.training exactly
     like nn.BatchNorm2d (batch statistics + running-stat update in train mode).  Still an ATen call; the
     fused stats-in-conv-epilogue kernel is the next step."""
+    if bn.training and not (torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad)) \
+            and x.dtype == torch.bfloat16 and x.stride(1) == 1 and x.shape[1] % 8 == 0:
+        r = None
+        if residual is not None:
+            r = residual if residual.stride(1) == 1 else residual.contiguous(memory_format=torch.channels_last)
+            r = nhwc(r)
+        return from_nhwc(hip.batch_norm_train_nhwc(nhwc(x), bn, relu=relu, residual=r))
     y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training,
                      0.0 if bn.momentum is None else bn.momentum, bn.eps)
     if bn.training and bn.num_batches_tracked is not None:

@@ -419,3 +419,137 @@ def conv2d_nhwc(x, packed, bias, Cout, R, S, stride=1, pad=0, dil=1, relu=False,
     t["events"].append((e0, e1))
     t["flops"] += 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * Cout * x.shape[3] * R * S
     return y
+
+
+# ------------------------------------------------------------------------------------------ norms / resampling
+def _norm_forward(x_nhwc, G, gamma, beta, eps, relu, residual, running=None, momentum=0.1, out=None):
+    """Shared BatchNorm(train)/InstanceNorm forward on an NHWC bf16 view.  Returns (out, mean, rstd)."""
+    lib = _lib.load()
+    B, H, W, C, ps = _nhwc_geom(x_nhwc)
+    ppg = (B * H * W) // G
+    dev = x_nhwc.device
+    stats = torch.empty((6, G, C), dtype=torch.float32, device=dev)        # sum, sumsq, mean, rstd, scale, shift
+    _lib.check(lib.oess_norm_stats_nhwc_bf16(_ptr(x_nhwc), ps, G, ppg, C, _ptr(stats[0]), _ptr(stats[1]), _stream()),
+               "oess_norm_stats_nhwc_bf16")
+    rm = rv = None
+    if running is not None:
+        rm, rv = running
+    _lib.check(lib.oess_norm_finalize(_ptr(stats[0]), _ptr(stats[1]), G, C, float(ppg), float(eps), _ptr(gamma), _ptr(beta),
+                                      _ptr(rm), _ptr(rv), float(momentum), _ptr(stats[2]), _ptr(stats[3]), _ptr(stats[4]),
+                                      _ptr(stats[5]), _stream()), "oess_norm_finalize")
+    if out is None:
+        out = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=dev)
+    _, _, _, _, ops = _nhwc_geom(out)
+    rps = 0
+    if residual is not None:
+        _, _, _, _, rps = _nhwc_geom(residual)
+    _lib.check(lib.oess_norm_apply_nhwc_bf16(_ptr(x_nhwc), ps, _ptr(stats[4]), _ptr(stats[5]), _ptr(residual), rps, int(relu),
+                                             G, ppg, C, _ptr(out), ops, _stream()), "oess_norm_apply_nhwc_bf16")
+    return out, stats[2], stats[3]
+
+
+def batch_norm_train_nhwc(x_nhwc, bn, relu=False, residual=None):
+    """nn.BatchNorm2d in TRAIN mode (batch statistics, running-stat update), inference-only (no autograd):
+    the frozen teacher encoder (image_model.py:113-114 freezes it but leaves it in .train())."""
+    out, _, _ = _norm_forward(x_nhwc, 1, bn.weight.detach(), bn.bias.detach(), bn.eps, relu, residual,
+                              running=(bn.running_mean, bn.running_var),
+                              momentum=0.0 if bn.momentum is None else bn.momentum)
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return out
+
+
+class _InstanceNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, relu, residual, eps):
+        xn = x.permute(0, 2, 3, 1)
+        rn = None if residual is None else residual.permute(0, 2, 3, 1)
+        out, mean, rstd = _norm_forward(xn, x.shape[0], None, None, eps, relu, rn)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.relu = relu
+        ctx.has_res = residual is not None
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, mean, rstd = ctx.saved_tensors
+        gy = gy.to(torch.bfloat16)
+        if gy.stride(1) != 1:
+            gy = gy.contiguous(memory_format=torch.channels_last)
+        xn, gn = x.permute(0, 2, 3, 1), gy.permute(0, 2, 3, 1)
+        B, H, W, C, xps = _nhwc_geom(xn)
+        _, _, _, _, gps = _nhwc_geom(gn)
+        dx = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=x.device)
+        s = torch.empty((2, B, C), dtype=torch.float32, device=x.device)
+        _lib.check(lib.oess_instnorm_bwd_nhwc_bf16(_ptr(xn), xps, _ptr(gn), gps, _ptr(mean), _ptr(rstd), int(ctx.relu), B, H * W,
+                                                   C, _ptr(s[0]), _ptr(s[1]), _ptr(dx), C, _stream()),
+                   "oess_instnorm_bwd_nhwc_bf16")
+        return dx.permute(0, 3, 1, 2), None, (gy if ctx.has_res else None), None
+
+
+def instance_norm(x, relu=False, residual=None, eps=1e-5):
+    """nn.InstanceNorm2d(affine=False) [+ residual add] [+ ReLU] on a logical-NCHW channels_last bf16 tensor."""
+    _need_gpu(x)
+    if relu and residual is not None:
+        raise NotImplementedError("ReLU after the residual add is not a pattern of the reference (the backward mask "
+                                  "would depend on the residual)")
+    if x.dtype != torch.bfloat16 or x.stride(1) != 1:
+        x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    if residual is not None and (residual.dtype != torch.bfloat16 or residual.stride(1) != 1):
+        residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    return _InstanceNormFn.apply(x, bool(relu), residual, float(eps))
+
+
+class _UpsampleConcatFn(torch.autograd.Function):
+    """cat([F.interpolate(x, scale_factor=2, mode='nearest'), skip], 1) written straight into one NHWC buffer."""
+
+    @staticmethod
+    def forward(ctx, x, skip):
+        lib = _lib.load()
+        xn = x.permute(0, 2, 3, 1)
+        B, H, W, C, ps = _nhwc_geom(xn)
+        Cs = 0 if skip is None else skip.shape[1]
+        buf = torch.empty((B, 2 * H, 2 * W, C + Cs), dtype=torch.bfloat16, device=x.device)
+        _lib.check(lib.oess_upsample_nearest2x_nhwc_bf16(_ptr(xn), ps, B, H, W, C, _ptr(buf), C + Cs, _stream()),
+                   "oess_upsample_nearest2x_nhwc_bf16")
+        if skip is not None:
+            buf[..., C:] = skip.permute(0, 2, 3, 1)
+        ctx.meta = (B, H, W, C, Cs)
+        return buf.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        B, H, W, C, Cs = ctx.meta
+        g = g.to(torch.bfloat16)
+        if g.stride(1) != 1:
+            g = g.contiguous(memory_format=torch.channels_last)
+        gn = g.permute(0, 2, 3, 1)
+        _, _, _, _, gps = _nhwc_geom(gn)
+        gx = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=g.device)
+        _lib.check(lib.oess_downsample_sum2x_nhwc_bf16(_ptr(gn), gps, B, H, W, C, _ptr(gx), C, _stream()),
+                   "oess_downsample_sum2x_nhwc_bf16")
+        gskip = None
+        if Cs and ctx.needs_input_grad[1]:
+            gskip = g[:, C:]
+        return gx.permute(0, 3, 1, 2), gskip
+
+
+def upsample2x_concat(x, skip=None):
+    _need_gpu(x)
+    if x.dtype != torch.bfloat16 or x.stride(1) != 1:
+        x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    return _UpsampleConcatFn.apply(x, skip)
+
+
+def bilinear_l2norm(x, scale=4, normalize=True):
+    """nn.Upsample(scale, bilinear, align_corners=True) + F.normalize(dim=1), inference form (no autograd)."""
+    lib = _lib.load()
+    _need_gpu(x)
+    xn = x.permute(0, 2, 3, 1)
+    B, H, W, C, ps = _nhwc_geom(xn)
+    out = torch.empty((B, H * scale, W * scale, C), dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.oess_bilinear_l2norm_nhwc_bf16(_ptr(xn), ps, B, H, W, C, scale, int(normalize), _ptr(out), C, _stream()),
+               "oess_bilinear_l2norm_nhwc_bf16")
+    return out.permute(0, 3, 1, 2)

@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import engine
+from .. import engine, hip
 from ._resnet import Bottleneck, HipConv2d, ResNet
 
 
@@ -44,7 +44,8 @@ class DilationFeatureExtractor(nn.Module):
         with torch.no_grad():                      # encoder params are frozen (image_model.py:113-114)
             x = self.encoder(x)
         x = self.decoder[0](x)
-        x = F.interpolate(x, scale_factor=4, mode="bilinear", align_corners=True)
-        if self.normalize_feature:
-            x = F.normalize(x, p=2, dim=1)
-        return x
+        if torch.is_grad_enabled() and x.requires_grad:
+            # differentiable path (contrastive loss active): library resampler until the adjoint kernel lands
+            x = F.interpolate(x, scale_factor=4, mode="bilinear", align_corners=True)
+            return F.normalize(x, p=2, dim=1) if self.normalize_feature else x
+        return hip.bilinear_l2norm(x, 4, self.normalize_feature)

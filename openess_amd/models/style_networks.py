@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as f
 
-from .. import engine
+from .. import engine, hip
 
 
 def gaussian_weights_init(m):
@@ -40,9 +40,9 @@ def _conv(n_in, n_out, kernel_size, stride=1, padding=0, bias=True):
     return m
 
 
-def _instance_norm(x, relu):
-    y = f.instance_norm(x)                      # affine=False, no running stats (nn.InstanceNorm2d defaults)
-    return f.relu(y) if relu else y
+def _instance_norm(x, relu, residual=None):
+    # nn.InstanceNorm2d defaults: affine=False, no running stats, eps=1e-5; fused [+ residual] [+ ReLU]
+    return hip.instance_norm(x, relu=relu, residual=residual)
 
 
 class ReLUINSConv2d(nn.Module):
@@ -66,10 +66,9 @@ class INSResBlock(nn.Module):
 
     def forward(self, x):
         out = _instance_norm(self.model[0](x), relu=True)
-        out = _instance_norm(self.model[3](out), relu=False)
         if len(self.model) > 5:
-            out = self.model[5](out)
-        return out + x
+            return self.model[5](_instance_norm(self.model[3](out), relu=False)) + x
+        return _instance_norm(self.model[3](out), relu=False, residual=x)      # out += residual (:287)
 
 
 def skip_concat(x1, x2):
@@ -143,16 +142,16 @@ class SemSegE2VID(nn.Module):
         sz_in = input_dict[1].shape[3]
         x = input_dict[8]
         out = {8: x}
+        concat = self.skip_type != 'sum'
         x = self.decoder_scale_1(x)
-        x = f.interpolate(x, scale_factor=2, mode='nearest')
-        x = self.apply_skip_connection(x, input_dict[4])
+        # nearest x2 + skip concat written into one NHWC buffer (no separate interpolate / cat tensors)
+        x = hip.upsample2x_concat(x, input_dict[4]) if concat else hip.upsample2x_concat(x) + input_dict[4]
         x = self.decoder_scale_2(x)
         self.update_skip_dict(out, x, sz_in)
-        x = f.interpolate(x, scale_factor=2, mode='nearest')
-        x = self.apply_skip_connection(x, input_dict[2])
+        x = hip.upsample2x_concat(x, input_dict[2]) if concat else hip.upsample2x_concat(x) + input_dict[2]
         x = self.decoder_scale_3(x)
         self.update_skip_dict(out, x, sz_in)
-        x = f.interpolate(x, scale_factor=2, mode='nearest')
+        x = hip.upsample2x_concat(x)
         x = self.decoder_scale_4(x)
         x_ch256 = self.decoder_ch256[0](x) if self.materialize_ch256 else None
         wf, bf = self._composed_head()
