@@ -209,6 +209,14 @@ int oess_downsample_sum2x_nhwc_bf16(const void* gout, long long gout_pix_stride,
 int oess_bilinear_l2norm_nhwc_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int C, int scale,
                                    int normalize, void* out, long long out_pix_stride, oess_stream_t stream);
 
+/* Weight gradient of oess_conv2d_fwd_bf16's convolution: dW (OIHW fp32, ACCUMULATED into: zero it first)
+ * from x (NHWC bf16, Cin_x >= Cin channels present, Cin_x % 8 == 0) and dy (NHWC bf16, Cout % 8 == 0).
+ * Replaces the weight half of ATen's convolution_backward behind nn.Conv2d (models/style_networks.py:252-289). */
+int oess_conv2d_wgrad_bf16(const void* x, long long x_pix_stride, int B, int H, int W, int Cin_x, const void* dy,
+                           long long dy_pix_stride, int Cout, int Cin, int R, int S, int stride, int pad, int dil,
+                           float* dw_oihw, void* workspace, size_t workspace_bytes, oess_stream_t stream);
+/* workspace: split-K partial tiles; any size >= one padded tile set works, 64 MiB lets the kernel use full parallelism */
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,8 @@ SIGNATURES = {
     "oess_upsample_nearest2x_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp, c_ll, c_vp]),
     "oess_downsample_sum2x_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp, c_ll, c_vp]),
     "oess_bilinear_l2norm_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_ll, c_vp]),
+    "oess_conv2d_wgrad_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp, c_ll, c_int, c_int, c_int, c_int,
+                                       c_int, c_int, c_int, c_vp, c_vp, c_sz, c_vp]),
     "oess_conv2d_packed_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     "oess_conv2d_pack_weight": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
     "oess_conv2d_fwd_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,

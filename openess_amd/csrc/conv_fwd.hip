@@ -65,8 +65,10 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_fwd_kernel(ConvArgs a) {
     constexpr int B_ROWS_PER_THREAD = BN / 32;   // 16-byte chunks of the B slab per thread
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32x4_t* lA = reinterpret_cast<u32x4_t*>(smem);              // [BM][8] chunks
-    u32x4_t* lB = lA + BM * 8;                                     // [BN][8] chunks
+    // LDS: 2 x { A slab [BM][8] chunks, B slab [BN][8] chunks } (double buffered), then the tap table
+    constexpr int STAGE_CHUNKS = (BM + BN) * 8;
+    u32x4_t* lbase = reinterpret_cast<u32x4_t*>(smem);
+    int2* ltab = reinterpret_cast<int2*>(smem + 2 * STAGE_CHUNKS * 16);      // [Kpad/8] {element offset, dy | dx<<16}
 
     // ---- XCD-aware tile mapping (bijective): consecutive logical tiles share an XCD's L2
     const int nwg = a.tiles_m * a.tiles_n;
@@ -80,59 +82,76 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_fwd_kernel(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int KT = a.Kpad / BK;
+
+    // ---- tap table, built once per workgroup: chunk kc -> (r, s, channel chunk).  Keeps the two integer
+    //      divisions out of the K loop (they were ~40 % of its VALU work).
+    {
+        const int cpt = a.Cin >> 3, ntaps = a.R * a.S;
+        for (int kc = tid; kc < KT * 8; kc += CONV_THREADS) {
+            const int tap = kc / cpt, cc = kc - tap * cpt;
+            const int r = tap / a.S, s = tap - r * a.S;
+            int2 e;
+            if (tap < ntaps) {
+                const int dy = r * a.dil, dx = s * a.dil;
+                e.x = (dy * a.W + dx) * (int)a.in_pix_stride + cc * 8;
+                e.y = (dy & 0xffff) | (dx << 16);
+            } else {
+                e.x = 0;
+                e.y = 0x7fff | (0x7fff << 16);                  // far outside: fails every bounds test
+            }
+            ltab[kc] = e;
+        }
+    }
 
     // ---- per-thread gather state: chunk column c (fixed), rows (tid>>3) + 32*i
     const int c = tid & 7;
     const int row0 = tid >> 3;
     int iy0[4], ix0[4];
-    long long pbase[4];
-    bool rvalid[4];
+    const uint16_t* rowptr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + row0 + 32 * i;
-        rvalid[i] = m < a.M;
-        const int mm = rvalid[i] ? m : 0;
+        const bool valid = m < a.M;
+        const int mm = valid ? m : 0;
         const int hw = a.Ho * a.Wo;
         const int b = mm / hw, rem = mm - b * hw;
         const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-        iy0[i] = oy * a.stride - a.pad;
+        iy0[i] = valid ? oy * a.stride - a.pad : -0x4000;       // invalid rows fail the bounds test
         ix0[i] = ox * a.stride - a.pad;
-        pbase[i] = (long long)b * a.H * a.W;
+        rowptr[i] = a.in + (((long long)b * a.H + (oy * a.stride - a.pad)) * a.W + ix0[i]) * a.in_pix_stride;
     }
-    const int cpt = a.Cin >> 3;                   // 16-byte chunks per filter tap
-    const int ntaps = a.R * a.S;
-    const int KT = a.Kpad / BK;
     const uint16_t* wrow = a.w + (size_t)(n0 + row0) * a.Kpad + c * 8;
 
     u32x4_t ra[4], rb[B_ROWS_PER_THREAD];
+    const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+    // global -> registers for K-slab KT_IDX.  Loads are unconditional (clamped to the tensor base) and
+    // zeroed by select afterwards, so the four gathers issue back to back without exec-mask branches.
 #define OESS_GLOAD(KT_IDX)                                                                                          \
     {                                                                                                               \
-        const int kc = (KT_IDX) * 8 + c;                                                                            \
-        const int tap = kc / cpt, cc = kc - tap * cpt;                                                              \
-        const int r_ = tap / a.S, s_ = tap - r_ * a.S;                                                              \
-        const int dy = r_ * a.dil, dx = s_ * a.dil;                                                                 \
-        const bool tap_ok = tap < ntaps;                                                                            \
+        const int2 e_ = ltab[(KT_IDX) * 8 + c];                                                                     \
+        const int dy_ = (int)(short)(e_.y & 0xffff), dx_ = e_.y >> 16;                                              \
+        bool ok_[4];                                                                                                \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \
-            const int iy = iy0[i] + dy, ix = ix0[i] + dx;                                                           \
-            const bool ok = rvalid[i] && tap_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;                      \
-            const u32x4_t* src = reinterpret_cast<const u32x4_t*>(                                                  \
-                a.in + (pbase[i] + (long long)(ok ? iy : 0) * a.W + (ok ? ix : 0)) * a.in_pix_stride + cc * 8);     \
-            const u32x4_t zero_ = {0u, 0u, 0u, 0u};                                                                 \
-            const u32x4_t val = ok ? *src : zero_;                                                                  \
-            ra[i] = val;                                                                                            \
+            ok_[i] = (unsigned)(iy0[i] + dy_) < (unsigned)a.H && (unsigned)(ix0[i] + dx_) < (unsigned)a.W;          \
+            const uint16_t* src_ = ok_[i] ? rowptr[i] + e_.x : a.in;                                                \
+            ra[i] = *reinterpret_cast<const u32x4_t*>(src_);                                                        \
         }                                                                                                           \
         _Pragma("unroll") for (int i = 0; i < B_ROWS_PER_THREAD; ++i)                                               \
             rb[i] = *reinterpret_cast<const u32x4_t*>(wrow + (size_t)(32 * i) * a.Kpad + (size_t)(KT_IDX) * BK);    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) ra[i] = ok_[i] ? ra[i] : zero4;                               \
     }
-#define OESS_LSTORE()                                                                                  \
+#define OESS_LSTORE(BUF)                                                                               \
     {                                                                                                  \
+        u32x4_t* lA_ = lbase + (BUF) * STAGE_CHUNKS;                                                   \
+        u32x4_t* lB_ = lA_ + BM * 8;                                                                   \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
             const int r_ = row0 + 32 * i;                                                              \
-            lA[r_ * 8 + swz(r_, c)] = ra[i];                                                           \
+            lA_[r_ * 8 + swz(r_, c)] = ra[i];                                                          \
         }                                                                                              \
         _Pragma("unroll") for (int i = 0; i < B_ROWS_PER_THREAD; ++i) {                                \
             const int r_ = row0 + 32 * i;                                                              \
-            lB[r_ * 8 + swz(r_, c)] = rb[i];                                                           \
+            lB_[r_ * 8 + swz(r_, c)] = rb[i];                                                          \
         }                                                                                              \
     }
 
@@ -144,11 +163,16 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+    __syncthreads();                                   // tap table visible
     OESS_GLOAD(0)
+    OESS_LSTORE(0)
+    __syncthreads();
+    if (KT > 1) OESS_GLOAD(1)
+    // double-buffered LDS: ONE barrier per K-slab.  compute(buf) -> store next slab into the other buffer ->
+    // barrier -> issue the global loads two slabs ahead (they fly under the next compute).
     for (int kt = 0; kt < KT; ++kt) {
-        OESS_LSTORE()
-        __syncthreads();
-        if (kt + 1 < KT) OESS_GLOAD(kt + 1)       // in flight while the MFMAs below run
+        const u32x4_t* lA = lbase + (kt & 1) * STAGE_CHUNKS;
+        const u32x4_t* lB = lA + BM * 8;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8_t fa[MT], fb[NT];
@@ -169,8 +193,13 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_fwd_kernel(ConvArgs a) {
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
+        if (kt + 1 < KT) {
+            OESS_LSTORE((kt + 1) & 1)
+            __syncthreads();
+            if (kt + 2 < KT) OESS_GLOAD(kt + 2)
+        }
     }
+    __syncthreads();                                   // all LDS reads done before the epilogue reuses smem
 
     // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)
     const int ncol_l = lane & 31;
@@ -323,18 +352,27 @@ int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, 
     a.relu = relu;
     a.tiles_m = (a.M + BM - 1) / BM;
     hipStream_t st = (hipStream_t)stream;
+    {   // > 64 KiB of dynamic LDS needs an explicit opt-in (once per process)
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_done = true;
+        }
+    }
     // the packed weight has Npad = multiple of 128 rows, so any BN <= 128 tiles it safely
     if (Cout > 64) {
         a.tiles_n = (Cout + 127) / 128;
-        const size_t lds = (size_t)BM * (128 + 8) * 2;            // epilogue image (34 KiB) > staging (32 KiB)
+        const size_t lds = (size_t)2 * (BM + 128) * 8 * 16 + (size_t)(a.Kpad / 8) * 8;   // 64 KiB staging + tap table
         hipLaunchKernelGGL(conv_fwd_kernel<128>, dim3(a.tiles_m * a.tiles_n), dim3(CONV_THREADS), lds, st, a);
     } else if (Cout > 32) {
         a.tiles_n = 1;
-        const size_t lds = (size_t)(BM + 64) * 8 * 16;
+        const size_t lds = (size_t)2 * (BM + 64) * 8 * 16 + (size_t)(a.Kpad / 8) * 8;
         hipLaunchKernelGGL(conv_fwd_kernel<64>, dim3(a.tiles_m * a.tiles_n), dim3(CONV_THREADS), lds, st, a);
     } else {
         a.tiles_n = 1;
-        const size_t lds = (size_t)(BM + 32) * 8 * 16;
+        const size_t lds = (size_t)2 * (BM + 32) * 8 * 16 + (size_t)(a.Kpad / 8) * 8;
         hipLaunchKernelGGL(conv_fwd_kernel<32>, dim3(a.tiles_m * a.tiles_n), dim3(CONV_THREADS), lds, st, a);
     }
     OESS_HIP(hipGetLastError());

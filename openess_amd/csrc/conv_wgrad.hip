@@ -1,0 +1,230 @@
+// Weight gradient of a 2-D convolution on gfx950 (bf16 operands, fp32 MFMA accumulate, fp32 result).
+//
+//   dW[co][ci][r][s] = sum over (b, oy, ox) of  dY[b,oy,ox,co] * X[b, oy*stride-pad+r*dil, ox*stride-pad+s*dil, ci]
+//
+// GEMM view: D[co][kk] = sum_p A[co][p] * Bm[p][kk], kk = (r, s, ci), reduction over output pixels p.
+// Both operands are stored pixel-major in HBM (NHWC), i.e. with the REDUCTION index strided, so the MFMA
+// fragments (8 consecutive k per lane) need a transpose.  It is done by the LDS transpose-read
+// ds_read_b64_tr_b16 (semantics probed on MI355X, tools/probes/tr_probe.hip: within a 16-lane group, lane
+// i supplies the address of 4 contiguous bf16 and receives element (i&3) of lanes (i>>2)+{0,4,8,12}); with
+// lane address = &T[k0 + (i>>2)][n0 + 4*(i&3)] lane i receives T[k0..k0+3][n0+i]: a 4x16 transposed block.
+// LDS tiles keep the natural [pixel][channel] order (row pitch 320 B = 64 mod 256: conflict-free tr reads).
+//
+// Workgroup: 128 (co) x 128 (kk) tile, 4 waves of 64x64, K-step = 64 output pixels of ONE output row
+// (no per-pixel div/mod), split-K over output rows, fp32 atomics into the OIHW gradient (pre-zeroed).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "oess.h"
+#include "oess_common.h"
+
+namespace {
+using namespace oess;
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+constexpr int TM = 128, TN = 128, KP = 64;
+constexpr int PITCH = 320;                 // bytes per pixel row of an LDS tile (128 ch * 2 B + 64 B skew)
+constexpr int WG = 256;
+
+struct WgradArgs {
+    const uint16_t* x;  long long xps;      // input activations NHWC bf16
+    const uint16_t* dy; long long dps;      // output gradient NHWC bf16
+    float* part;                            // split-K partials [splits][tiles_m*128][tiles_n*128] fp32 (plain stores)
+    int B, H, W, Cin, Cin_x;                // Cin = weight's input channels; Cin_x = channels present in x (>= Cin, %8 == 0)
+    int Ho, Wo, Cout;
+    int R, S, stride, pad, dil;
+    int Kdim;                               // R*S*Cin_x
+    int rows_total, rows_per_split;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ bf16x4_t tr_read(uint32_t lds_addr) {
+    bf16x4_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
+    return v;
+}
+
+__global__ __launch_bounds__(WG) void conv_wgrad_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KP * PITCH];
+    unsigned char* lA = smem;                      // dY tile  [KP pixels][128 co]
+    unsigned char* lB = smem + KP * PITCH;         // X  tile  [KP pixels][128 kk]
+    const int tile = blockIdx.x;
+    const int tile_n = tile % a.tiles_n, tile_m = tile / a.tiles_n;
+    const int co0 = tile_m * TM, kk0 = tile_n * TN;
+    const int split = blockIdx.y;
+    const int row_beg = split * a.rows_per_split;
+    int row_end = row_beg + a.rows_per_split;
+    if (row_end > a.rows_total) row_end = a.rows_total;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- global->LDS staging roles: 16 chunk columns x 16 pixel rows per pass, 4 passes
+    const int ccol = tid & 15, prow = tid >> 4;
+    // A (dY): channel chunk
+    const int a_co = co0 + ccol * 8;
+    const bool a_ok = a_co < a.Cout;               // Cout % 8 == 0 is required by the host wrapper
+    // B (X): fixed (tap, channel chunk) of this thread
+    const int kk = kk0 + ccol * 8;
+    const int cpt = a.Cin_x;                        // kk = tap * Cin_x + ci
+    const int tap = kk / cpt, ci0 = kk - tap * cpt;
+    const bool b_ok = kk < a.Kdim;
+    const int r = tap / a.S, s = tap - r * a.S;
+    const int dyo = r * a.dil - a.pad, dxo = s * a.dil - a.pad;
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // tr-read lane geometry (see header): 16-lane group g4, i0 = 16*(g4&1), k-offset = 8*(g4>>1)
+    const int g4 = lane >> 4, li = lane & 15;
+    const uint32_t ldsA = (uint32_t)(uintptr_t)lA, ldsB = (uint32_t)(uintptr_t)lB;
+    const uint32_t tr_row = (uint32_t)((g4 >> 1) * 8 + (li >> 2));
+    const uint32_t tr_col = (uint32_t)((g4 & 1) * 16 + (li & 3) * 4);
+
+    const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+    const int spr = (a.Wo + KP - 1) / KP;                    // K-steps per output row
+    const int nsteps = (row_end - row_beg) * spr;
+    u32x4_t ra[4], rb[4];
+#define OESS_WG_LOAD(STEP)                                                                                          \
+    {                                                                                                               \
+        const int row_ = row_beg + (STEP) / spr, ox0_ = ((STEP) % spr) * KP;                                        \
+        const int b_ = row_ / a.Ho, oy_ = row_ - b_ * a.Ho;                                                         \
+        const int iy_ = oy_ * a.stride + dyo;                                                                       \
+        const bool iy_ok_ = iy_ >= 0 && iy_ < a.H;                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \
+            const int ox = ox0_ + prow + 16 * i;                                                                    \
+            const bool pv = ox < a.Wo;                                                                              \
+            const long long opix = ((long long)b_ * a.Ho + oy_) * a.Wo + (pv ? ox : 0);                             \
+            const u32x4_t* pa = reinterpret_cast<const u32x4_t*>(a.dy + opix * a.dps + (a_ok ? a_co : 0));         \
+            ra[i] = (pv && a_ok) ? *pa : zero4;                                                                     \
+            const int ix = ox * a.stride + dxo;                                                                     \
+            const bool ok = pv && b_ok && iy_ok_ && ix >= 0 && ix < a.W;                                            \
+            const long long ipix = ((long long)b_ * a.H + (ok ? iy_ : 0)) * a.W + (ok ? ix : 0);                    \
+            const u32x4_t* pb = reinterpret_cast<const u32x4_t*>(a.x + ipix * a.xps + (b_ok ? ci0 : 0));           \
+            rb[i] = ok ? *pb : zero4;                                                                               \
+        }                                                                                                           \
+    }
+    if (nsteps > 0) OESS_WG_LOAD(0)
+    for (int step = 0; step < nsteps; ++step) {
+        __syncthreads();                            // previous K-step's LDS reads are done
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pr = prow + 16 * i;
+            *reinterpret_cast<u32x4_t*>(lA + pr * PITCH + ccol * 16) = ra[i];
+            *reinterpret_cast<u32x4_t*>(lB + pr * PITCH + ccol * 16) = rb[i];
+        }
+        __syncthreads();
+        if (step + 1 < nsteps) OESS_WG_LOAD(step + 1)   // next slab's HBM loads fly under the MFMAs below
+        {
+#pragma unroll
+            for (int ks = 0; ks < KP / 16; ++ks) {
+                bf16x4_t al[2], ah[2], bl[2], bh[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const uint32_t base = ldsA + (uint32_t)(ks * 16 + tr_row) * PITCH + (uint32_t)(wm * 64 + i * 32 + tr_col) * 2;
+                    al[i] = tr_read(base);
+                    ah[i] = tr_read(base + 4 * PITCH);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const uint32_t base = ldsB + (uint32_t)(ks * 16 + tr_row) * PITCH + (uint32_t)(wn * 64 + j * 32 + tr_col) * 2;
+                    bl[j] = tr_read(base);
+                    bh[j] = tr_read(base + 4 * PITCH);
+                }
+                // the "+v" operands tie every later use of the eight results to this wait (hipcc does not track
+                // inline-asm LDS reads: cdna_hip_programming.md 5.4 rule 18)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1])
+                             :: "memory");
+                bf16x8_t fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = __builtin_shufflevector(al[i], ah[i], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j] = __builtin_shufflevector(bl[j], bh[j], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+#undef OESS_WG_LOAD
+    // ---- epilogue: plain coalesced stores of the partial tile (no atomics); reduced by wgrad_reduce_kernel
+    const int ldn = a.tiles_n * TN;
+    float* P = a.part + (size_t)split * a.tiles_m * TM * ldn;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kq = kk0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                P[(size_t)co * ldn + kq] = acc[i][j][e];
+            }
+        }
+}
+
+// dW[co][ci][r][s] (+)= sum over splits of part[split][co][(r,s,ci)]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int Mpad, int ldn,
+                                                           int Cout, int Cin, int Cin_x, int RS, float* __restrict__ dw) {
+    const int total = Cout * Cin * RS;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int tp = i % RS, t2 = i / RS;
+        const int ci = t2 % Cin, co = t2 / Cin;
+        const size_t off = (size_t)co * ldn + (size_t)tp * Cin_x + ci;
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += part[(size_t)k * Mpad * ldn + off];
+        dw[i] += s;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int oess_conv2d_wgrad_bf16(const void* x, long long x_pix_stride, int B, int H, int W, int Cin_x, const void* dy,
+                           long long dy_pix_stride, int Cout, int Cin, int R, int S, int stride, int pad, int dil,
+                           float* dw_oihw, void* workspace, size_t workspace_bytes, oess_stream_t stream) {
+    if (!x || !dy || !dw_oihw || !workspace || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin_x < Cin || (Cin_x & 7) || Cout <= 0 ||
+        (Cout & 7) || R <= 0 || S <= 0 || stride <= 0 || pad < 0 || dil <= 0 || (x_pix_stride & 7) || (dy_pix_stride & 7))
+        return OESS_EINVAL;
+    WgradArgs a;
+    a.x = (const uint16_t*)x; a.xps = x_pix_stride; a.dy = (const uint16_t*)dy; a.dps = dy_pix_stride; a.part = (float*)workspace;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cin_x = Cin_x; a.Cout = Cout;
+    a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
+    a.Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1;
+    a.Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
+    if (a.Ho <= 0 || a.Wo <= 0) return OESS_EINVAL;
+    a.Kdim = R * S * Cin_x;
+    a.tiles_m = (Cout + TM - 1) / TM;
+    a.tiles_n = (a.Kdim + TN - 1) / TN;
+    a.rows_total = B * a.Ho;
+    const int tiles = a.tiles_m * a.tiles_n;
+    int splits = (1024 + tiles - 1) / tiles;                 // ~4 workgroups per CU in flight
+    const size_t per_split = (size_t)a.tiles_m * TM * a.tiles_n * TN * sizeof(float);
+    if (per_split > workspace_bytes) return OESS_ENOMEM;
+    if ((size_t)splits * per_split > workspace_bytes) splits = (int)(workspace_bytes / per_split);
+    if (splits > a.rows_total) splits = a.rows_total;
+    if (splits < 1) splits = 1;
+    a.rows_per_split = (a.rows_total + splits - 1) / splits;
+    splits = (a.rows_total + a.rows_per_split - 1) / a.rows_per_split;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, splits), dim3(WG), 0, (hipStream_t)stream, a);
+    const int total = Cout * Cin * R * S;
+    int rg = (total + 255) / 256;
+    if (rg > 4096) rg = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, splits,
+                       a.tiles_m * TM, a.tiles_n * TN, Cout, Cin, Cin_x, R * S, dw_oihw);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+}  // extern "C"

@@ -93,9 +93,9 @@ def conv2d_infer(x, pw, Cout, k, stride=1, pad=0, dil=1, relu=False, residual=No
 
 
 class _ConvTrainFn(torch.autograd.Function):
-    """Trainable conv: forward and data-gradient on the HIP MFMA kernel (dgrad = forward kernel on the
-    rotated / transposed packed weight); weight- and bias-gradient still come from ATen's
-    convolution_backward (library call) until the hand-written wgrad kernel lands."""
+    """Trainable conv, all three products on hand-written MFMA kernels: forward (conv_fwd.hip), data gradient
+    (the same kernel on the rotated / transposed packed weight; stride-2 dgrad still falls back to ATen) and
+    weight gradient (conv_wgrad.hip, LDS transpose-read operands, split-K)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, pw, k, stride, pad, dil, out_f32):
@@ -121,12 +121,14 @@ class _ConvTrainFn(torch.autograd.Function):
                 gx = torch.ops.aten.convolution_backward(gy, x, weight.to(x.dtype), None, [stride, stride], [pad, pad],
                                                          [dil, dil], False, [0, 0], 1, [True, False, False])[0]
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            xin = x[:, :weight.shape[1]] if Cin_x != weight.shape[1] else x
-            res = torch.ops.aten.convolution_backward(gy, xin, weight.to(x.dtype), [weight.shape[0]] if has_bias else None,
-                                                      [stride, stride], [pad, pad], [dil, dil], False, [0, 0], 1,
-                                                      [False, True, has_bias])
-            gw = res[1].float()
-            gb = res[2].float() if has_bias else None
+            Cout, Cin = weight.shape[0], weight.shape[1]
+            gy8 = gy if gy.shape[1] % 8 == 0 else to_cl_bf16(gy)
+            if ctx.needs_input_grad[1]:
+                gw = hip.conv2d_wgrad(nhwc(x), nhwc(gy8), gy8.shape[1], Cin, k, k, stride, pad, dil)
+                if gy8.shape[1] != Cout:
+                    gw = gw[:Cout]
+            if has_bias and ctx.needs_input_grad[2]:
+                gb = hip.channel_sum(nhwc(gy8))[:Cout]
         return gx, gw, gb, None, None, None, None, None, None
 
 

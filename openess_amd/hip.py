@@ -553,3 +553,28 @@ def bilinear_l2norm(x, scale=4, normalize=True):
     _lib.check(lib.oess_bilinear_l2norm_nhwc_bf16(_ptr(xn), ps, B, H, W, C, scale, int(normalize), _ptr(out), C, _stream()),
                "oess_bilinear_l2norm_nhwc_bf16")
     return out.permute(0, 3, 1, 2)
+
+
+def conv2d_wgrad(x, gy, Cout, Cin, R, S, stride=1, pad=0, dil=1):
+    """dW (OIHW fp32) of conv2d_nhwc from NHWC bf16 views x [B,H,W,Cin_x>=Cin] and gy [B,Ho,Wo,Cout]."""
+    lib = _lib.load()
+    _need_gpu(x, gy)
+    B, H, W, Cin_x, xps = _nhwc_geom(x)
+    _, Ho, Wo, Cg, gps = _nhwc_geom(gy)
+    if Cg != Cout:
+        raise ValueError("gy channel count != Cout")
+    dw = torch.zeros((Cout, Cin, R, S), dtype=torch.float32, device=x.device)
+    ws = _workspace(256 << 20, x.device, tag="wgrad")
+    _lib.check(lib.oess_conv2d_wgrad_bf16(_ptr(x), xps, B, H, W, Cin_x, _ptr(gy), gps, Cout, Cin, R, S, stride, pad, dil,
+                                          _ptr(dw), _ptr(ws), ws.numel(), _stream()), "oess_conv2d_wgrad_bf16")
+    return dw
+
+
+def channel_sum(x_nhwc):
+    """Per-channel sum over all pixels of an NHWC bf16 view (bias gradient) -> fp32 [C]."""
+    lib = _lib.load()
+    B, H, W, C, ps = _nhwc_geom(x_nhwc)
+    st = torch.empty((2, C), dtype=torch.float32, device=x_nhwc.device)
+    _lib.check(lib.oess_norm_stats_nhwc_bf16(_ptr(x_nhwc), ps, 1, B * H * W, C, _ptr(st[0]), _ptr(st[1]), _stream()),
+               "oess_norm_stats_nhwc_bf16")
+    return st[0]

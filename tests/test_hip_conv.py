@@ -92,3 +92,33 @@ def test_conv_dgrad_operator():
     gx = hip.conv2d_nhwc(gy_nhwc, hip.pack_conv_weight(w, flip=True), None, Cin, R, R, 1, dil * (R - 1) - pad, dil,
                          out_f32=True)
     np.testing.assert_allclose(gx.permute(0, 3, 1, 2).cpu().numpy(), x.grad.cpu().numpy(), rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, R, stride, pad, dil
+    (2, 12, 20, 16, 24, 3, 1, 1, 1),
+    (2, 9, 70, 64, 32, 3, 1, 1, 1),        # Wo > 64: two pixel chunks per row, Cout < tile
+    (1, 11, 13, 256, 256, 3, 1, 1, 1),
+    (2, 10, 12, 32, 256, 1, 1, 0, 1),      # 1x1 head
+    (2, 16, 24, 64, 64, 3, 2, 1, 1),       # stride 2
+    (1, 14, 18, 48, 136, 3, 1, 2, 2),      # dilation, ragged tiles
+    (2, 8, 130, 8, 16, 5, 1, 2, 1),
+])
+def test_conv_wgrad_matches_autograd(case):
+    from openess_amd import hip
+    B, H, W, Cin, Cout, R, stride, pad, dil = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(B, H, W, Cin, device="cuda").bfloat16()
+    w = torch.zeros(Cout, Cin, R, R, device="cuda", requires_grad=True)
+    y = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, stride, pad, dil)
+    gy = torch.randn_like(y).bfloat16()
+    y.backward(gy.float())
+    dw = hip.conv2d_wgrad(x, gy.permute(0, 2, 3, 1).contiguous(), Cout, Cin, R, R, stride, pad, dil)
+    ref = w.grad
+    err = float((dw - ref).abs().max() / ref.abs().max())
+    assert err < 2e-3, err
+    # input with zero-padded extra channels (Cin_x > Cin), as the 5->8 / 3->8 padded stems have
+    if Cin % 16 == 8:
+        xp = torch.cat([x, torch.zeros(B, H, W, 8, device="cuda", dtype=torch.bfloat16)], -1)
+        dw2 = hip.conv2d_wgrad(xp, gy.permute(0, 2, 3, 1).contiguous(), Cout, Cin, R, R, stride, pad, dil)
+        assert float((dw2 - ref).abs().max() / ref.abs().max()) < 2e-3

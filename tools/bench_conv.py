@@ -63,5 +63,33 @@ def main():
         print(f"{name:30s} {ms:8.3f} ms {fl / ms / 1e9:8.1f} TF/s   | torch/MIOpen bf16 NHWC {ms_t:8.3f} ms {fl / ms_t / 1e9:8.1f} TF/s")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--wgrad" not in sys.argv:
     main()
+
+
+def bench_wgrad():
+    shapes = [("dec 3x3 256->256 @55x80", 8, 55, 80, 256, 256, 3, 1, 1), ("dec 3x3 256->128 @110x160", 8, 110, 160, 256, 128, 3, 1, 1),
+              ("dec 3x3 128->64 @220x320", 8, 220, 320, 128, 64, 3, 1, 1), ("dec 3x3 64->32 @440x640", 8, 440, 640, 64, 32, 3, 1, 1),
+              ("head 1x1 32->256 @440x640", 8, 440, 640, 32, 256, 1, 1, 0)]
+    for name, B, H, W, Cin, Cout, R, st, pad in shapes:
+        x = torch.randn(B, H, W, Cin, device="cuda").bfloat16()
+        gy = torch.randn(B, H, W, Cout, device="cuda").bfloat16()
+        w = torch.randn(Cout, Cin, R, R, device="cuda").bfloat16()
+        fl = 2.0 * B * H * W * Cout * Cin * R * R
+        for tag, fn in (("hip", lambda: hip.conv2d_wgrad(x, gy, Cout, Cin, R, R, st, pad, 1)),
+                        ("aten", lambda: torch.ops.aten.convolution_backward(gy.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), w, None, [st, st], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False]))):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            print(f"wgrad {name:28s} {tag:5s} {ms:8.3f} ms {fl / ms / 1e9:8.1f} TF/s")
+
+
+if __name__ == "__main__" and "--wgrad" in sys.argv:
+    bench_wgrad()
