@@ -21,6 +21,8 @@
 //   - workgroup ids are remapped so that the n-tiles of one m-tile land on the same XCD (shared L2).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 #include "oess.h"
 #include "oess_common.h"
 
@@ -50,9 +52,92 @@ struct ConvArgs {
     int M;                   // B*Ho*Wo
     int relu;
     int tiles_m, tiles_n;
+    unsigned inv_cpt, inv_s;   // exact small-range reciprocals: kc / cpt == (kc * inv_cpt) >> 20, tap / S == (tap * inv_s) >> 16
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+template <int BN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)[BM / (4 / ((BN == 128) ? 2 : 1)) / 32][(BN / ((BN == 128) ? 2 : 1)) / 32],
+                                              unsigned char* smem, int m0, int n0, int wm, int wn, int lane, int tid) {
+    constexpr int WAVES_N = (BN == 128) ? 2 : 1;
+    constexpr int WAVES_M = 4 / WAVES_N;
+    constexpr int WM = BM / WAVES_M;
+    constexpr int WN = BN / WAVES_N;
+    constexpr int MT = WM / 32, NT = WN / 32;
+    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)
+    const int ncol_l = lane & 31;
+    if (a.out_f32) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + wn * WN + j * 32 + ncol_l;
+                const float bv = (a.bias && n < a.Cout) ? a.bias[n] : 0.0f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    if (m < a.M && n < a.Cout) {
+                        float v = acc[i][j][e] + bv;
+                        if (a.relu) v = fmaxf(v, 0.0f);
+                        a.out_f32[(long long)m * a.out_pix_stride + n] = v;
+                    }
+                }
+            }
+        return;
+    }
+    // bf16 path: stage the tile as [BM][BN] bf16 in LDS (row pitch BN*2 + 16 bytes against bank conflicts)
+    uint16_t* lC = reinterpret_cast<uint16_t*>(smem);
+    constexpr int PITCH = BN + 8;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int nl = wn * WN + j * 32 + ncol_l;
+            const int n = n0 + nl;
+            const float bv = (a.bias && n < a.Cout) ? a.bias[n] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ml = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                lC[ml * PITCH + nl] = f32_to_bf16(acc[i][j][e] + bv);      // activation applied after the residual
+            }
+        }
+    __syncthreads();
+    constexpr int CHUNKS_N = BN / 8;                       // 16-byte chunks per tile row
+    for (int idx = tid; idx < BM * CHUNKS_N; idx += CONV_THREADS) {
+        const int ml = idx / CHUNKS_N, cn = idx - ml * CHUNKS_N;
+        const int m = m0 + ml, n = n0 + cn * 8;
+        if (m >= a.M || n >= a.Cout) continue;
+        uint4 v = *reinterpret_cast<const uint4*>(&lC[ml * PITCH + cn * 8]);
+        uint16_t* dst = a.out + (long long)m * a.out_pix_stride + n;
+        union { uint4 q4; uint16_t h[8]; } u, rs;
+        u.q4 = v;
+        rs.q4 = make_uint4(0u, 0u, 0u, 0u);
+        const bool full = n + 8 <= a.Cout;
+        if (a.residual) {
+            if (full) rs.q4 = *reinterpret_cast<const uint4*>(a.residual + (long long)m * a.res_pix_stride + n);
+            else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (n + q < a.Cout) rs.h[q] = a.residual[(long long)m * a.res_pix_stride + n + q];
+            }
+        }
+        if (a.residual || a.relu) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float f = bf16_to_f32(u.h[q]);
+                if (a.residual) f += bf16_to_f32(rs.h[q]);
+                if (a.relu) f = fmaxf(f, 0.0f);
+                u.h[q] = f32_to_bf16(f);
+            }
+        }
+        if (full) {
+            *reinterpret_cast<uint4*>(dst) = u.q4;
+        } else {                                   // ragged channel tail (Cout % 8 != 0)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (n + q < a.Cout) dst[q] = u.h[q];
+        }
+    }
+}
 
 template <int BN>
 __global__ __launch_bounds__(CONV_THREADS) void conv_fwd_kernel(ConvArgs a) {
@@ -201,78 +286,188 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_fwd_kernel(ConvArgs a) {
     }
     __syncthreads();                                   // all LDS reads done before the epilogue reuses smem
 
-    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)
-    const int ncol_l = lane & 31;
-    if (a.out_f32) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int n = n0 + wn * WN + j * 32 + ncol_l;
-                const float bv = (a.bias && n < a.Cout) ? a.bias[n] : 0.0f;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    if (m < a.M && n < a.Cout) {
-                        float v = acc[i][j][e] + bv;
-                        if (a.relu) v = fmaxf(v, 0.0f);
-                        a.out_f32[(long long)m * a.out_pix_stride + n] = v;
-                    }
-                }
-            }
-        return;
+    conv_epilogue<BN>(a, acc, smem, m0, n0, wm, wn, lane, tid);
+}
+
+
+// =================================================================================================
+// v2: LDS-DMA pipeline.  Both operand slabs are moved HBM -> LDS by `buffer_load_dwordx4 ... lds`
+// (no staging VGPRs, no ds_write pass, fully asynchronous).  Probed on MI355X
+// (tools/probes/lds_dma_probe.hip): the destination is M0-base + lane*16 (lane-linear per wave) and an
+// out-of-range voffset WRITES ZEROS, which is exactly the zero padding an implicit GEMM needs: padded
+// taps and rows beyond M simply get voffset = 0x80000000.  The XOR swizzle is applied on the SOURCE
+// side (lane p of a wave instruction fetches the chunk that belongs at LDS slot p), reads are unchanged.
+// NSTAGE-deep LDS ring, ONE raw s_barrier per K-slab, counted vmcnt so that NSTAGE-2 slabs stay in
+// flight across the barrier (a __syncthreads would drain them: cdna_hip_programming.md section 5).
+// =================================================================================================
+template <int BN, int NSTAGE>
+__global__ __launch_bounds__(CONV_THREADS) void conv_fwd_dma_kernel(ConvArgs a) {
+    constexpr int WAVES_N = (BN == 128) ? 2 : 1;
+    constexpr int WAVES_M = 4 / WAVES_N;
+    constexpr int WM = BM / WAVES_M;
+    constexpr int WN = BN / WAVES_N;
+    constexpr int MT = WM / 32, NT = WN / 32;
+    constexpr int A_INSTR = 4;                       // 128 rows x 8 chunks = 16 wave-instructions / 4 waves
+    constexpr int B_INSTR = BN / 32;                 // BN rows x 8 chunks / 64 lanes / 4 waves
+    constexpr int IPS = A_INSTR + B_INSTR;           // DMA instructions per thread per stage
+    constexpr int STAGE_BYTES = (BM + BN) * 8 * 16;
+    constexpr int NFRAG = MT + NT;                   // ds_read_b128 per k-step
+
+    // ONE LDS array (a second __shared__ object makes hipcc drain vmcnt before every ds_read)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int nwg = a.tiles_m * a.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    // bf16 path: stage the tile as [BM][BN] bf16 in LDS (row pitch BN*2 + 16 bytes against bank conflicts)
-    uint16_t* lC = reinterpret_cast<uint16_t*>(smem);
-    constexpr int PITCH = BN + 8;
+    const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int KT = a.Kpad / BK;
+    const int cpt = a.Cin >> 3, ntaps = a.R * a.S;
+
+    // buffer descriptors (wave-uniform kernel arguments only)
+    const long long in_bytes = (((long long)a.B * a.H * a.W - 1) * a.in_pix_stride + a.Cin) * 2;
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7ffffff0, 0x00020000);
+
+    // lane geometry of one wave-level DMA instruction: 8 rows x 8 chunk slots
+    const int lrow = lane >> 3, slot = lane & 7;
+    int iy0[A_INSTR], ix0[A_INSTR], rowoff[A_INSTR], csrc[A_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int r = (wave * A_INSTR + i) * 8 + lrow;           // row of the tile this lane fetches
+        const int m = m0 + r;
+        const bool valid = m < a.M;
+        const int mm = valid ? m : 0;
+        const int hw = a.Ho * a.Wo;
+        const int b = mm / hw, rem = mm - b * hw;
+        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        iy0[i] = valid ? oy * a.stride - a.pad : -0x4000;
+        ix0[i] = ox * a.stride - a.pad;
+        rowoff[i] = (int)((((long long)b * a.H + (oy * a.stride - a.pad)) * a.W + ix0[i]) * a.in_pix_stride * 2);
+        csrc[i] = slot ^ ((r >> 1) & 7);                           // source chunk that lives at this LDS slot
+    }
+    int boff[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int r = (wave * B_INSTR + i) * 8 + lrow;
+        boff[i] = ((n0 + r) * a.Kpad + (slot ^ ((r >> 1) & 7)) * 8) * 2;
+    }
+
+    // DMA issue for K-slab kt.  Tap arithmetic uses exact reciprocals (host-verified): no LDS table reads here,
+    // because hipcc drains vmcnt(0) in front of any compiler-visible LDS read while an LDS-DMA is in flight.
+    auto issue = [&](int kt) {
+        unsigned char* st = smem + (kt % NSTAGE) * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            const unsigned kc = (unsigned)(kt * 8 + csrc[i]);
+            const unsigned tap = (kc * a.inv_cpt) >> 20;
+            const int cc = (int)(kc - tap * cpt);
+            const unsigned r = (tap * a.inv_s) >> 16;
+            const int sx = (int)(tap - r * a.S);
+            const int dy = (int)r * a.dil, dx = sx * a.dil;
+            const bool ok = (int)tap < ntaps && (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
+            const unsigned voff = ok ? (unsigned)(rowoff[i] + ((dy * a.W + dx) * (int)a.in_pix_stride + cc * 8) * 2) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave * A_INSTR + i) * 1024),
+                                                     16, voff, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(st + BM * 128 + (wave * B_INSTR + i) * 1024),
+                                                     16, (unsigned)(boff[i] + kt * BK * 2), 0, 0, 0);
+    };
+
+    f32x16_t acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int nl = wn * WN + j * 32 + ncol_l;
-            const int n = n0 + nl;
-            const float bv = (a.bias && n < a.Cout) ? a.bias[n] : 0.0f;
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int ml = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                lC[ml * PITCH + nl] = f32_to_bf16(acc[i][j][e] + bv);      // activation applied after the residual
-            }
-        }
-    __syncthreads();
-    constexpr int CHUNKS_N = BN / 8;                       // 16-byte chunks per tile row
-    for (int idx = tid; idx < BM * CHUNKS_N; idx += CONV_THREADS) {
-        const int ml = idx / CHUNKS_N, cn = idx - ml * CHUNKS_N;
-        const int m = m0 + ml, n = n0 + cn * 8;
-        if (m >= a.M || n >= a.Cout) continue;
-        uint4 v = *reinterpret_cast<const uint4*>(&lC[ml * PITCH + cn * 8]);
-        uint16_t* dst = a.out + (long long)m * a.out_pix_stride + n;
-        union { uint4 q4; uint16_t h[8]; } u, rs;
-        u.q4 = v;
-        rs.q4 = make_uint4(0u, 0u, 0u, 0u);
-        const bool full = n + 8 <= a.Cout;
-        if (a.residual) {
-            if (full) rs.q4 = *reinterpret_cast<const uint4*>(a.residual + (long long)m * a.res_pix_stride + n);
-            else {
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // fragment addresses (bytes from the stage base), fixed over the K loop: row r, chunk slot swz(r, ks*2 + half)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    uint32_t fa_off[MT], fb_off[NT];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) if (n + q < a.Cout) rs.h[q] = a.residual[(long long)m * a.res_pix_stride + n + q];
-            }
-        }
-        if (a.residual || a.relu) {
+    for (int i = 0; i < MT; ++i) fa_off[i] = (uint32_t)(wm * WM + i * 32 + (lane & 31)) * 128;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                float f = bf16_to_f32(u.h[q]);
-                if (a.residual) f += bf16_to_f32(rs.h[q]);
-                if (a.relu) f = fmaxf(f, 0.0f);
-                u.h[q] = f32_to_bf16(f);
-            }
-        }
-        if (full) {
-            *reinterpret_cast<uint4*>(dst) = u.q4;
-        } else {                                   // ragged channel tail (Cout % 8 != 0)
+    for (int j = 0; j < NT; ++j) fb_off[j] = (uint32_t)(BM * 128 + (wn * WN + j * 32 + (lane & 31)) * 128);
+    const int half = lane >> 5;
+    // slot of chunk (ks*2+half) in row r: (ks*2+half) ^ ((r>>1)&7); (r>>1)&7 == ((lane&31)>>1)&7 for every tile row here
+    const int rsw = ((lane & 31) >> 1) & 7;
+
 #pragma unroll
-            for (int q = 0; q < 8; ++q) if (n + q < a.Cout) dst[q] = u.h[q];
-        }
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < KT) issue(s);
+
+#define OESS_FRAG_READ(DST_A, DST_B, KS)                                                                         \
+    {                                                                                                            \
+        const uint32_t sl_ = (uint32_t)((((KS) * 2 + half) ^ rsw) * 16);                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                           \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(DST_A[i]) : "v"(stage_ + fa_off[i] + sl_) : "memory");   \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                           \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(DST_B[j]) : "v"(stage_ + fb_off[j] + sl_) : "memory");   \
     }
+#define OESS_FRAG_MMA(SRC_A, SRC_B)                                                                              \
+    {                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                           \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                       \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SRC_A[i], SRC_B[j], acc[i][j], 0, 0, 0);     \
+    }
+    // wait until only N_ LDS reads remain outstanding; the "+v" operands tie later uses of the fragments to the wait
+#define OESS_WAIT_FRAGS(N_, FA_, FB_)                                                                            \
+    {                                                                                                            \
+        if constexpr (MT == 2 && NT == 2)                                                                        \
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(FA_[0]), "+v"(FA_[1]), "+v"(FB_[0]), "+v"(FB_[1]) : "n"(N_) : "memory"); \
+        else if constexpr (MT == 1 && NT == 2)                                                                   \
+            asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(FA_[0]), "+v"(FB_[0]), "+v"(FB_[1]) : "n"(N_) : "memory"); \
+        else                                                                                                     \
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(FA_[0]), "+v"(FB_[0]) : "n"(N_) : "memory");             \
+    }
+
+    for (int kt = 0; kt < KT; ++kt) {
+        // retire slab kt: at most NSTAGE-2 younger slabs may stay in flight (fewer at the tail)
+        if (kt + NSTAGE - 2 < KT) {
+            if constexpr (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr ((NSTAGE - 2) * IPS == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if constexpr ((NSTAGE - 2) * IPS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr ((NSTAGE - 2) * IPS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr ((NSTAGE - 2) * IPS == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if constexpr ((NSTAGE - 2) * IPS == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if constexpr ((NSTAGE - 2) * IPS == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                   // slab kt complete for every wave; buffer of slab kt-1 is free
+        if (kt + NSTAGE - 1 < KT) issue(kt + NSTAGE - 1);
+        const uint32_t stage_ = lds0 + (uint32_t)((kt % NSTAGE) * STAGE_BYTES);
+        bf16x8_t fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+        // register double-buffered fragments: reads of k-step ks+1 are in flight under the MFMAs of k-step ks
+        OESS_FRAG_READ(fa0, fb0, 0)
+        OESS_FRAG_READ(fa1, fb1, 1)
+        OESS_WAIT_FRAGS(NFRAG, fa0, fb0)
+        OESS_FRAG_MMA(fa0, fb0)
+        OESS_FRAG_READ(fa0, fb0, 2)
+        OESS_WAIT_FRAGS(NFRAG, fa1, fb1)
+        OESS_FRAG_MMA(fa1, fb1)
+        OESS_FRAG_READ(fa1, fb1, 3)
+        OESS_WAIT_FRAGS(NFRAG, fa0, fb0)
+        OESS_FRAG_MMA(fa0, fb0)
+        OESS_WAIT_FRAGS(0, fa1, fb1)
+        OESS_FRAG_MMA(fa1, fb1)
+    }
+#undef OESS_FRAG_READ
+#undef OESS_FRAG_MMA
+#undef OESS_WAIT_FRAGS
+    __syncthreads();
+
+    conv_epilogue<BN>(a, acc, smem, m0, n0, wm, wn, lane, tid);
 }
 
 // ---- weight packing: OIHW fp32 (PyTorch Conv2d.weight) -> Wp[Npad][Kpad] bf16, k = (r, s, ci)
@@ -352,29 +547,67 @@ int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, 
     a.relu = relu;
     a.tiles_m = (a.M + BM - 1) / BM;
     hipStream_t st = (hipStream_t)stream;
-    {   // > 64 KiB of dynamic LDS needs an explicit opt-in (once per process)
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_done = true;
+    // implementation selector (A/B testing): OESS_CONV_IMPL = v1 | dma2 | dma3 | dma4 ; default below
+    static int impl = -1;
+    if (impl < 0) {
+        const char* e = getenv("OESS_CONV_IMPL");
+        impl = 2;       // measured best: 2-stage LDS-DMA ring, 2 workgroups per CU (bench_conv.py)
+        if (e) {
+            if (!strcmp(e, "v1")) impl = 0;
+            else if (!strcmp(e, "dma2")) impl = 2;
+            else if (!strcmp(e, "dma3")) impl = 3;
+            else if (!strcmp(e, "dma4")) impl = 4;
         }
+        const void* fns[] = {(const void*)&conv_fwd_kernel<128>, (const void*)&conv_fwd_kernel<64>, (const void*)&conv_fwd_kernel<32>,
+                             (const void*)&conv_fwd_dma_kernel<128, 2>, (const void*)&conv_fwd_dma_kernel<64, 2>, (const void*)&conv_fwd_dma_kernel<32, 2>,
+                             (const void*)&conv_fwd_dma_kernel<128, 3>, (const void*)&conv_fwd_dma_kernel<64, 3>, (const void*)&conv_fwd_dma_kernel<32, 3>,
+                             (const void*)&conv_fwd_dma_kernel<128, 4>, (const void*)&conv_fwd_dma_kernel<64, 4>, (const void*)&conv_fwd_dma_kernel<32, 4>};
+        for (const void* f : fns)      // > 64 KiB of dynamic LDS needs an explicit opt-in
+            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    const long long in_extent = (((long long)B * H * W - 1) * in_pix_stride + Cin) * 2;
+    int use = (in_extent >= 0x7ffffff0ll) ? 0 : impl;              // 32-bit buffer offsets in the DMA kernels
+    {   // exact reciprocals for the in-kernel tap arithmetic (checked over the whole range; else fall back)
+        const unsigned cpt = (unsigned)(Cin >> 3), nkc = (unsigned)(a.Kpad / 8);
+        a.inv_cpt = ((1u << 20) + cpt - 1) / cpt;
+        a.inv_s = ((1u << 16) + (unsigned)S - 1) / (unsigned)S;
+        bool exact = nkc < 4096;
+        for (unsigned kc = 0; exact && kc < nkc; ++kc) exact = ((kc * a.inv_cpt) >> 20) == kc / cpt;
+        const unsigned maxtap = nkc / cpt + 1;
+        for (unsigned t = 0; exact && t <= maxtap; ++t) exact = ((t * a.inv_s) >> 16) == t / (unsigned)S;
+        if (!exact) use = 0;
     }
     // the packed weight has Npad = multiple of 128 rows, so any BN <= 128 tiles it safely
-    if (Cout > 64) {
-        a.tiles_n = (Cout + 127) / 128;
-        const size_t lds = (size_t)2 * (BM + 128) * 8 * 16 + (size_t)(a.Kpad / 8) * 8;   // 64 KiB staging + tap table
-        hipLaunchKernelGGL(conv_fwd_kernel<128>, dim3(a.tiles_m * a.tiles_n), dim3(CONV_THREADS), lds, st, a);
-    } else if (Cout > 32) {
-        a.tiles_n = 1;
-        const size_t lds = (size_t)2 * (BM + 64) * 8 * 16 + (size_t)(a.Kpad / 8) * 8;
-        hipLaunchKernelGGL(conv_fwd_kernel<64>, dim3(a.tiles_m * a.tiles_n), dim3(CONV_THREADS), lds, st, a);
-    } else {
-        a.tiles_n = 1;
-        const size_t lds = (size_t)2 * (BM + 32) * 8 * 16 + (size_t)(a.Kpad / 8) * 8;
-        hipLaunchKernelGGL(conv_fwd_kernel<32>, dim3(a.tiles_m * a.tiles_n), dim3(CONV_THREADS), lds, st, a);
+    const int bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+    a.tiles_n = (Cout + bn - 1) / bn;
+    const dim3 grid(a.tiles_m * a.tiles_n), block(CONV_THREADS);
+    const size_t tab = (size_t)(a.Kpad / 8) * 8;
+    const size_t epi = (size_t)BM * (bn + 8) * 2;
+#define OESS_LAUNCH_V1(BN_)                                                                  \
+    {                                                                                        \
+        size_t lds = (size_t)2 * (BM + BN_) * 8 * 16 + tab;                                  \
+        if (lds < epi) lds = epi;                                                            \
+        hipLaunchKernelGGL(conv_fwd_kernel<BN_>, grid, block, lds, st, a);                   \
     }
+#define OESS_LAUNCH_DMA(BN_, NS_)                                                            \
+    {                                                                                        \
+        size_t lds = (size_t)NS_ * (BM + BN_) * 8 * 16;                                      \
+        if (lds < epi) lds = epi;                                                            \
+        hipLaunchKernelGGL((conv_fwd_dma_kernel<BN_, NS_>), grid, block, lds, st, a);        \
+    }
+#define OESS_DISPATCH(BN_)                                                                   \
+    switch (use) {                                                                           \
+        case 2: OESS_LAUNCH_DMA(BN_, 2) break;                                               \
+        case 3: OESS_LAUNCH_DMA(BN_, 3) break;                                               \
+        case 4: OESS_LAUNCH_DMA(BN_, 4) break;                                               \
+        default: OESS_LAUNCH_V1(BN_) break;                                                  \
+    }
+    if (bn == 128) OESS_DISPATCH(128)
+    else if (bn == 64) OESS_DISPATCH(64)
+    else OESS_DISPATCH(32)
+#undef OESS_DISPATCH
+#undef OESS_LAUNCH_DMA
+#undef OESS_LAUNCH_V1
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }
