@@ -162,7 +162,11 @@ int oess_conv2d_pack_weight(const float* w_oihw, int Cout, int Cin, int R, int S
 int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int Cin, const void* w_packed,
                          const float* bias, int Cout, int R, int S, int stride, int pad, int dil, int relu,
                          const void* residual, long long res_pix_stride, void* out_bf16, float* out_f32,
-                         long long out_pix_stride, oess_stream_t stream);
+                         long long out_pix_stride, float* tile_stats, oess_stream_t stream);
+/* tile_stats (nullable): [ceil(M/128)][2][Cout] fp32, per-128-row-tile column sums and sums of squares of the fp32
+ * result (BatchNorm batch statistics straight from the accumulators; bias-free, no activation/residual).
+ * oess_norm_reduce_tile_stats folds them into sum[C] / sumsq[C] for oess_norm_finalize. */
+int oess_norm_reduce_tile_stats(const float* tile_stats, int tiles, int C, float* sum, float* sumsq, oess_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * ConvLSTM gate fusion.  Replaces the chunk/sigmoid/tanh/mul/add tail of ConvLSTM.forward

@@ -44,6 +44,7 @@ struct ConvArgs {
     uint16_t* out;           // NHWC bf16 (or null when out_f32 is set)
     float* out_f32;          // NHWC fp32 alternative output
     const uint16_t* residual;  // optional NHWC bf16 tensor added before the activation (same pixel stride as out)
+    float* stats;              // optional [tiles_m][2][Cout] per-tile column sums / sums of squares of the fp32 result
     long long in_pix_stride, out_pix_stride, res_pix_stride;
     int B, H, W, Cin;        // input geometry; Cin % 8 == 0
     int Ho, Wo, Cout;
@@ -89,6 +90,26 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)
     // bf16 path: stage the tile as [BM][BN] bf16 in LDS (row pitch BN*2 + 16 bytes against bank conflicts)
     uint16_t* lC = reinterpret_cast<uint16_t*>(smem);
     constexpr int PITCH = BN + 8;
+    float* red = reinterpret_cast<float*>(smem + BM * PITCH * 2);          // [WAVES_M][BN][2] (BatchNorm partials)
+    if (a.stats) {
+        // per-column sum / sum of squares of the fp32 accumulators over this tile's rows (rows >= M are exact zeros:
+        // their A rows were zero filled and stats are only requested for bias-free convs)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { const float v = acc[i][j][e]; s1 += v; s2 += v * v; }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32) {
+                const int col = wn * WN + j * 32 + lane;
+                red[(wm * BN + col) * 2 + 0] = s1;
+                red[(wm * BN + col) * 2 + 1] = s2;
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -103,6 +124,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)
             }
         }
     __syncthreads();
+    if (a.stats && tid < BN) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_M; ++w) { s1 += red[(w * BN + tid) * 2]; s2 += red[(w * BN + tid) * 2 + 1]; }
+        const int n = n0 + tid;
+        if (n < a.Cout) {
+            const int tile_m = m0 / BM;
+            a.stats[((size_t)tile_m * 2 + 0) * a.Cout + n] = s1;
+            a.stats[((size_t)tile_m * 2 + 1) * a.Cout + n] = s2;
+        }
+    }
     constexpr int CHUNKS_N = BN / 8;                       // 16-byte chunks per tile row
     for (int idx = tid; idx < BM * CHUNKS_N; idx += CONV_THREADS) {
         const int ml = idx / CHUNKS_N, cn = idx - ml * CHUNKS_N;
@@ -523,7 +555,7 @@ size_t oess_conv2d_packed_bytes(int Cout, int Cin, int R, int S, int flip_for_dg
 int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int Cin, const void* w_packed,
                          const float* bias, int Cout, int R, int S, int stride, int pad, int dil, int relu,
                          const void* residual, long long res_pix_stride, void* out_bf16, float* out_f32,
-                         long long out_pix_stride, oess_stream_t stream) {
+                         long long out_pix_stride, float* tile_stats, oess_stream_t stream) {
     if (!in || !w_packed || (!out_bf16 && !out_f32) || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 7) || Cout <= 0 ||
         R <= 0 || S <= 0 || stride <= 0 || pad < 0 || dil <= 0)
         return OESS_EINVAL;
@@ -534,6 +566,8 @@ int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, 
     a.in = (const uint16_t*)in; a.w = (const uint16_t*)w_packed; a.bias = bias;
     a.out = out_f32 ? nullptr : (uint16_t*)out_bf16; a.out_f32 = out_f32;
     a.residual = (const uint16_t*)residual;
+    a.stats = tile_stats;
+    if (tile_stats && (bias || out_f32 || residual || relu)) return OESS_EINVAL;
     a.in_pix_stride = in_pix_stride; a.out_pix_stride = out_pix_stride; a.res_pix_stride = res_pix_stride;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
@@ -582,7 +616,7 @@ int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, 
     a.tiles_n = (Cout + bn - 1) / bn;
     const dim3 grid(a.tiles_m * a.tiles_n), block(CONV_THREADS);
     const size_t tab = (size_t)(a.Kpad / 8) * 8;
-    const size_t epi = (size_t)BM * (bn + 8) * 2;
+    const size_t epi = (size_t)BM * (bn + 8) * 2 + 4096;     // output image + BatchNorm partials
 #define OESS_LAUNCH_V1(BN_)                                                                  \
     {                                                                                        \
         size_t lds = (size_t)2 * (BM + BN_) * 8 * 16 + tab;                                  \

@@ -14,7 +14,7 @@
 namespace {
 using namespace oess;
 constexpr int THREADS = 256;
-constexpr int PIX_PER_WG = 1024;
+constexpr int PIX_PER_WG_MAX = 1024;
 
 union Pack8 { uint4 q; uint16_t h[8]; };
 
@@ -35,8 +35,9 @@ __global__ __launch_bounds__(THREADS) void stats_kernel(const uint16_t* __restri
     const int rows = THREADS / cl;
     const int lane_c = threadIdx.x % cl, row = threadIdx.x / cl;
     const int g = blockIdx.y;
-    const int64_t p_beg = (int64_t)blockIdx.x * PIX_PER_WG;
-    int64_t p_end = p_beg + PIX_PER_WG;
+    const int64_t ppw = (ppg + gridDim.x - 1) / gridDim.x;           // pixels per workgroup
+    const int64_t p_beg = (int64_t)blockIdx.x * ppw;
+    int64_t p_end = p_beg + ppw;
     if (p_end > ppg) p_end = ppg;
     float a1[8], a2[8];
 #pragma unroll
@@ -253,6 +254,39 @@ __global__ __launch_bounds__(THREADS) void bilinear_l2_kernel(const uint16_t* __
     }
 }
 
+// reduce the conv epilogue's per-tile partials [tiles][2][C] -> sum[C], sumsq[C]   (sum / sumsq pre-zeroed)
+// block = 32 channels x 8 tile lanes; grid.y slices the tile range; one atomic per (block, channel).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int tiles, int C,
+                                                              float* __restrict__ sum, float* __restrict__ sumsq) {
+    __shared__ float red[8][32][2];
+    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C)
+        for (int t = blockIdx.y * 8 + tl; t < tiles; t += gridDim.y * 8) {
+            s1 += part[((size_t)t * 2) * C + c];
+            s2 += part[((size_t)t * 2 + 1) * C + c];
+        }
+    red[tl][cl][0] = s1; red[tl][cl][1] = s2;
+    __syncthreads();
+    if (tl == 0 && c < C) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }
+        atomicAdd(&sum[c], s1);
+        atomicAdd(&sumsq[c], s2);
+    }
+}
+
+// chunks per group: enough workgroups to fill the chip (>= ~1024 in total), at most 1024 / at least 64 pixels each
+unsigned stats_chunks(int64_t ppg, int G) {
+    int64_t want = (1024 + G - 1) / G;
+    int64_t lo = (ppg + PIX_PER_WG_MAX - 1) / PIX_PER_WG_MAX, hi = (ppg + 63) / 64;
+    if (want < lo) want = lo;
+    if (want > hi) want = hi;
+    if (want < 1) want = 1;
+    return (unsigned)want;
+}
+
 int grid_for(int64_t work) {
     int64_t g = (work + THREADS - 1) / THREADS;
     if (g < 1) g = 1;
@@ -275,9 +309,22 @@ int oess_norm_stats_nhwc_bf16(const void* x, long long x_pix_stride, int G, long
     if (cl > THREADS) return OESS_EINVAL;
     const int rows = THREADS / cl;
     const size_t lds = (size_t)rows * C * 2 * sizeof(float);
-    dim3 grid((unsigned)((pixels_per_group + PIX_PER_WG - 1) / PIX_PER_WG), (unsigned)G);
+    dim3 grid(stats_chunks(pixels_per_group, G), (unsigned)G);
     hipLaunchKernelGGL(stats_kernel<0>, grid, dim3(THREADS), lds, st, (const uint16_t*)x, (int64_t)x_pix_stride, nullptr,
                        (int64_t)0, nullptr, nullptr, 0, (int64_t)pixels_per_group, C, sum, sumsq);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_norm_reduce_tile_stats(const float* tile_stats, int tiles, int C, float* sum, float* sumsq, oess_stream_t stream) {
+    if (!tile_stats || !sum || !sumsq || tiles <= 0 || C <= 0) return OESS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    OESS_HIP(hipMemsetAsync(sum, 0, (size_t)C * sizeof(float), st));
+    OESS_HIP(hipMemsetAsync(sumsq, 0, (size_t)C * sizeof(float), st));
+    int gy = (tiles + 63) / 64;                    // >= 8 tiles per tile lane
+    if (gy > 32) gy = 32;
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 31) / 32, gy), dim3(256), 0, st, tile_stats, tiles, C, sum, sumsq);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }
@@ -318,7 +365,7 @@ int oess_instnorm_bwd_nhwc_bf16(const void* x, long long x_pix_stride, const voi
     if (cl > THREADS) return OESS_EINVAL;
     const int rows = THREADS / cl;
     const size_t lds = (size_t)rows * C * 2 * sizeof(float);
-    dim3 grid((unsigned)((pixels_per_group + PIX_PER_WG - 1) / PIX_PER_WG), (unsigned)G);
+    dim3 grid(stats_chunks(pixels_per_group, G), (unsigned)G);
     hipLaunchKernelGGL(stats_kernel<1>, grid, dim3(THREADS), lds, st, (const uint16_t*)x, (int64_t)x_pix_stride,
                        (const uint16_t*)dy, (int64_t)dy_pix_stride, mean, rstd, relu, (int64_t)pixels_per_group, C, s1, s2);
     hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(grid_for((int64_t)G * pixels_per_group * cl)), dim3(THREADS), 0, st,

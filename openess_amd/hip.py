@@ -316,7 +316,7 @@ def pack_conv_weight(w, flip=False):
 
 
 def conv2d_nhwc(x, packed, bias, Cout, R, S, stride=1, pad=0, dil=1, relu=False, residual=None, out=None,
-                out_f32=False):
+                out_f32=False, tile_stats=None):
     """out = act(conv(x, w) + bias [+ residual]) on NHWC bf16 views (channel slices of wider buffers are fine).
     x's channel count must be a multiple of 8 (zero-padded channels; packed weights are zero there)."""
     lib = _lib.load()
@@ -341,7 +341,8 @@ def conv2d_nhwc(x, packed, bias, Cout, R, S, stride=1, pad=0, dil=1, relu=False,
     if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
         bias = bias.float().contiguous()
     _lib.check(lib.oess_conv2d_fwd_bf16(_ptr(x), ps_in, B, H, W, Cin, _ptr(packed), _ptr(bias), Cout, R, S, stride, pad,
-                                        dil, int(relu), _ptr(residual), ps_res, o_bf16, o_f32, ps_out, _stream()),
+                                        dil, int(relu), _ptr(residual), ps_res, o_bf16, o_f32, ps_out, _ptr(tile_stats),
+                                        _stream()),
                "oess_conv2d_fwd_bf16")
     return out
 
@@ -408,13 +409,13 @@ _conv2d_nhwc_raw = conv2d_nhwc
 
 
 def conv2d_nhwc(x, packed, bias, Cout, R, S, stride=1, pad=0, dil=1, relu=False, residual=None, out=None,
-                out_f32=False):
+                out_f32=False, tile_stats=None):
     t = _CONV_TIMING
     if t is None or Cout <= 64:
-        return _conv2d_nhwc_raw(x, packed, bias, Cout, R, S, stride, pad, dil, relu, residual, out, out_f32)
+        return _conv2d_nhwc_raw(x, packed, bias, Cout, R, S, stride, pad, dil, relu, residual, out, out_f32, tile_stats)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    y = _conv2d_nhwc_raw(x, packed, bias, Cout, R, S, stride, pad, dil, relu, residual, out, out_f32)
+    y = _conv2d_nhwc_raw(x, packed, bias, Cout, R, S, stride, pad, dil, relu, residual, out, out_f32, tile_stats)
     e1.record()
     t["events"].append((e0, e1))
     t["flops"] += 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * Cout * x.shape[3] * R * S
@@ -578,3 +579,31 @@ def channel_sum(x_nhwc):
     _lib.check(lib.oess_norm_stats_nhwc_bf16(_ptr(x_nhwc), ps, 1, B * H * W, C, _ptr(st[0]), _ptr(st[1]), _stream()),
                "oess_norm_stats_nhwc_bf16")
     return st[0]
+
+
+def conv_bn_train_nhwc(x, packed, Cout, R, S, stride, pad, dil, bn, relu=False, residual=None):
+    """Bias-free conv + nn.BatchNorm2d in TRAIN mode [+ residual] [+ ReLU], inference form (frozen teacher): the batch
+    statistics come from the conv epilogue's fp32 accumulators (no separate statistics pass over the activation)."""
+    lib = _lib.load()
+    B, H, W, _, _ = _nhwc_geom(x)
+    Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (S - 1) - 1) // stride + 1
+    M = B * Ho * Wo
+    tiles = (M + 127) // 128
+    part = torch.empty((tiles, 2, Cout), dtype=torch.float32, device=x.device)
+    y = conv2d_nhwc(x, packed, None, Cout, R, S, stride, pad, dil, tile_stats=part)
+    st = torch.empty((6, 1, Cout), dtype=torch.float32, device=x.device)
+    _lib.check(lib.oess_norm_reduce_tile_stats(_ptr(part), tiles, Cout, _ptr(st[0]), _ptr(st[1]), _stream()),
+               "oess_norm_reduce_tile_stats")
+    mom = 0.0 if bn.momentum is None else bn.momentum
+    _lib.check(lib.oess_norm_finalize(_ptr(st[0]), _ptr(st[1]), 1, Cout, float(M), float(bn.eps), _ptr(bn.weight.detach()),
+                                      _ptr(bn.bias.detach()), _ptr(bn.running_mean), _ptr(bn.running_var), float(mom),
+                                      _ptr(st[2]), _ptr(st[3]), _ptr(st[4]), _ptr(st[5]), _stream()), "oess_norm_finalize")
+    rps = 0
+    if residual is not None:
+        _, _, _, _, rps = _nhwc_geom(residual)
+    _lib.check(lib.oess_norm_apply_nhwc_bf16(_ptr(y), Cout, _ptr(st[4]), _ptr(st[5]), _ptr(residual), rps, int(relu), 1, M, Cout,
+                                             _ptr(y), Cout, _stream()), "oess_norm_apply_nhwc_bf16")
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return y

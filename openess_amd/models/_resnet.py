@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import engine
+from .. import engine, hip
 
 
 class HipConv2d(nn.Conv2d):
@@ -14,6 +14,7 @@ class HipConv2d(nn.Conv2d):
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
         self._pw = engine.PackedWeight()
+        self._pw_folded = engine.PackedWeight()      # eval-mode BatchNorm folded in
 
     def forward(self, x):
         if x.shape[1] % 8 or x.dtype != torch.bfloat16:
@@ -25,6 +26,30 @@ class HipConv2d(nn.Conv2d):
             return engine.conv2d_train(x, self.weight, self.bias, self._pw, k, s, p, d)
         pw = self._pw.get(self.weight, self.bias, None, cin_pad=x.shape[1])
         return engine.conv2d_infer(x, pw, self.out_channels, k, s, p, d)
+
+
+def conv_bn(conv, bn, x, relu=False, residual=None):
+    """conv -> BatchNorm2d [-> + residual] [-> ReLU] with nn.BatchNorm2d semantics for both bn.training states.
+    No autograd needed (frozen teacher, validation): train-mode BN takes its batch statistics from the conv
+    epilogue (no statistics pass); eval-mode BN is folded into the packed weights and the whole tail is the
+    conv epilogue.  With autograd: MFMA conv + library BatchNorm."""
+    needs_grad = torch.is_grad_enabled() and (conv.weight.requires_grad or x.requires_grad or bn.weight.requires_grad)
+    if needs_grad or conv.bias is not None:
+        return engine.batch_norm_act(conv(x), bn, relu=relu, residual=residual)
+    if x.shape[1] % 8 or x.dtype != torch.bfloat16:
+        x = engine.to_cl_bf16(x)
+    elif x.stride(1) != 1:
+        x = x.contiguous(memory_format=torch.channels_last)
+    if residual is not None and (residual.stride(1) != 1 or residual.dtype != torch.bfloat16):
+        residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    k, s, p, d = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0]
+    if bn.training:
+        pw = conv._pw.get(conv.weight, None, None, cin_pad=x.shape[1])
+        y = hip.conv_bn_train_nhwc(engine.nhwc(x), pw.packed, conv.out_channels, k, k, s, p, d, bn, relu=relu,
+                                   residual=None if residual is None else engine.nhwc(residual))
+        return engine.from_nhwc(y)
+    pw = conv._pw_folded.get(conv.weight, None, bn, cin_pad=x.shape[1])
+    return engine.conv2d_infer(x, pw, conv.out_channels, k, s, p, d, relu=relu, residual=residual)
 
 
 def conv3x3(in_planes, out_planes, stride=1, groups=1, dilation=1):
@@ -55,12 +80,11 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         identity = x
-        out = engine.batch_norm_act(self.conv1(x), self.bn1, relu=True)
-        out = engine.batch_norm_act(self.conv2(out), self.bn2, relu=True)
-        out = self.conv3(out)
+        out = conv_bn(self.conv1, self.bn1, x, relu=True)
+        out = conv_bn(self.conv2, self.bn2, out, relu=True)
         if self.downsample is not None:
-            identity = engine.batch_norm_act(self.downsample[0](x), self.downsample[1])
-        return engine.batch_norm_act(out, self.bn3, relu=True, residual=identity)
+            identity = conv_bn(self.downsample[0], self.downsample[1], x)
+        return conv_bn(self.conv3, self.bn3, out, relu=True, residual=identity)
 
 
 class ResNet(nn.Module):
@@ -116,7 +140,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def stem(self, x):
-        x = engine.batch_norm_act(self.conv1(x), self.bn1, relu=True)
+        x = conv_bn(self.conv1, self.bn1, x, relu=True)
         return self.maxpool(x)
 
     def features(self, x):

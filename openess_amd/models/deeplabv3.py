@@ -8,7 +8,7 @@ import torch.nn.functional as F
 
 from .. import engine
 from . import _resnet as resnet
-from ._resnet import HipConv2d
+from ._resnet import HipConv2d, conv_bn
 
 
 class IntermediateLayerGetter(nn.ModuleDict):
@@ -32,7 +32,7 @@ class IntermediateLayerGetter(nn.ModuleDict):
         x = engine.to_cl_bf16(x)
         for name, module in self.named_children():
             if name == 'conv1':
-                x = engine.batch_norm_act(module(x), self['bn1'], relu=True)
+                x = conv_bn(module, self['bn1'], x, relu=True)
                 continue
             if name in ('bn1', 'relu'):
                 continue
@@ -44,7 +44,7 @@ class IntermediateLayerGetter(nn.ModuleDict):
 
 class _ConvBNReLU(nn.Sequential):
     def forward(self, x):
-        return engine.batch_norm_act(self[0](x), self[1], relu=True)
+        return conv_bn(self[0], self[1], x, relu=True)
 
 
 class ASPPConv(_ConvBNReLU):
@@ -80,7 +80,7 @@ class ASPP(nn.Module):
 
     def forward(self, x):
         res = torch.cat([conv(x) for conv in self.convs], dim=1)
-        y = engine.batch_norm_act(self.project[0](res), self.project[1], relu=True)
+        y = conv_bn(self.project[0], self.project[1], res, relu=True)
         return self.project[3](y)
 
 
@@ -105,7 +105,7 @@ class DeepLabHead(nn.Module):
 
     def forward(self, feature):
         feature = self.ASPP(feature['out'])
-        x = engine.batch_norm_act(self.classifier[0](feature), self.classifier[1], relu=True)
+        x = conv_bn(self.classifier[0], self.classifier[1], feature, relu=True)
         logits = engine.conv2d_train(x, self.text_embeddings[:, :, None, None].float(), None, self._pw_text, 1,
                                      ver=self.text_embeddings._version)
         return logits, feature

@@ -78,6 +78,15 @@ class PretrainStep:
             if name == 'front_sensor_b':
                 m.eval()                       # unfrozen_e2vid: False in every pre-training YAML
 
+    def _teacher(self, frame):
+        """The reference always runs the teacher forward (pretrain_trainer.py:434,484), including its train-mode
+        BatchNorm side effects, even when the contrastive loss is off and its output is unused.  In that case no
+        gradient can reach the teacher's decoder, so the forward runs without autograd bookkeeping."""
+        if self.if_spatial_contrastive:
+            return self.model_frame(frame)
+        with torch.no_grad():
+            return self.model_frame(frame)
+
     def _pool(self, feat, superpixels, S):
         return hip.superpixel_pool(feat, superpixels, self.superpixel_size, S=S)
 
@@ -90,7 +99,7 @@ class PretrainStep:
         S = batch[5] if len(batch) > 5 else None
         if self.config_option == 'frame2voxel':
             event, frame, pl = batch[0], batch[2], batch[3]
-            feat_frame = self.model_frame(frame)
+            feat_frame = self._teacher(frame)
             self.reconstructor.last_states_for_each_channel = {'grayscale': None}
             for i in range(self.nr_events_data):
                 _, _, latent_real = self.reconstructor.update_reconstruction(
@@ -109,7 +118,7 @@ class PretrainStep:
                 t_loss = t_loss + loss_dense
         else:                                                                   # frame2recon (:475-529)
             frame, recon, pl = batch[0], batch[2], batch[3]
-            feat_frame = self.model_frame(frame)
+            feat_frame = self._teacher(frame)
             logits_recon, feat_recon = self.model_recon(recon)
             if self.if_spatial_contrastive:
                 k = self._pool(feat_recon, batch[4], S)
