@@ -191,6 +191,9 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    if rank == 0 and os.environ.get("OESS_CONV_BREAKDOWN") and conv_stats:
+        for k, (n, tm, fl) in sorted(conv_stats["by_shape"].items(), key=lambda kv: -kv[1][1]):
+            print(f"# conv HxWxCin->Cout k,s,d {k}: {n // a.steps:3d}/step {tm / a.steps:7.3f} ms/step {fl / tm / 1e9:7.1f} TF/s", file=sys.stderr)
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = world * B * a.steps / dt

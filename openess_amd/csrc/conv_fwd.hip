@@ -332,7 +332,9 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_fwd_kernel(ConvArgs a) {
 // NSTAGE-deep LDS ring, ONE raw s_barrier per K-slab, counted vmcnt so that NSTAGE-2 slabs stay in
 // flight across the barrier (a __syncthreads would drain them: cdna_hip_programming.md section 5).
 // =================================================================================================
-template <int BN, int NSTAGE>
+// FASTK: Cin % 64 == 0, i.e. every 64-wide K-slab lies inside ONE filter tap -> the tap decode is wave-uniform
+// (scalar) and the per-lane part of a gather address is a constant.
+template <int BN, int NSTAGE, bool FASTK>
 __global__ __launch_bounds__(CONV_THREADS) void conv_fwd_dma_kernel(ConvArgs a) {
     constexpr int WAVES_N = (BN == 128) ? 2 : 1;
     constexpr int WAVES_M = 4 / WAVES_N;
@@ -395,18 +397,37 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_fwd_dma_kernel(ConvArgs a) 
     // because hipcc drains vmcnt(0) in front of any compiler-visible LDS read while an LDS-DMA is in flight.
     auto issue = [&](int kt) {
         unsigned char* st = smem + (kt % NSTAGE) * STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) {
-            const unsigned kc = (unsigned)(kt * 8 + csrc[i]);
-            const unsigned tap = (kc * a.inv_cpt) >> 20;
-            const int cc = (int)(kc - tap * cpt);
+        if constexpr (FASTK) {
+            // scalar tap decode for the whole slab
+            const unsigned kc0 = (unsigned)(kt * 8);
+            const unsigned tap = (kc0 * a.inv_cpt) >> 20;
+            const int cc0 = (int)(kc0 - tap * cpt);
             const unsigned r = (tap * a.inv_s) >> 16;
             const int sx = (int)(tap - r * a.S);
             const int dy = (int)r * a.dil, dx = sx * a.dil;
-            const bool ok = (int)tap < ntaps && (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
-            const unsigned voff = ok ? (unsigned)(rowoff[i] + ((dy * a.W + dx) * (int)a.in_pix_stride + cc * 8) * 2) : 0x80000000u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave * A_INSTR + i) * 1024),
-                                                     16, voff, 0, 0, 0);
+            const int tapoff = ((dy * a.W + dx) * (int)a.in_pix_stride + cc0 * 8) * 2;
+            const bool tap_ok = (int)tap < ntaps;
+#pragma unroll
+            for (int i = 0; i < A_INSTR; ++i) {
+                const bool ok = tap_ok && (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
+                const unsigned voff = ok ? (unsigned)(rowoff[i] + csrc[i] * 16 + tapoff) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave * A_INSTR + i) * 1024),
+                                                         16, voff, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_INSTR; ++i) {
+                const unsigned kc = (unsigned)(kt * 8 + csrc[i]);
+                const unsigned tap = (kc * a.inv_cpt) >> 20;
+                const int cc = (int)(kc - tap * cpt);
+                const unsigned r = (tap * a.inv_s) >> 16;
+                const int sx = (int)(tap - r * a.S);
+                const int dy = (int)r * a.dil, dx = sx * a.dil;
+                const bool ok = (int)tap < ntaps && (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
+                const unsigned voff = ok ? (unsigned)(rowoff[i] + ((dy * a.W + dx) * (int)a.in_pix_stride + cc * 8) * 2) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave * A_INSTR + i) * 1024),
+                                                         16, voff, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i)
@@ -590,12 +611,11 @@ int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, 
             if (!strcmp(e, "v1")) impl = 0;
             else if (!strcmp(e, "dma2")) impl = 2;
             else if (!strcmp(e, "dma3")) impl = 3;
-            else if (!strcmp(e, "dma4")) impl = 4;
         }
         const void* fns[] = {(const void*)&conv_fwd_kernel<128>, (const void*)&conv_fwd_kernel<64>, (const void*)&conv_fwd_kernel<32>,
-                             (const void*)&conv_fwd_dma_kernel<128, 2>, (const void*)&conv_fwd_dma_kernel<64, 2>, (const void*)&conv_fwd_dma_kernel<32, 2>,
-                             (const void*)&conv_fwd_dma_kernel<128, 3>, (const void*)&conv_fwd_dma_kernel<64, 3>, (const void*)&conv_fwd_dma_kernel<32, 3>,
-                             (const void*)&conv_fwd_dma_kernel<128, 4>, (const void*)&conv_fwd_dma_kernel<64, 4>, (const void*)&conv_fwd_dma_kernel<32, 4>};
+                             (const void*)&conv_fwd_dma_kernel<128, 2, false>, (const void*)&conv_fwd_dma_kernel<64, 2, false>, (const void*)&conv_fwd_dma_kernel<32, 2, false>,
+                             (const void*)&conv_fwd_dma_kernel<128, 2, true>, (const void*)&conv_fwd_dma_kernel<64, 2, true>, (const void*)&conv_fwd_dma_kernel<32, 2, true>,
+                             (const void*)&conv_fwd_dma_kernel<128, 3, false>, (const void*)&conv_fwd_dma_kernel<64, 3, false>, (const void*)&conv_fwd_dma_kernel<32, 3, false>};
         for (const void* f : fns)      // > 64 KiB of dynamic LDS needs an explicit opt-in
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
@@ -616,6 +636,7 @@ int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, 
     a.tiles_n = (Cout + bn - 1) / bn;
     const dim3 grid(a.tiles_m * a.tiles_n), block(CONV_THREADS);
     const size_t tab = (size_t)(a.Kpad / 8) * 8;
+    const bool fastk = (Cin % 64) == 0 && !getenv("OESS_CONV_NOFASTK");
     const size_t epi = (size_t)BM * (bn + 8) * 2 + 4096;     // output image + BatchNorm partials
 #define OESS_LAUNCH_V1(BN_)                                                                  \
     {                                                                                        \
@@ -627,13 +648,13 @@ int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, 
     {                                                                                        \
         size_t lds = (size_t)NS_ * (BM + BN_) * 8 * 16;                                      \
         if (lds < epi) lds = epi;                                                            \
-        hipLaunchKernelGGL((conv_fwd_dma_kernel<BN_, NS_>), grid, block, lds, st, a);        \
+        if (fastk) hipLaunchKernelGGL((conv_fwd_dma_kernel<BN_, NS_, true>), grid, block, lds, st, a);   \
+        else hipLaunchKernelGGL((conv_fwd_dma_kernel<BN_, NS_, false>), grid, block, lds, st, a);        \
     }
 #define OESS_DISPATCH(BN_)                                                                   \
     switch (use) {                                                                           \
         case 2: OESS_LAUNCH_DMA(BN_, 2) break;                                               \
         case 3: OESS_LAUNCH_DMA(BN_, 3) break;                                               \
-        case 4: OESS_LAUNCH_DMA(BN_, 4) break;                                               \
         default: OESS_LAUNCH_V1(BN_) break;                                                  \
     }
     if (bn == 128) OESS_DISPATCH(128)

@@ -401,8 +401,13 @@ def conv_timing_end():
     if not t:
         return None
     torch.cuda.synchronize()
-    ms = sum(a.elapsed_time(b) for a, b in t["events"])
-    return {"ms": ms, "flops": t["flops"], "launches": len(t["events"])}
+    times = [a.elapsed_time(b) for a, b in t["events"]]
+    ms = sum(times)
+    by = {}
+    for (k, fl), tm in zip(t.get("keys", []), times):
+        e = by.setdefault(k, [0, 0.0, 0.0])
+        e[0] += 1; e[1] += tm; e[2] += fl
+    return {"ms": ms, "flops": t["flops"], "launches": len(t["events"]), "by_shape": by}
 
 
 _conv2d_nhwc_raw = conv2d_nhwc
@@ -417,8 +422,10 @@ def conv2d_nhwc(x, packed, bias, Cout, R, S, stride=1, pad=0, dil=1, relu=False,
     e0.record()
     y = _conv2d_nhwc_raw(x, packed, bias, Cout, R, S, stride, pad, dil, relu, residual, out, out_f32, tile_stats)
     e1.record()
+    fl = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * Cout * x.shape[3] * R * S
     t["events"].append((e0, e1))
-    t["flops"] += 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * Cout * x.shape[3] * R * S
+    t["flops"] += fl
+    t.setdefault("keys", []).append(((x.shape[1], x.shape[2], x.shape[3], Cout, R, stride, dil), fl))
     return y
 
 
