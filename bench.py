@@ -50,27 +50,6 @@ def make_inputs(rank, device, workload):
     return ev, frame, pl.to(device), sp.to(device), (B - 1) * 100 + 100
 
 
-class GradAllReduce:
-    """One bucketed all-reduce (mean) of the trainable parameters' gradients per step."""
-
-    def __init__(self, params, world):
-        self.params = [p for p in params if p.requires_grad]
-        self.world = world
-
-    def __call__(self):
-        grads = [p.grad for p in self.params if p.grad is not None]
-        if not grads or self.world == 1:
-            return
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat)
-        flat /= self.world
-        off = 0
-        for g in grads:
-            n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
-            off += n
-
-
 def cpu_baseline(sample_events, rectify_map):
     """Oracle (CPU port) timed on this host, BOUNDED: the voxelizer runs on one full sample (2M events);
     the network phases run on ONE sample at half resolution per side (220x320: 1/4 of the pixels, conv
@@ -85,7 +64,13 @@ def cpu_baseline(sample_events, rectify_map):
     torch.manual_seed(1205)
     x, y, t, p = sample_events
     t0 = time.perf_counter()
-    ev = voxelize_sample(x, y, t, p, rectify_map, NWIN, C, H_SENSOR, W_SENSOR, CROP)[None]
+    try:       # scalar C port (oracle/voxel_oracle.c) when built, else the NumPy restatement
+        from oracle import cport
+        ev = torch.from_numpy(cport.dsec_event_tensor(x, y, t, p, rectify_map, NWIN, C, H_SENSOR, W_SENSOR, CROP))[None]
+        vox_kind = "C port, 1 thread"
+    except Exception:
+        ev = voxelize_sample(x, y, t, p, rectify_map, NWIN, C, H_SENSOR, W_SENSOR, CROP)[None]
+        vox_kind = "NumPy"
     t_vox = time.perf_counter() - t0
     ev = F.avg_pool2d(ev, 2) * 4            # same sparsity class, 1/4 of the pixels
     hq, wq = ev.shape[-2:]
@@ -115,7 +100,7 @@ def cpu_baseline(sample_events, rectify_map):
     t_dec = time.perf_counter() - t1
     total = t_vox + 4.0 * (t_teacher + t_e2vid * (NWIN / nsteps) + t_dec)
     return {"value": round(1.0 / total, 5), "unit": "event-frames/s", "cores": nthr, "kind": "port",
-            "sample": f"oracle on host CPU ({ncores} cores, {nthr} torch threads): voxelizer 1 full sample {t_vox:.2f}s; "
+            "sample": f"oracle on host CPU ({ncores} cores, {nthr} torch threads): voxelizer ({vox_kind}) 1 full sample {t_vox:.2f}s; "
                       f"networks on 1 sample at 220x320 (1/4 pixels): teacher fwd {t_teacher:.2f}s, E2VID {nsteps} of "
                       f"{NWIN} recurrent steps {t_e2vid:.2f}s, SemSegE2VID fwd+bwd+AdamW {t_dec:.2f}s; scaled x4 pixels, "
                       f"x{NWIN // nsteps} steps -> {total:.1f}s per event-frame"}
@@ -143,6 +128,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from openess_amd import hip
+    from openess_amd.training.ddp import GradAllReduce, broadcast_module_states
     from openess_amd.training.pretrain_step import PretrainStep
 
     contrastive = a.workload != "frame2voxel_pixel_distill"
@@ -150,9 +136,7 @@ def main():
     step = PretrainStep(config_option=option, img_size=(H_NET, W_SENSOR), nr_events_data=NWIN, nr_temporal_bins=C,
                         if_spatial_contrastive=contrastive, superpixel_size=100, device=device)
     if world > 1:      # identical initial weights on every rank
-        for m in step.models_dict.values():
-            for t in list(m.parameters()) + list(m.buffers()):
-                dist.broadcast(t.data, 0)
+        broadcast_module_states(step.models_dict.values())
     trainable = [p for m in step.models_dict.values() for p in m.parameters()]
     reducer = GradAllReduce(trainable, world)
     ev, frame, pl, sp, S = make_inputs(rank, device, a.workload)
@@ -200,7 +184,7 @@ def main():
         roof = None
         if conv_stats and conv_stats["ms"] > 0:
             ach = conv_stats["flops"] / (conv_stats["ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "conv_fwd_kernel<128> (implicit-GEMM bf16 MFMA, fwd + dgrad launches)",
+            roof = {"bound": "mfma", "kernel": "conv_fwd_dma_kernel<128,2> (implicit-GEMM bf16 MFMA, LDS-DMA; all fwd + dgrad launches with Cout > 64)",
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                     "launches_per_step": conv_stats["launches"] // a.steps,

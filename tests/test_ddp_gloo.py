@@ -1,0 +1,72 @@
+"""N > 1 path on CPU: world_size-2 gloo processes.  Checks (iv) of SURVEY.md section 4: the gradient all-reduce
+makes a 2-rank step equal to the single-process step on the concatenated batch (for a loss that is a mean
+over samples), identical initial weights after broadcast, disjoint seeded shards, None-grad parameters skipped."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from openess_amd.training.ddp import GradAllReduce, broadcast_module_states, shard_indices
+    torch.manual_seed(100 + rank)                        # different init per rank on purpose
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(4, 2, 1))
+    unused = torch.nn.Linear(2, 2)                       # never used -> grad stays None
+    broadcast_module_states([net, unused])
+    w0 = [p.detach().clone() for p in net.parameters()]
+    torch.manual_seed(7)
+    data = torch.randn(8, 3, 6, 6)
+    target = torch.randn(8, 2, 6, 6)
+    idx = shard_indices(8, rank, world)
+    opt = torch.optim.AdamW(list(net.parameters()) + list(unused.parameters()), lr=1e-2)
+    red = GradAllReduce(list(net.parameters()) + list(unused.parameters()), world, bucket_bytes=256)
+    opt.zero_grad()
+    loss = ((net(data[idx]) - target[idx]) ** 2).mean()
+    loss.backward()
+    red()
+    opt.step()
+    out[rank] = {"w0": w0, "w1": [p.detach().clone() for p in net.parameters()], "idx": idx,
+                 "unused_grad_none": all(p.grad is None for p in unused.parameters())}
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_process_step():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    a, b = out[0], out[1]
+    for x, y in zip(a["w0"], b["w0"]):
+        assert torch.equal(x, y)                          # broadcast made the replicas identical
+    for x, y in zip(a["w1"], b["w1"]):
+        assert torch.allclose(x, y, atol=1e-7)            # and they stay identical after the step
+    assert sorted(a["idx"].tolist() + b["idx"].tolist()) == list(range(8))
+    assert a["unused_grad_none"] and b["unused_grad_none"]
+    # single-process reference on the union of the shards
+    torch.manual_seed(100)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(4, 2, 1))
+    with torch.no_grad():
+        for p, w in zip(net.parameters(), a["w0"]):
+            p.copy_(w)
+    torch.manual_seed(7)
+    data = torch.randn(8, 3, 6, 6)
+    target = torch.randn(8, 2, 6, 6)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-2)
+    loss = ((net(data) - target) ** 2).mean()
+    loss.backward()
+    opt.step()
+    for p, w in zip(net.parameters(), a["w1"]):
+        assert torch.allclose(p.detach(), w, atol=1e-6)

@@ -114,3 +114,36 @@ def test_metrics(golden_losses):
     miou, _, acc = ol.miou_acc(cm)
     assert miou == pytest.approx(float(g["met_miou"]), rel=1e-12)
     assert acc == pytest.approx(float(g["met_acc"]), rel=1e-12)
+
+
+def test_c_port_matches_reference_golden(golden_events):
+    """oracle/voxel_oracle.c (scalar C port, used as bench.py's CPU baseline) against the same golden vectors."""
+    from oracle import cport
+    g = golden_events
+    for tag in ("a", "b", "c"):
+        C, H, W = (int(v) for v in g[f"tri_{tag}_chw"])
+        out = cport.voxelgrid_trilinear(g[f"tri_{tag}_x"], g[f"tri_{tag}_y"], g[f"tri_{tag}_p"], g[f"tri_{tag}_t"], C, H, W)
+        np.testing.assert_allclose(out, g[f"tri_{tag}_out_norm0"], rtol=0, atol=2e-6)      # event-major vs 8-pass order
+        cnt = cport.voxelgrid_trilinear(g[f"tri_{tag}_x"], g[f"tri_{tag}_y"], g[f"tri_{tag}_p"], g[f"tri_{tag}_t"], C, H, W, True)
+        ref = oe.voxelgrid_trilinear(g[f"tri_{tag}_x"], g[f"tri_{tag}_y"], g[f"tri_{tag}_p"], g[f"tri_{tag}_t"], C, H, W, count_mode=True)
+        assert np.array_equal(cnt, ref)
+    C, H, W = (int(v) for v in g["tri_int_chw"])
+    assert np.array_equal(cport.voxelgrid_trilinear(g["tri_int_x"], g["tri_int_y"], g["tri_int_p"], g["tri_int_t"], C, H, W), g["tri_int_out"])
+    H, W = (int(v) for v in g["near_hw"])
+    for bins in (5, 2, 1):
+        for sp in (0, 1):
+            assert np.array_equal(cport.voxelgrid_nearest_i64(g["near_ev"], (H, W), bins, bool(sp)), g[f"near_out_b{bins}_sp{sp}"])
+    assert np.array_equal(cport.voxelgrid_nearest_i64(g["near_ev0"], (H, W), 5, False), g["near_out0_b5_sp0"])
+
+
+def test_c_port_dsec_sample_matches_numpy_oracle():
+    from oracle import cport
+    from tests import synth
+    C, H, W, crop, nwin, n_per = 5, 96, 128, 8, 3, 4000
+    x, y, t, p = synth.dsec_raw_events(nwin * n_per, H, W, seed=3)
+    rm = synth.rectify_map(H, W)
+    a = cport.dsec_event_tensor(x, y, t, p, rm, nwin, C, H, W, crop)
+    b = oe.dsec_event_tensor(x, y, t, p, rm, nwin, C, H, W, crop)
+    np.testing.assert_allclose(a, b, rtol=0, atol=2e-6)
+    assert np.array_equal(cport.dsec_event_tensor(x, y, t, p, rm, nwin, C, H, W, crop, True),
+                          oe.dsec_event_tensor(x, y, t, p, rm, nwin, C, H, W, crop, count_mode=True))
