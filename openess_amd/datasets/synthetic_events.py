@@ -1,0 +1,65 @@
+"""Synthetic provider with the reference's dataset tuple contract.
+
+`__getitem__` returns the DSEC-style 7-tuple
+    (event_or_frame, label, frame_or_recon, pl, superpixel, sam_feat, file_path)
+(DSEC/dataset/sequence_ov.py:384,409,440).  In the voxel options the first item is NOT a pre-built voxel
+tensor but a dict of the sample's RAW event columns (x,y: uint16, t: int64 us, p: uint8): the voxelizer runs
+on the GPU for the whole batch at once (trainer `prepare_batch`), which is the point of the MI355X path.
+`collate` stacks everything and builds the segment offsets."""
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from . import _synth
+
+
+class SyntheticEvents(Dataset):
+    def __init__(self, length=16, sensor_hw=(480, 640), crop_rows=40, nr_events_data=20, nr_events_window=100000,
+                 nr_bins=5, num_classes=11, config_option='frame2voxel', superpixel_size=100, mode='train', seed=1205):
+        self.length, self.sensor_hw, self.crop_rows = length, tuple(sensor_hw), crop_rows
+        self.nr_events_data, self.nr_events_window, self.nr_bins = nr_events_data, nr_events_window, nr_bins
+        self.num_classes, self.config_option, self.superpixel_size = num_classes, config_option, superpixel_size
+        self.mode, self.seed = mode, seed
+        self.require_paired_data = False
+        self.rectify_map = _synth.rectify_map(*self.sensor_hw)
+
+    def __len__(self):
+        return self.length
+
+    def getHeightAndWidth(self):
+        return self.sensor_hw[0] - self.crop_rows, self.sensor_hw[1]
+
+    def __getitem__(self, index):
+        H, W = self.sensor_hw
+        Hn = H - self.crop_rows
+        rng = np.random.default_rng(self.seed + index + (0 if self.mode == 'train' else 10**6))
+        n = self.nr_events_data * self.nr_events_window
+        x, y, t, p = _synth.dsec_raw_events(n, H, W, seed=self.seed + index)
+        events = {'x': torch.from_numpy(x), 'y': torch.from_numpy(y), 't': torch.from_numpy(t), 'p': torch.from_numpy(p)}
+        frame = torch.from_numpy(rng.uniform(0, 1, (3, Hn, W)).astype(np.float32))
+        label = rng.integers(0, self.num_classes, (Hn, W))
+        label[rng.uniform(0, 1, (Hn, W)) < 0.05] = 255
+        label = torch.from_numpy(label).long()
+        pl = label.clone()
+        g = int(round(self.superpixel_size ** 0.5))
+        yy = (np.arange(Hn) * g // Hn)[:, None]
+        xx = (np.arange(W) * g // W)[None, :]
+        superpixel = torch.from_numpy((yy * g + xx).astype(np.int64))
+        sam_feat = torch.ones(256, 64, 64)
+        first = events if self.config_option in ('frame2voxel', 'recon2voxel') else frame
+        return first, label, frame, pl, superpixel, sam_feat, f"synthetic/{self.mode}/{index:06d}"
+
+
+def collate(samples):
+    """Batch the 7-tuples; raw event dicts are concatenated and get per-sub-window segment offsets."""
+    first = [s[0] for s in samples]
+    if isinstance(first[0], dict) and 'events' in first[0]:
+        batch0 = {'events_list': [f['events'] for f in first]}
+    elif isinstance(first[0], dict):
+        ev = {k: torch.cat([f[k] for f in first]) for k in ('x', 'y', 't', 'p')}
+        ev['events_per_sample'] = torch.tensor([f['x'].numel() for f in first])
+        batch0 = ev
+    else:
+        batch0 = torch.stack(first)
+    rest = [torch.stack([s[i] for s in samples]) for i in range(1, 6)]
+    return (batch0, *rest, [s[6] for s in samples])

@@ -1,0 +1,211 @@
+"""BaseTrainer (training/base_trainer_ov.py:20-590): loader construction, epoch / validation loops, checkpoint
+hook, cosine LR.  Same overridable methods and attribute names (models_dict, optimizers_dict, lr_schedulers,
+train_loader_sensor_b, val_loader_sensor_b, epoch_count, step_count, metrics_semseg_b).
+
+MI355X-specific: `prepare_batch` takes the loader's RAW event columns and runs the batched HIP voxelizer on
+the device (the reference voxelizes per sample in CPU loader workers and ships 901 MB of voxels per batch over
+an unpinned H2D copy, base_trainer_ov.py:166-173 / pretrain_trainer.py:428-432); when torch.distributed is
+initialised the step all-reduces gradients (training/ddp.py) and the sampler shards by rank."""
+import math
+
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader, Subset
+
+from .. import hip
+from ..evaluation.metrics import MetricsSemseg
+from ..utils.saver import CheckpointSaver
+from .ddp import GradAllReduce, broadcast_module_states, shard_indices
+
+
+class BaseTrainer(object):
+    is_training = True
+
+    def __init__(self, settings):
+        self.settings = settings
+        if not torch.cuda.is_available():
+            raise RuntimeError("openess_amd trainers need the GPU (no CPU fallback in the product path)")
+        self.device = torch.device('cuda', torch.cuda.current_device())
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.do_val_training_epoch = True
+        self.metrics_semseg_b = MetricsSemseg(settings.semseg_num_classes, settings.semseg_ignore_label,
+                                              settings.semseg_class_names)
+        self.init_fn()
+        self.createDataLoaders()
+        self.models_dict = {k: v.to(self.device) for k, v in self.models_dict.items()}
+        self.saver = CheckpointSaver(save_dir=settings.ckpt_dir)
+        self.epoch_count = self.step_count = 0
+        self.checkpoint = None
+        if settings.resume_training:
+            self.checkpoint = self.saver.load_checkpoint(self.models_dict, self.optimizers_dict,
+                                                         checkpoint_file=settings.resume_ckpt_file, load_optimizer=False)
+            self.epoch_count, self.step_count = self.checkpoint['epoch'], self.checkpoint['step_count']
+        elif getattr(settings, 'load_pretrained_weights', False):
+            self.saver.load_pretrained_weights(self.models_dict, self.models_dict.keys(), settings.pretrained_file,
+                                               settings.frozen_backbone)
+            settings.logger.info('Pretrained checkpoints loaded from {}'.format(settings.pretrained_file))
+        if self.world > 1:
+            broadcast_module_states(self.models_dict.values())
+        self.grad_reducer = GradAllReduce([p for m in self.models_dict.values() for p in m.parameters()], self.world)
+        self.epoch = self.epoch_count
+        # cosine schedule with T_max = epochs * iterations but stepped once per EPOCH (base_trainer_ov.py:68-75,375-376)
+        total_steps = settings.num_epochs * len(self.train_loader_sensor_b)
+        self.lr_schedulers = {k: torch.optim.lr_scheduler.CosineAnnealingLR(v, T_max=max(total_steps, 1))
+                              for k, v in self.optimizers_dict.items()}
+
+    # ------------------------------------------------------------------ hooks for subclasses
+    def init_fn(self):
+        pass
+
+    def train_step(self, batch):
+        raise NotImplementedError
+
+    def val_step(self, batch, sensor, i_batch, vis_reconstr_idx, file_path):
+        raise NotImplementedError
+
+    def trainEpoch(self):
+        for m in self.models_dict.values():
+            m.train()
+        n = len(self.train_loader_sensor_b)
+        for i_batch, sample_batched in enumerate(self.train_loader_sensor_b):
+            out = self.train_step(self.prepare_batch(sample_batched))
+            if i_batch % 20 == 0 and self.rank == 0:
+                self.log_train(i_batch, n, out[0])
+            self.step_count += 1
+
+    def log_train(self, i_batch, n, losses):
+        msg = 'epoch: [{0}][{1}/{2}], '.format(self.epoch_count, i_batch, n) + ', '.join(
+            "{}: {:.5f}".format(k, float(v)) for k, v in losses.items())
+        print(msg)
+        self.settings.logger.info(msg)
+
+    def resetValidationStatistics(self):
+        self.metrics_semseg_b.reset()
+
+    # ------------------------------------------------------------------ data
+    def getDataloader(self, dataset_name):
+        """Dataset selector (base_trainer_ov.py:83-90)."""
+        if getattr(self.settings, 'synthetic_data', False):
+            from ..datasets.synthetic_events import SyntheticEvents
+            return SyntheticEvents
+        if dataset_name == 'DDD17_events':
+            from ..datasets.ddd17_events_loader import DDD17Events
+            return DDD17Events
+        if dataset_name == 'DSEC_events':
+            from ..datasets.DSEC_events_loader import DSECEvents
+            return DSECEvents
+        raise ValueError(dataset_name)
+
+    def createDataLoaders(self):
+        s = self.settings
+        builder = self.getDataloader(s.dataset_name_b)
+        from ..datasets.synthetic_events import SyntheticEvents, collate
+        if builder is SyntheticEvents:
+            sensor_hw = (s.img_size_b[0] + (40 if s.dataset_name_b == 'DSEC_events' else 60), s.img_size_b[1])
+            crop = sensor_hw[0] - s.img_size_b[0]
+            common = dict(sensor_hw=sensor_hw, crop_rows=crop, nr_events_data=s.nr_events_data_b,
+                          nr_events_window=s.nr_events_window_b, nr_bins=s.nr_temporal_bins_b,
+                          num_classes=s.semseg_num_classes, config_option=s.config_option,
+                          superpixel_size=getattr(s, 'superpixel_size', 100))
+            n_train = getattr(s, 'synthetic_length', 2 * s.batch_size_b * self.world)
+            train_ds = builder(length=n_train, mode='train', **common)
+            val_ds = builder(length=max(s.batch_size_b, 2), mode='val', **common)
+        else:
+            train_ds, val_ds = builder.build_from_settings(s)
+        self.sensor_geometry = (train_ds.sensor_hw, train_ds.crop_rows) if hasattr(train_ds, 'sensor_hw') else None
+        self.rectify_maps = torch.from_numpy(train_ds.rectify_map[None]).to(self.device) if hasattr(train_ds, 'rectify_map') else None
+        if self.world > 1:
+            train_ds = Subset(train_ds, shard_indices(len(train_ds), self.rank, self.world).tolist())
+        self.train_loader_sensor_b = DataLoader(train_ds, batch_size=s.batch_size_b, num_workers=s.num_cpu_workers,
+                                                pin_memory=True, shuffle=True, drop_last=True, collate_fn=collate)
+        self.val_loader_sensor_b = DataLoader(val_ds, batch_size=s.batch_size_b, num_workers=s.num_cpu_workers,
+                                              pin_memory=True, shuffle=False, drop_last=False, collate_fn=collate)
+
+    def prepare_batch(self, sample_batched):
+        """Host batch -> device batch.  A raw-event dict becomes the B x (nr_events_data*C) x H x W voxel tensor
+        via ONE batched launch sequence of the HIP voxelizer (rectification, time normalisation, crop fused)."""
+        s = self.settings
+        first = sample_batched[0]
+        rest = [t.to(self.device, non_blocking=True) if torch.is_tensor(t) else t for t in sample_batched[1:]]
+        if isinstance(first, dict) and 'events_list' in first:            # DDD17: int64 [N,4] rows per sample
+            first = self.train_loader_sensor_b.dataset.voxelize_batch(first['events_list'], self.device)
+        elif isinstance(first, dict):
+            (H, W), crop = self.sensor_geometry
+            C, nwin = s.nr_temporal_bins_b, s.nr_events_data_b
+            counts = first['events_per_sample'].tolist()
+            if any(n % nwin for n in counts):
+                # the reference drops the remainder: nr_events_temp = nr_events_loaded // nr_events_data (sequence_ov.py:302)
+                keep, base = [], 0
+                for n in counts:
+                    keep.append(torch.arange(base, base + (n // nwin) * nwin))
+                    base += n
+                keep = torch.cat(keep)
+                first = {k: (v[keep] if k != 'events_per_sample' else v) for k, v in first.items()}
+            offs = [0]
+            for n in counts:
+                per, base = n // nwin, offs[-1]
+                offs.extend([base + per * (i + 1) for i in range(nwin)])
+            seg = torch.tensor(offs, dtype=torch.int64)
+            B = len(counts)
+            dev = {k: first[k].to(self.device, non_blocking=True) for k in ('x', 'y', 't', 'p')}
+            seg_map = torch.zeros(B * nwin, dtype=torch.int32, device=self.device)
+            vox = hip.voxelize_dsec_raw(dev['x'], dev['y'], dev['t'], dev['p'], self.rectify_maps, seg_map, seg, C, H, W,
+                                        crop_rows=crop)
+            first = vox.view(B, nwin * C, H - crop, W)
+        else:
+            first = first.to(self.device, non_blocking=True)
+        sp = rest[3] if len(rest) > 3 and torch.is_tensor(rest[3]) else None
+        S = None
+        if sp is not None and getattr(s, 'if_spatial_contrastive', False):
+            sps = getattr(s, 'superpixel_size', 100)          # host-side row count: no device sync in the step
+            S = int((sample_batched[4] + torch.arange(sample_batched[4].shape[0])[:, None, None] * sps).max()) + 1
+        return (first, *rest, S)
+
+    # ------------------------------------------------------------------ loops (base_trainer_ov.py:358-448)
+    def _epoch_loop(self, validate, single_ckpt):
+        s = self.settings
+        for _ in range(self.epoch_count, s.num_epochs):
+            self.trainEpoch()
+            if (self.epoch_count % s.val_epoch_step) == 0:
+                if validate:
+                    self.valEpochs()
+                if s.save_checkpoint and self.rank == 0:
+                    save = self.saver.save_checkpoint_model_single if single_ckpt else self.saver.save_checkpoint_model
+                    save(self.models_dict, self.epoch_count, self.step_count)
+            for opt in self.optimizers_dict:
+                self.lr_schedulers[opt].step()
+            self.epoch_count += 1
+
+    def training(self):
+        self._epoch_loop(validate=True, single_ckpt=True)
+
+    def pretraining(self):
+        self._epoch_loop(validate=False, single_ckpt=False)
+
+    def valEpochs(self):
+        self.resetValidationStatistics()
+        with torch.no_grad():
+            for m in self.models_dict.values():
+                m.eval()
+            summary = self.valEpoch(self.val_loader_sensor_b, 'sensor_b')
+            self.resetValidationStatistics()
+        return summary
+
+    def valEpoch(self, data_loader, sensor_name):
+        cumulative = {}
+        for i_batch, sample_batched in enumerate(data_loader):
+            batch = self.prepare_batch(sample_batched)
+            out = self.val_step(batch[:-4], sensor_name, i_batch, -1, sample_batched[-1])
+            for k, v in out[0].items():
+                cumulative[k] = cumulative.get(k, 0) + v
+        if self.world > 1 and self.metrics_semseg_b.metrics_acc is not None:      # 968-byte confusion-matrix sum
+            dist.all_reduce(self.metrics_semseg_b.metrics_acc)
+        metrics = self.metrics_semseg_b.get_metrics_summary()
+        self.settings.logger.info('')
+        for k, v in metrics.items():
+            if k != 'cm':
+                self.settings.logger.info(" '{}': '{:.2f}'%.".format(k, v.item()))
+        self.settings.logger.info('')
+        self.last_val_metrics = metrics
+        return metrics

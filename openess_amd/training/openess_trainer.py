@@ -1,0 +1,81 @@
+"""OpenESSModel (training/openess_trainer.py:78-656), the default branch of train.py: two DeepLabv3 students
+(frame + reconstruction) trained jointly with T2E pseudo-label losses, an L1 feature-consistency loss, a cosine
+logit-consistency loss and the superpixel InfoNCE loss.
+
+Only the `frame2recon` option with `if_spatial_contrastive: True` is runnable in the reference
+(openess_trainer.py:478-529): `recon2voxel` references an undefined `superpixels` (:379 vs :408-409) and
+`frame2voxel` computes an unused contrastive value while trainEpoch reads a key that was never written
+(:464-475, :307-308).  Those two branches raise NotImplementedError here instead of being silently "fixed".
+The MaskCLIP tower the reference constructs (:107-114) is never called by any step and is not built
+(SURVEY.md 8f row 1)."""
+import torch
+import torch.nn.functional as f
+
+from .. import hip
+from ..models.deeplabv3 import deeplabv3_resnet50
+from ..utils.loss_functions import NCELoss, TaskLoss
+from .base_trainer_ov import BaseTrainer
+
+
+class OpenESSModel(BaseTrainer):
+    def init_fn(self):
+        s = self.settings
+        if s.config_option != 'frame2recon':
+            raise NotImplementedError("OpenESSModel: only config_option 'frame2recon' is runnable in the reference "
+                                      "(openess_trainer.py:360-535); see the module docstring")
+        mk = lambda: deeplabv3_resnet50(num_classes=s.semseg_num_classes, text_embeddings_path='',
+                                        output_stride=s.output_stride, pretrained_backbone=s.pretrained_backbone)
+        self.model_recon, self.model_frame = mk(), mk()
+        self.models_dict = {'model_recon': self.model_recon, 'model_frame': self.model_frame}
+        for m in self.models_dict.values():
+            m.to(self.device)
+        self.task_loss = TaskLoss(losses=list(s.task_loss), gamma=2.0, num_classes=s.semseg_num_classes, ignore_index=255)
+        self.nce_loss = NCELoss(temperature=0.07)
+        self.l1_loss = torch.nn.L1Loss()
+        self.optimizers_dict = {
+            'optimizer_recon': torch.optim.AdamW([p for p in self.model_recon.parameters() if p.requires_grad], lr=s.lr_recon),
+            'optimizer_frame': torch.optim.AdamW([p for p in self.model_frame.parameters() if p.requires_grad], lr=s.lr_frame)}
+
+    def task_train_step(self, batch):
+        s = self.settings
+        losses, t_loss = {}, 0.
+        for m in self.models_dict.values():
+            m.train()
+        frame, recon, pl, superpixels = batch[0], batch[2], batch[3], batch[4]
+        logits_frame, feat_frame = self.model_frame(frame)
+        l = self.task_loss(logits_frame, pl) * s.weight_task_loss
+        losses['semseg_frame_loss'] = l.detach()
+        t_loss = t_loss + l
+        logits_recon, feat_recon = self.model_recon(recon)
+        l = self.task_loss(logits_recon, pl) * s.weight_task_loss
+        losses['semseg_recon_loss'] = l.detach()
+        t_loss = t_loss + l
+        l = self.l1_loss(feat_frame.float(), feat_recon.float())
+        losses['cons_feat_loss'] = l.detach()
+        t_loss = t_loss + l
+        l = torch.mean(1 - f.cosine_similarity(logits_frame, logits_recon, dim=1))
+        losses['cons_pred_loss'] = l.detach()
+        t_loss = t_loss + l
+        if getattr(s, 'if_spatial_contrastive', False):
+            k = hip.superpixel_pool(feat_recon, superpixels, 30)          # superpixel_size hard-coded to 30 (:506)
+            q = hip.superpixel_pool(feat_frame, superpixels, 30)
+            l = self.nce_loss(k, q)
+            losses['contrastive_nce_loss'] = l.detach()
+            t_loss = t_loss + l
+        return t_loss, losses, {}
+
+    def train_step(self, batch):
+        for opt in self.optimizers_dict.values():
+            opt.zero_grad()
+        t_loss, losses, outputs = self.task_train_step(batch)
+        t_loss.backward()
+        self.grad_reducer()
+        for opt in self.optimizers_dict.values():
+            opt.step()
+        return losses, outputs, t_loss.detach()
+
+    def val_step(self, batch, sensor, i_batch, vis_reconstr_idx, file_path):
+        pred, _ = self.models_dict['model_recon'](batch[2])
+        losses = {'semseg_' + sensor + '_loss': self.task_loss(pred, batch[1]).detach()}
+        self.metrics_semseg_b.update_batch(pred.argmax(dim=1), batch[1])
+        return losses, None

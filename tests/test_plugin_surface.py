@@ -1,0 +1,129 @@
+"""Plugin surface: Settings attribute names, every reference YAML loads (when the reference tree is
+present), trainer dispatch order, checkpoint format, DDD17 on-disk reader."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CFG = os.path.join(HERE, "configs")
+REF_CFG = "/root/reference/config"
+
+
+def test_settings_attributes():
+    from openess_amd.config.settings import Settings
+    s = Settings(os.path.join(CFG, "pretrain_dsec_synthetic.yaml"), generate_log=False)
+    assert s.dataset_name_b == 'DSEC_events' and s.sensor_b_name == 'events'
+    assert s.input_channels_b == 5 and s.nr_events_data_b == 3 and s.img_size_b == [64, 96]
+    assert s.semseg_num_classes == 11 and s.semseg_ignore_label == 255 and len(s.semseg_class_names) == 11
+    assert s.semseg_color_map.shape == (11, 3) and tuple(s.semseg_color_map[10]) == (255, 0, 0)
+    assert s.config_option == 'frame2voxel' and s.if_pretraining and s.if_spatial_contrastive and s.superpixel_size == 25
+    assert s.batch_size_b == 2 and s.lr_voxel == 5e-4 and s.task_loss == ['dice', 'cross_entropy']
+    assert s.if_linear_probing is False and s.use_amp is False and s.frozen_backbone is False
+    assert s.e2vid_config.no_normalize is False and s.e2vid_config.no_recurrent is False
+    assert s.synthetic_data
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason="reference tree not present (GPU box)")
+def test_every_reference_yaml_loads_and_dispatches(monkeypatch):
+    """(v) of SURVEY.md section 4: YAML round trip of every file under the reference's config/."""
+    from openess_amd.config.settings import Settings
+    monkeypatch.setenv("OPENESS_ALLOW_MISSING_DATA", "1")
+    files = sorted(glob.glob(os.path.join(REF_CFG, "**", "*.yaml"), recursive=True))
+    assert len(files) >= 30
+    kinds = set()
+    for fpath in files:
+        s = Settings(fpath, generate_log=False)
+        assert s.config_option in ('recon2voxel', 'frame2voxel', 'frame2recon')
+        kind = ('sup' if s.if_supervised_only else 'pre' if getattr(s, 'if_pretraining', False)
+                else 'ft' if getattr(s, 'if_finetuning', False) else 'lp' if s.if_linear_probing else 'openess')
+        kinds.add(kind)
+        if '/linear_probe/' in fpath:
+            # quirk reproduced: top-level if_linear_probing is ignored -> these files dispatch to OpenESSModel
+            assert kind in ('openess', 'ft', 'pre', 'sup')
+    assert {'pre', 'ft'} <= kinds
+
+
+def test_checkpoint_format_roundtrip(tmp_path):
+    from openess_amd.utils.saver import CheckpointSaver
+    models = {'back_end': torch.nn.Linear(3, 2), 'model_frame': torch.nn.Linear(2, 2), 'model_recon': torch.nn.Linear(4, 1)}
+    sv = CheckpointSaver(str(tmp_path))
+    path = sv.save_checkpoint_model(models, 3, 17)
+    assert os.path.basename(path) == 'Epoch_3.pt'
+    ck = torch.load(path)
+    assert set(ck) == {'back_end', 'model_recon', 'epoch', 'step_count'}        # model_frame is not saved (saver.py:31-42)
+    tgt = {'back_end': torch.nn.Linear(3, 2), 'model_recon': torch.nn.Linear(5, 1)}      # shape mismatch is filtered
+    before = tgt['model_recon'].weight.clone()
+    sv.load_pretrained_weights(tgt, tgt.keys(), path)
+    assert torch.equal(tgt['back_end'].weight, models['back_end'].weight)
+    assert torch.equal(tgt['model_recon'].weight, before)
+    assert os.path.basename(sv.save_checkpoint_model_single(models, 0, 0)) == 'ckp.pt'
+
+
+def _fake_ddd17(root, n_events=9000, n_frames=3):
+    from PIL import Image
+    d = os.path.join(root, "dir0")
+    os.makedirs(os.path.join(d, "index"))
+    os.makedirs(os.path.join(d, "segmentation_masks"))
+    rng = np.random.default_rng(0)
+    t = np.sort(rng.integers(0, 10**6, n_events)).astype(np.int64).reshape(-1, 1)
+    xyp = np.stack([rng.integers(0, 346, n_events), rng.integers(0, 260, n_events), rng.integers(0, 2, n_events)], -1).astype(np.int16)
+    t.tofile(os.path.join(d, "events.dat.t"))
+    xyp.tofile(os.path.join(d, "events.dat.xyp"))
+    idx = np.array([[0, (i + 1) * n_events // n_frames, 0] for i in range(n_frames)], dtype=np.int64)
+    np.save(os.path.join(d, "index", "index_50ms.npy"), idx)
+    for i in range(n_frames):
+        Image.fromarray(rng.integers(0, 6, (260, 346)).astype(np.uint8)).save(os.path.join(d, "segmentation_masks", f"segmentation_{i + 1:08d}.png"))
+    return d, t, xyp, idx
+
+
+def test_ddd17_memmap_reader(tmp_path):
+    from openess_amd.datasets.ddd17_events_loader import DDD17Events
+    d, t, xyp, idx = _fake_ddd17(str(tmp_path))
+    ds = DDD17Events(str(tmp_path), nr_events_data=4, nr_events_per_data=500, nr_bins_per_data=5)
+    assert len(ds) == 3
+    item = ds[1]
+    ev = item[0]['events'].numpy()
+    hi = idx[1, 1]
+    lo = max(hi - 4 * 500, 0)
+    assert ev.shape == (hi - lo, 4) and ev.dtype == np.int64
+    assert np.array_equal(ev[:, 2], t[lo:hi, 0]) and np.array_equal(ev[:, [0, 1, 3]], xyp[lo:hi].astype(np.int64))
+    assert item[1].shape == (200, 352) and item[1].dtype == torch.int64
+
+
+@pytest.mark.gpu
+def test_ddd17_batch_voxelization_matches_oracle(tmp_path):
+    import torch.nn.functional as f
+    from openess_amd.datasets.ddd17_events_loader import DDD17Events
+    from oracle import events as oe
+    _fake_ddd17(str(tmp_path))
+    ds = DDD17Events(str(tmp_path), nr_events_data=4, nr_events_per_data=500, nr_bins_per_data=5)
+    evs = [ds[i][0]['events'] for i in (1, 2)]
+    vox = ds.voxelize_batch(evs, torch.device("cuda"))
+    assert vox.shape == (2, 20, 200, 352)
+    for b, ev in enumerate(evs):
+        ref = oe.ddd17_event_tensor(ev.numpy(), 4, (260, 346), 5, False)           # 20 x 260 x 346
+        ref = f.interpolate(torch.from_numpy(ref).view(4, 5, 260, 346), size=(260, 352), mode='bilinear', align_corners=True)
+        ref = ref.reshape(20, 260, 352)[:, :-60]
+        np.testing.assert_allclose(vox[b].cpu().numpy(), ref.numpy(), rtol=0, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,loop", [("pretrain_dsec_synthetic.yaml", "pretraining"), ("finetune_dsec_synthetic.yaml", "training")])
+def test_train_py_dispatch_and_one_epoch(cfg, loop, tmp_path, monkeypatch):
+    """train.py's dispatch + one synthetic epoch end to end (voxelizer -> step -> checkpoint in the reference format)."""
+    import train
+    from openess_amd.config.settings import Settings
+    train.seed_everything()
+    s = Settings(os.path.join(CFG, cfg), generate_log=False)
+    s.ckpt_dir = str(tmp_path)
+    trainer, which = train.build_trainer(s)
+    assert which == loop
+    getattr(trainer, which)()
+    assert trainer.epoch_count == 1 and trainer.step_count == len(trainer.train_loader_sensor_b)
+    saved = os.listdir(str(tmp_path))
+    assert saved == (['Epoch_0.pt'] if loop == 'pretraining' else ['ckp.pt'])
+    if loop == 'training':
+        assert 0.0 <= float(trainer.last_val_metrics['miou']) <= 100.0
