@@ -53,7 +53,6 @@ struct ConvArgs {
     int M;                   // B*Ho*Wo
     int relu;
     int tiles_m, tiles_n;
-    int dbg;                   // ablation switches (OESS_CONV_DBG): 1 = no DMA issue, 2 = no MFMA
     unsigned inv_cpt, inv_s;   // exact small-range reciprocals: kc / cpt == (kc * inv_cpt) >> 20, tap / S == (tap * inv_s) >> 16
 };
 
@@ -471,8 +470,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_fwd_dma_kernel(ConvArgs a) 
     {                                                                                                            \
         _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                           \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                       \
-                if (!(a.dbg & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SRC_A[i], SRC_B[j], acc[i][j], 0, 0, 0); \
-                else asm volatile("" :: "v"(SRC_A[i]), "v"(SRC_B[j]));                                           \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SRC_A[i], SRC_B[j], acc[i][j], 0, 0, 0);     \
     }
     // wait until only N_ LDS reads remain outstanding; the "+v" operands tie later uses of the fragments to the wait
 #define OESS_WAIT_FRAGS(N_, FA_, FB_)                                                                            \
@@ -500,7 +498,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_fwd_dma_kernel(ConvArgs a) 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();                   // slab kt complete for every wave; buffer of slab kt-1 is free
-        if (kt + NSTAGE - 1 < KT && !(a.dbg & 1)) issue(kt + NSTAGE - 1);
+        if (kt + NSTAGE - 1 < KT) issue(kt + NSTAGE - 1);
         const uint32_t stage_ = lds0 + (uint32_t)((kt % NSTAGE) * STAGE_BYTES);
         bf16x8_t fa0[MT], fb0[NT], fa1[MT], fb1[NT];
         // register double-buffered fragments: reads of k-step ks+1 are in flight under the MFMAs of k-step ks
@@ -602,7 +600,6 @@ int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, 
     if (M > 0x7fffffffll) return OESS_EINVAL;
     a.M = (int)M;
     a.relu = relu;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("OESS_CONV_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     a.tiles_m = (a.M + BM - 1) / BM;
     hipStream_t st = (hipStream_t)stream;
     // implementation selector (A/B testing): OESS_CONV_IMPL = v1 | dma2 | dma3 | dma4 ; default below
