@@ -58,12 +58,14 @@ struct ConvArgs {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-template <int BN>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)[BM / (4 / ((BN == 128) ? 2 : 1)) / 32][(BN / ((BN == 128) ? 2 : 1)) / 32],
+template <int BMX, int BN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
+                                              f32x16_t (&acc)[BMX / ((BMX * 2 / 64) / ((BN == 128) ? 2 : 1)) / 32][(BN / ((BN == 128) ? 2 : 1)) / 32],
                                               unsigned char* smem, int m0, int n0, int wm, int wn, int lane, int tid) {
+    constexpr int NTHREADS = BMX * 2;
     constexpr int WAVES_N = (BN == 128) ? 2 : 1;
-    constexpr int WAVES_M = 4 / WAVES_N;
-    constexpr int WM = BM / WAVES_M;
+    constexpr int WAVES_M = (NTHREADS / 64) / WAVES_N;
+    constexpr int WM = BMX / WAVES_M;
     constexpr int WN = BN / WAVES_N;
     constexpr int MT = WM / 32, NT = WN / 32;
     // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5)
@@ -90,7 +92,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)
     // bf16 path: stage the tile as [BM][BN] bf16 in LDS (row pitch BN*2 + 16 bytes against bank conflicts)
     uint16_t* lC = reinterpret_cast<uint16_t*>(smem);
     constexpr int PITCH = BN + 8;
-    float* red = reinterpret_cast<float*>(smem + BM * PITCH * 2);          // [WAVES_M][BN][2] (BatchNorm partials)
+    float* red = reinterpret_cast<float*>(smem + BMX * PITCH * 2);          // [WAVES_M][BN][2] (BatchNorm partials)
     if (a.stats) {
         // per-column sum / sum of squares of the fp32 accumulators over this tile's rows (rows >= M are exact zeros:
         // their A rows were zero filled and stats are only requested for bias-free convs)
@@ -130,13 +132,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)
         for (int w = 0; w < WAVES_M; ++w) { s1 += red[(w * BN + tid) * 2]; s2 += red[(w * BN + tid) * 2 + 1]; }
         const int n = n0 + tid;
         if (n < a.Cout) {
-            const int tile_m = m0 / BM;
-            a.stats[((size_t)tile_m * 2 + 0) * a.Cout + n] = s1;
-            a.stats[((size_t)tile_m * 2 + 1) * a.Cout + n] = s2;
+            // tile_stats rows are per 128 output rows; a 256-row tile fills row 2t and zeroes row 2t+1
+            const int trow = (m0 / BMX) * (BMX / 128);
+            a.stats[((size_t)trow * 2 + 0) * a.Cout + n] = s1;
+            a.stats[((size_t)trow * 2 + 1) * a.Cout + n] = s2;
+            if (BMX == 256 && m0 + 128 < a.M) {
+                a.stats[((size_t)(trow + 1) * 2 + 0) * a.Cout + n] = 0.f;
+                a.stats[((size_t)(trow + 1) * 2 + 1) * a.Cout + n] = 0.f;
+            }
         }
     }
     constexpr int CHUNKS_N = BN / 8;                       // 16-byte chunks per tile row
-    for (int idx = tid; idx < BM * CHUNKS_N; idx += CONV_THREADS) {
+    for (int idx = tid; idx < BMX * CHUNKS_N; idx += NTHREADS) {
         const int ml = idx / CHUNKS_N, cn = idx - ml * CHUNKS_N;
         const int m = m0 + ml, n = n0 + cn * 8;
         if (m >= a.M || n >= a.Cout) continue;
@@ -163,7 +170,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16_t (&acc)
             }
         }
         if (full) {
-            *reinterpret_cast<uint4*>(dst) = u.q4;
+            *reinterpret_cast<uint4*>(dst) = u.q4;      // (nontemporal stores measured 5-8 % slower here)
         } else {                                   // ragged channel tail (Cout % 8 != 0)
 #pragma unroll
             for (int q = 0; q < 8; ++q) if (n + q < a.Cout) dst[q] = u.h[q];
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_fwd_kernel(ConvArgs a) {
     }
     __syncthreads();                                   // all LDS reads done before the epilogue reuses smem
 
-    conv_epilogue<BN>(a, acc, smem, m0, n0, wm, wn, lane, tid);
+    conv_epilogue<BM, BN>(a, acc, smem, m0, n0, wm, wn, lane, tid);
 }
 
 
@@ -334,17 +341,19 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_fwd_kernel(ConvArgs a) {
 // =================================================================================================
 // FASTK: Cin % 64 == 0, i.e. every 64-wide K-slab lies inside ONE filter tap -> the tap decode is wave-uniform
 // (scalar) and the per-lane part of a gather address is a constant.
-template <int BN, int NSTAGE, bool FASTK>
-__global__ __launch_bounds__(CONV_THREADS) void conv_fwd_dma_kernel(ConvArgs a) {
+template <int BMX, int BN, int NSTAGE, bool FASTK>
+__global__ __launch_bounds__(BMX * 2) void conv_fwd_dma_kernel(ConvArgs a) {
+    constexpr int NTHREADS = BMX * 2;                // 128-row tile: 4 waves, 256-row tile: 8 waves
+    constexpr int NWAVES = NTHREADS / 64;
     constexpr int WAVES_N = (BN == 128) ? 2 : 1;
-    constexpr int WAVES_M = 4 / WAVES_N;
-    constexpr int WM = BM / WAVES_M;
+    constexpr int WAVES_M = NWAVES / WAVES_N;
+    constexpr int WM = BMX / WAVES_M;
     constexpr int WN = BN / WAVES_N;
     constexpr int MT = WM / 32, NT = WN / 32;
-    constexpr int A_INSTR = 4;                       // 128 rows x 8 chunks = 16 wave-instructions / 4 waves
-    constexpr int B_INSTR = BN / 32;                 // BN rows x 8 chunks / 64 lanes / 4 waves
+    constexpr int A_INSTR = BMX * 8 / 64 / NWAVES;   // = 4: BMX rows x 8 chunks / 64 lanes / waves
+    constexpr int B_INSTR = BN * 8 / 64 / NWAVES;    // BN rows x 8 chunks / 64 lanes / waves
     constexpr int IPS = A_INSTR + B_INSTR;           // DMA instructions per thread per stage
-    constexpr int STAGE_BYTES = (BM + BN) * 8 * 16;
+    constexpr int STAGE_BYTES = (BMX + BN) * 8 * 16;
     constexpr int NFRAG = MT + NT;                   // ds_read_b128 per k-step
 
     // ONE LDS array (a second __shared__ object makes hipcc drain vmcnt before every ds_read)
@@ -357,7 +366,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_fwd_dma_kernel(ConvArgs a) 
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0 = tile_m * BMX, n0 = tile_n * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -431,7 +440,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_fwd_dma_kernel(ConvArgs a) 
         }
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(st + BM * 128 + (wave * B_INSTR + i) * 1024),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(st + BMX * 128 + (wave * B_INSTR + i) * 1024),
                                                      16, (unsigned)(boff[i] + kt * BK * 2), 0, 0, 0);
     };
 
@@ -449,7 +458,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_fwd_dma_kernel(ConvArgs a) 
 #pragma unroll
     for (int i = 0; i < MT; ++i) fa_off[i] = (uint32_t)(wm * WM + i * 32 + (lane & 31)) * 128;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) fb_off[j] = (uint32_t)(BM * 128 + (wn * WN + j * 32 + (lane & 31)) * 128);
+    for (int j = 0; j < NT; ++j) fb_off[j] = (uint32_t)(BMX * 128 + (wn * WN + j * 32 + (lane & 31)) * 128);
     const int half = lane >> 5;
     // slot of chunk (ks*2+half) in row r: (ks*2+half) ^ ((r>>1)&7); (r>>1)&7 == ((lane&31)>>1)&7 for every tile row here
     const int rsw = ((lane & 31) >> 1) & 7;
@@ -520,7 +529,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_fwd_dma_kernel(ConvArgs a) 
 #undef OESS_WAIT_FRAGS
     __syncthreads();
 
-    conv_epilogue<BN>(a, acc, smem, m0, n0, wm, wn, lane, tid);
+    conv_epilogue<BMX, BN>(a, acc, smem, m0, n0, wm, wn, lane, tid);
 }
 
 // ---- weight packing: OIHW fp32 (PyTorch Conv2d.weight) -> Wp[Npad][Kpad] bf16, k = (r, s, ci)
@@ -613,9 +622,11 @@ int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, 
             else if (!strcmp(e, "dma3")) impl = 3;
         }
         const void* fns[] = {(const void*)&conv_fwd_kernel<128>, (const void*)&conv_fwd_kernel<64>, (const void*)&conv_fwd_kernel<32>,
-                             (const void*)&conv_fwd_dma_kernel<128, 2, false>, (const void*)&conv_fwd_dma_kernel<64, 2, false>, (const void*)&conv_fwd_dma_kernel<32, 2, false>,
-                             (const void*)&conv_fwd_dma_kernel<128, 2, true>, (const void*)&conv_fwd_dma_kernel<64, 2, true>, (const void*)&conv_fwd_dma_kernel<32, 2, true>,
-                             (const void*)&conv_fwd_dma_kernel<128, 3, false>, (const void*)&conv_fwd_dma_kernel<64, 3, false>, (const void*)&conv_fwd_dma_kernel<32, 3, false>};
+                             (const void*)&conv_fwd_dma_kernel<128, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<128, 64, 2, false>, (const void*)&conv_fwd_dma_kernel<128, 32, 2, false>,
+                             (const void*)&conv_fwd_dma_kernel<128, 128, 2, true>, (const void*)&conv_fwd_dma_kernel<128, 64, 2, true>, (const void*)&conv_fwd_dma_kernel<128, 32, 2, true>,
+                             (const void*)&conv_fwd_dma_kernel<128, 128, 3, false>, (const void*)&conv_fwd_dma_kernel<128, 64, 3, false>, (const void*)&conv_fwd_dma_kernel<128, 32, 3, false>,
+                             (const void*)&conv_fwd_dma_kernel<256, 128, 3, false>, (const void*)&conv_fwd_dma_kernel<256, 128, 3, true>,
+                             (const void*)&conv_fwd_dma_kernel<256, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<256, 128, 2, true>};
         for (const void* f : fns)      // > 64 KiB of dynamic LDS needs an explicit opt-in
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
@@ -648,8 +659,8 @@ int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, 
     {                                                                                        \
         size_t lds = (size_t)NS_ * (BM + BN_) * 8 * 16;                                      \
         if (lds < epi) lds = epi;                                                            \
-        if (fastk) hipLaunchKernelGGL((conv_fwd_dma_kernel<BN_, NS_, true>), grid, block, lds, st, a);   \
-        else hipLaunchKernelGGL((conv_fwd_dma_kernel<BN_, NS_, false>), grid, block, lds, st, a);        \
+        if (fastk) hipLaunchKernelGGL((conv_fwd_dma_kernel<128, BN_, NS_, true>), grid, block, lds, st, a);   \
+        else hipLaunchKernelGGL((conv_fwd_dma_kernel<128, BN_, NS_, false>), grid, block, lds, st, a);        \
     }
 #define OESS_DISPATCH(BN_)                                                                   \
     switch (use) {                                                                           \
@@ -657,6 +668,28 @@ int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, 
         case 3: OESS_LAUNCH_DMA(BN_, 3) break;                                               \
         default: OESS_LAUNCH_V1(BN_) break;                                                  \
     }
+    // 256 x 128 tile, 8 waves, 1 workgroup per CU: 25 % fewer L2->LDS bytes per FLOP.  Measured neutral against the
+    // 128-row kernel (tools/conv_ablate.py: +-3 % per layer) because the wave tile, hence the LDS fragment traffic,
+    // is unchanged, so it is opt-in: OESS_CONV_BIG=3 (3-slab ring) or 2 (2-slab ring).
+    static int big = -1;
+    if (big < 0) { const char* e = getenv("OESS_CONV_BIG"); big = e ? atoi(e) : 0; }
+    const int tiles_m256 = (a.M + 255) / 256;
+    if (use >= 2 && big > 0 && bn == 128 && (long long)tiles_m256 * a.tiles_n >= 768) {
+        a.tiles_m = tiles_m256;
+        const dim3 grid2(a.tiles_m * a.tiles_n);
+        const size_t epi2 = (size_t)256 * (128 + 8) * 2 + 4096;
+        if (big == 3) {
+            size_t lds = (size_t)3 * (256 + 128) * 8 * 16;
+            if (lds < epi2) lds = epi2;
+            if (fastk) hipLaunchKernelGGL((conv_fwd_dma_kernel<256, 128, 3, true>), grid2, dim3(512), lds, st, a);
+            else hipLaunchKernelGGL((conv_fwd_dma_kernel<256, 128, 3, false>), grid2, dim3(512), lds, st, a);
+        } else {
+            size_t lds = (size_t)2 * (256 + 128) * 8 * 16;
+            if (lds < epi2) lds = epi2;
+            if (fastk) hipLaunchKernelGGL((conv_fwd_dma_kernel<256, 128, 2, true>), grid2, dim3(512), lds, st, a);
+            else hipLaunchKernelGGL((conv_fwd_dma_kernel<256, 128, 2, false>), grid2, dim3(512), lds, st, a);
+        }
+    } else
     if (bn == 128) OESS_DISPATCH(128)
     else if (bn == 64) OESS_DISPATCH(64)
     else OESS_DISPATCH(32)

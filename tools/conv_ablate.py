@@ -1,0 +1,26 @@
+"""Time one conv shape (HIP events) - used with OESS_CONV_* env switches for A/B runs."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from openess_amd import hip
+SHAPES = {"gates": (8, 110, 160, 256, 512, 3, 1, 1, 1), "l3": (8, 55, 80, 256, 256, 3, 1, 4, 4),
+          "pw": (8, 55, 80, 256, 1024, 1, 1, 0, 1), "l4": (8, 55, 80, 512, 512, 3, 1, 8, 8),
+          "gk4": (8, 110, 160, 1024, 512, 3, 1, 1, 1), "gk1": (8, 110, 160, 64, 512, 3, 1, 1, 1)}
+for name in sys.argv[1:]:
+    B, H, W, Cin, Cout, R, st, pad, dil = SHAPES[name]
+    mode = os.environ.get("ABL_DATA", "randn")
+    x = torch.randn(B, H, W, Cin, device="cuda").bfloat16()
+    w = torch.randn(Cout, Cin, R, R, device="cuda") * 0.05
+    if mode == "zeros": x.zero_(); w.zero_()
+    if mode == "ones": x.fill_(1.0); w.fill_(1.0)
+    pk = hip.pack_conv_weight(w)
+    out = torch.empty(B, H, W, Cout, device="cuda", dtype=torch.bfloat16)
+    for _ in range(5):
+        hip.conv2d_nhwc(x, pk, None, Cout, R, R, st, pad, dil, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(int(os.environ.get('ABL_N', '20'))):
+        hip.conv2d_nhwc(x, pk, None, Cout, R, R, st, pad, dil, out=out)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / int(os.environ.get('ABL_N', '20'))
+    fl = 2.0 * B * H * W * Cout * Cin * R * R
+    print(f"{name}: {ms:.4f} ms  {fl / ms / 1e9:.0f} TF/s", flush=True)
