@@ -150,8 +150,9 @@ int oess_confusion_accumulate(const int64_t* pred, const int64_t* label, int64_t
  * (ASPP) and models/style_networks.py:252-289 (ReLUINSConv2d / INSResBlock).
  *
  * oess_conv2d_pack_weight: OIHW fp32 (Conv2d.weight) -> packed bf16 [Npad][Kpad], K = (r, s, ci);
- *   flip_for_dgrad != 0 packs the data-gradient operator (taps rotated 180 deg, in/out swapped) so
- *   that dX = conv(dY, packed, pad = dil*(R-1) - pad) for stride-1 convolutions.
+ *   flip_for_dgrad == 1 packs the data-gradient operator (taps rotated 180 deg, in/out swapped) so
+ *   that dX = conv(dY, packed, pad = dil*(R-1) - pad) for stride-1 convolutions; == 2 packs the forward operator
+ *   with ConvLSTM gate-interleaved rows for oess_convlstm_fused_bf16.
  * oess_conv2d_fwd_bf16: out = act(conv(in, w) + bias [+ residual]); Cin must be a multiple of 8
  *   (pad the channel dimension; padded weights are zero).  Exactly one of out_bf16 / out_f32 is used
  *   (out_f32 wins when non-null).  Pixel strides are in ELEMENTS.
@@ -176,6 +177,18 @@ int oess_norm_reduce_tile_stats(const float* tile_stats, int tiles, int C, float
  * ------------------------------------------------------------------------------------------ */
 int oess_convlstm_gates_bf16(const void* gates, long long gates_pix_stride, const float* prev_cell, float* cell,
                              void* hidden, long long hidden_pix_stride, long long n_pixels, int C, oess_stream_t stream);
+
+/* ConvLSTM step in ONE kernel: Gates convolution (submodules.py:202-203) + the cell update above, fused in the MFMA
+ * epilogue.  w_packed_gates comes from oess_conv2d_pack_weight(..., flip_for_dgrad = 2): the 4C Conv2d rows are packed
+ * gate-interleaved (row 4*hc + gate) so that one lane of the transposed accumulator owns the four gates of a hidden
+ * channel; bias stays in Conv2d order [4C].  in = cat(x, h_prev) NHWC bf16 (Cin = Cx + C); hidden (bf16, own pixel
+ * stride) must NOT overlap `in` (neighbouring tiles still read h_prev: ping-pong two cat buffers); cell may alias
+ * prev_cell (null = zero state).  C_hidden % 32 == 0, stride 1, dilation 1.  The 4C-channel gate tensor is never
+ * written (-512 B/pixel of HBM traffic per step at C = 64 versus conv + oess_convlstm_gates_bf16). */
+int oess_convlstm_fused_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int Cin,
+                             const void* w_packed_gates, const float* bias, int C_hidden, int R, int S, int pad,
+                             const float* prev_cell, float* cell, void* hidden, long long hidden_pix_stride,
+                             oess_stream_t stream);
 
 /* Statistics of a channel slice without the apply pass (first half of K2): stats = {sum, sumsq, nnz, -}. */
 int oess_masked_stats_slice_f32(const float* in, int B, int Ctot, int c0, int Cs, int64_t HW, double* stats,

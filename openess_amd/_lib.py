@@ -42,6 +42,8 @@ SIGNATURES = {
                                    c_f, c_vp, c_vp, c_int, c_vp]),
     "oess_confusion_accumulate": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
     "oess_convlstm_gates_bf16": (c_int, [c_vp, c_ll, c_vp, c_vp, c_vp, c_ll, c_ll, c_int, c_vp]),
+    "oess_convlstm_fused_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp,
+                                         c_vp, c_vp, c_ll, c_vp]),
     "oess_masked_stats_slice_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp]),
     "oess_event_slice_to_nhwc8_bf16": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_ll, c_vp, c_int, c_vp, c_vp]),
     "oess_norm_stats_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_ll, c_int, c_vp, c_vp, c_vp]),

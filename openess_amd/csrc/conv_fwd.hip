@@ -53,15 +53,26 @@ struct ConvArgs {
     int M;                   // B*Ho*Wo
     int relu;
     int tiles_m, tiles_n;
+    // fused ConvLSTM epilogue (EPI == 1): Cout = 4*lstm_C gate-interleaved rows (n' = 4*hc + gate)
+    const float* lstm_prev;    // [M][C] fp32 previous cell state or null (= zero state)
+    float* lstm_cell;          // [M][C] fp32 new cell state (may alias lstm_prev: a tile only touches its own block)
+    uint16_t* lstm_h;          // hidden output, bf16, pixel stride lstm_h_stride (must NOT alias the conv input)
+    long long lstm_h_stride;
+    int lstm_C;
+    float rcp_hw, rcp_wo;      // persistent kernel: float reciprocals for the per-tile row decode (M < 2^22)
     unsigned inv_cpt, inv_s;   // exact small-range reciprocals: kc / cpt == (kc * inv_cpt) >> 20, tap / S == (tap * inv_s) >> 16
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-template <int BMX, int BN>
+// PITCH: row pitch (elements) of the bf16 LDS image.  BN + 8 pads the image; BN (no padding) makes it exactly one
+// ring stage (the persistent kernel parks it in the stage it has just finished reading) and still reads conflict
+// free: the 16-lane groups of ds_read_b128 cover 16 distinct 16-byte chunks of a 256-byte row pair.
+template <int BMX, int BN, int PITCH = BN + 8>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
                                               f32x16_t (&acc)[BMX / ((BMX * 2 / 64) / ((BN == 128) ? 2 : 1)) / 32][(BN / ((BN == 128) ? 2 : 1)) / 32],
-                                              unsigned char* smem, int m0, int n0, int wm, int wn, int lane, int tid) {
+                                              unsigned char* smem, int m0, int n0, int wm, int wn, int lane, int tid,
+                                              float* red_override = nullptr) {
     constexpr int NTHREADS = BMX * 2;
     constexpr int WAVES_N = (BN == 128) ? 2 : 1;
     constexpr int WAVES_M = (NTHREADS / 64) / WAVES_N;
@@ -91,8 +102,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
     }
     // bf16 path: stage the tile as [BM][BN] bf16 in LDS (row pitch BN*2 + 16 bytes against bank conflicts)
     uint16_t* lC = reinterpret_cast<uint16_t*>(smem);
-    constexpr int PITCH = BN + 8;
-    float* red = reinterpret_cast<float*>(smem + BMX * PITCH * 2);          // [WAVES_M][BN][2] (BatchNorm partials)
+    float* red = red_override ? red_override : reinterpret_cast<float*>(smem + BMX * PITCH * 2);   // [WAVES_M][BN][2] (BatchNorm partials)
     if (a.stats) {
         // per-column sum / sum of squares of the fp32 accumulators over this tile's rows (rows >= M are exact zeros:
         // their A rows were zero filled and stats are only requested for bias-free convs)
@@ -175,6 +185,60 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
 #pragma unroll
             for (int q = 0; q < 8; ++q) if (n + q < a.Cout) dst[q] = u.h[q];
         }
+    }
+}
+
+
+// ---- fused ConvLSTM cell update (e2vid/model/submodules.py:205-212) straight from the accumulators.
+// The gate convolution is run TRANSPOSED (D^T = W * A^T: the packed weight is the MFMA A operand), so a lane
+// holds, for ONE pixel (col = lane & 31), rows (e&3) + 8*(e>>2) + 4*(lane>>5) of the 32-row n block; with the
+// weight rows packed gate-interleaved (n' = 4*hc + gate) the four registers e = 4*q .. 4*q+3 are exactly the
+// (in, remember, out, cell) pre-activations of hidden channel 2*q + (lane>>5): the LSTM algebra is lane local,
+// the 4C-channel gate tensor never exists in memory, and c / h leave through padded LDS images as full rows.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
+__device__ __forceinline__ void lstm_epilogue(const ConvArgs& a, f32x16_t (&acc)[2][2], unsigned char* smem, int m0, int n0,
+                                              int wm, int wn, int lane, int tid) {
+    constexpr int CP = 33, HP = 34;                        // LDS pitches: fp32 cell image, bf16 hidden image
+    float* lc = reinterpret_cast<float*>(smem);            // [128][33]
+    uint16_t* lh = reinterpret_cast<uint16_t*>(smem + 128 * CP * 4);    // [128][34]
+    const int C = a.lstm_C;
+    const int hc0 = n0 >> 2;                               // first hidden channel of this tile (32 per 128-row n tile)
+    const int p = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ml = wm * 64 + i * 32 + p;
+        const int m = m0 + ml;
+        const bool valid = m < a.M;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int hcl = wn * 16 + j * 8 + 2 * q + hi;
+                const int hc = hc0 + hcl;
+                float gi = acc[i][j][q * 4 + 0], gr = acc[i][j][q * 4 + 1], go = acc[i][j][q * 4 + 2], gc = acc[i][j][q * 4 + 3];
+                if (a.bias) { gi += a.bias[hc]; gr += a.bias[C + hc]; go += a.bias[2 * C + hc]; gc += a.bias[3 * C + hc]; }
+                const float pc = (a.lstm_prev && valid) ? a.lstm_prev[(long long)m * C + hc] : 0.0f;
+                const float nc = fast_sigmoid(gr) * pc + fast_sigmoid(gi) * fast_tanh(gc);     // submodules.py:211
+                const float hv = fast_sigmoid(go) * fast_tanh(nc);                              // submodules.py:212
+                lc[ml * CP + hcl] = nc;
+                lh[ml * HP + hcl] = f32_to_bf16(hv);
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {                         // cell: 128 rows x 32 fp32, one 128-byte row per 32 lanes
+        const int idx = tid + 256 * k, row = idx >> 5, col = idx & 31;
+        const int m = m0 + row;
+        if (m < a.M) a.lstm_cell[(long long)m * C + hc0 + col] = lc[row * CP + col];
+    }
+    const uint32_t* lh32 = reinterpret_cast<const uint32_t*>(lh);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                          // hidden: 128 rows x 16 dwords (2 bf16 each)
+        const int idx = tid + 256 * k, row = idx >> 4, col = idx & 15;
+        const int m = m0 + row;
+        if (m < a.M) *reinterpret_cast<uint32_t*>(a.lstm_h + (long long)m * a.lstm_h_stride + hc0 + col * 2) = lh32[row * (HP / 2) + col];
     }
 }
 
@@ -341,7 +405,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_fwd_kernel(ConvArgs a) {
 // =================================================================================================
 // FASTK: Cin % 64 == 0, i.e. every 64-wide K-slab lies inside ONE filter tap -> the tap decode is wave-uniform
 // (scalar) and the per-lane part of a gather address is a constant.
-template <int BMX, int BN, int NSTAGE, bool FASTK>
+template <int BMX, int BN, int NSTAGE, bool FASTK, int EPI = 0>
 __global__ __launch_bounds__(BMX * 2) void conv_fwd_dma_kernel(ConvArgs a) {
     constexpr int NTHREADS = BMX * 2;                // 128-row tile: 4 waves, 256-row tile: 8 waves
     constexpr int NWAVES = NTHREADS / 64;
@@ -479,7 +543,8 @@ __global__ __launch_bounds__(BMX * 2) void conv_fwd_dma_kernel(ConvArgs a) {
     {                                                                                                            \
         _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                           \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                       \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SRC_A[i], SRC_B[j], acc[i][j], 0, 0, 0);     \
+                acc[i][j] = (EPI == 1) ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(SRC_B[j], SRC_A[i], acc[i][j], 0, 0, 0)     \
+                                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(SRC_A[i], SRC_B[j], acc[i][j], 0, 0, 0);   \
     }
     // wait until only N_ LDS reads remain outstanding; the "+v" operands tie later uses of the fragments to the wait
 #define OESS_WAIT_FRAGS(N_, FA_, FB_)                                                                            \
@@ -529,7 +594,222 @@ __global__ __launch_bounds__(BMX * 2) void conv_fwd_dma_kernel(ConvArgs a) {
 #undef OESS_WAIT_FRAGS
     __syncthreads();
 
-    conv_epilogue<BMX, BN>(a, acc, smem, m0, n0, wm, wn, lane, tid);
+    if constexpr (EPI == 1) lstm_epilogue(a, acc, smem, m0, n0, wm, wn, lane, tid);
+    else conv_epilogue<BMX, BN>(a, acc, smem, m0, n0, wm, wn, lane, tid);
+}
+
+// =================================================================================================
+// v3: PERSISTENT LDS-DMA kernel.  Same tile, ring and fragment pipeline as conv_fwd_dma_kernel<128, BN, 2>,
+// but one workgroup walks a strided list of output tiles of its XCD:
+//   * the first K-slab of the NEXT tile is DMA'd under the last K-slab of the current one, so a tile's
+//     pipeline fill (decode + issue + ~1 us DMA round trip) and the workgroup launch disappear from the
+//     critical path (tools/probes/mfma_loop_probe.hip: the bare K loop runs 1.22 PF as 4400 short workgroups
+//     and 1.43 PF as 512 persistent ones at K = 2304);
+//   * the epilogue's global stores are never waited for: the next tile's slab 0 is retired BEFORE the
+//     epilogue (vmcnt(0) there is the only full drain), its first barrier needs no vmcnt, and the stores
+//     complete under its first slab;
+//   * the bf16 output image is parked, unpadded, in the ring stage that was read last (exactly 32 KB at
+//     BN = 128), the other stage already holds the next tile's slab 0.
+// =================================================================================================
+__device__ __forceinline__ int div_small(int m, int d, float rcp) {     // exact for 0 <= m < 2^22
+    int q = (int)((float)m * rcp);
+    const int r = m - q * d;
+    q -= (r < 0);
+    q += (r >= d);
+    return q;
+}
+
+template <int BN, bool FASTK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_fwd_persist_kernel(ConvArgs a) {
+    constexpr int BMX = 128, NSTAGE = 2, NWAVES = 4;
+    constexpr int WAVES_N = (BN == 128) ? 2 : 1;
+    constexpr int WAVES_M = NWAVES / WAVES_N;
+    constexpr int WM = BMX / WAVES_M;
+    constexpr int WN = BN / WAVES_N;
+    constexpr int MT = WM / 32, NT = WN / 32;
+    constexpr int A_INSTR = BMX * 8 / 64 / NWAVES;
+    constexpr int B_INSTR = BN * 8 / 64 / NWAVES;
+    constexpr int STAGE_BYTES = (BMX + BN) * 8 * 16;
+    constexpr int NFRAG = MT + NT;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* red = reinterpret_cast<float*>(smem + NSTAGE * STAGE_BYTES);
+
+    // ---- tile schedule: XCD x owns the contiguous tile range [lo, lo + cnt); its workgroups stride through it,
+    // so at any time one XCD's L2 holds a compact band of input rows and all n-tiles of the same m-tiles.
+    const int nt_all = a.tiles_m * a.tiles_n;
+    const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    int t, t_end;
+    {
+        const int q = nt_all >> 3, r = nt_all & 7;
+        const int lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        t = lo + wslot;
+        t_end = lo + q + (xcd < r ? 1 : 0);
+    }
+    if (t >= t_end) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int KT = a.Kpad / BK;
+    const int cpt = a.Cin >> 3, ntaps = a.R * a.S;
+    const int hw = a.Ho * a.Wo;
+
+    const long long in_bytes = (((long long)a.B * a.H * a.W - 1) * a.in_pix_stride + a.Cin) * 2;
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7ffffff0, 0x00020000);
+
+    const int lrow = lane >> 3, slot = lane & 7;
+    int iy0[A_INSTR], ix0[A_INSTR], rowoff[A_INSTR], csrc[A_INSTR], boff[B_INSTR], bbase[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) csrc[i] = slot ^ ((((wave * A_INSTR + i) * 8 + lrow) >> 1) & 7);
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int r = (wave * B_INSTR + i) * 8 + lrow;
+        bbase[i] = (r * a.Kpad + (slot ^ ((r >> 1) & 7)) * 8) * 2;
+    }
+    int m0 = 0, n0 = 0;
+    // per-tile row decode of the gather lanes (float-reciprocal division: exact below 2^22 rows, host checked)
+    auto setup = [&](int tile) {
+        const int tile_n = tile % a.tiles_n, tile_m = tile / a.tiles_n;
+        m0 = tile_m * BMX;
+        n0 = tile_n * BN;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            const int r = (wave * A_INSTR + i) * 8 + lrow;
+            const int m = m0 + r;
+            const bool valid = m < a.M;
+            const int mm = valid ? m : 0;
+            const int b = div_small(mm, hw, a.rcp_hw), rem = mm - b * hw;
+            const int oy = div_small(rem, a.Wo, a.rcp_wo), ox = rem - oy * a.Wo;
+            iy0[i] = valid ? oy * a.stride - a.pad : -0x4000;
+            ix0[i] = ox * a.stride - a.pad;
+            rowoff[i] = (int)((((long long)b * a.H + (oy * a.stride - a.pad)) * a.W + ix0[i]) * a.in_pix_stride * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) boff[i] = bbase[i] + n0 * a.Kpad * 2;
+    };
+
+    auto issue = [&](int kt, int stage) {
+        unsigned char* st = smem + stage * STAGE_BYTES;
+        if constexpr (FASTK) {
+            const unsigned kc0 = (unsigned)(kt * 8);
+            const unsigned tap = (kc0 * a.inv_cpt) >> 20;
+            const int cc0 = (int)(kc0 - tap * cpt);
+            const unsigned r = (tap * a.inv_s) >> 16;
+            const int sx = (int)(tap - r * a.S);
+            const int dy = (int)r * a.dil, dx = sx * a.dil;
+            const int tapoff = ((dy * a.W + dx) * (int)a.in_pix_stride + cc0 * 8) * 2;
+            const bool tap_ok = (int)tap < ntaps;
+#pragma unroll
+            for (int i = 0; i < A_INSTR; ++i) {
+                const bool ok = tap_ok && (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
+                const unsigned voff = ok ? (unsigned)(rowoff[i] + csrc[i] * 16 + tapoff) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave * A_INSTR + i) * 1024),
+                                                         16, voff, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_INSTR; ++i) {
+                const unsigned kc = (unsigned)(kt * 8 + csrc[i]);
+                const unsigned tap = (kc * a.inv_cpt) >> 20;
+                const int cc = (int)(kc - tap * cpt);
+                const unsigned r = (tap * a.inv_s) >> 16;
+                const int sx = (int)(tap - r * a.S);
+                const int dy = (int)r * a.dil, dx = sx * a.dil;
+                const bool ok = (int)tap < ntaps && (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
+                const unsigned voff = ok ? (unsigned)(rowoff[i] + ((dy * a.W + dx) * (int)a.in_pix_stride + cc * 8) * 2) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave * A_INSTR + i) * 1024),
+                                                         16, voff, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(st + BMX * 128 + (wave * B_INSTR + i) * 1024),
+                                                     16, (unsigned)(boff[i] + kt * BK * 2), 0, 0, 0);
+    };
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    uint32_t fa_off[MT], fb_off[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa_off[i] = (uint32_t)(wm * WM + i * 32 + (lane & 31)) * 128;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb_off[j] = (uint32_t)(BMX * 128 + (wn * WN + j * 32 + (lane & 31)) * 128);
+    const int half = lane >> 5;
+    const int rsw = ((lane & 31) >> 1) & 7;
+
+#define OESS_FRAG_READ(DST_A, DST_B, KS)                                                                         \
+    {                                                                                                            \
+        const uint32_t sl_ = (uint32_t)((((KS) * 2 + half) ^ rsw) * 16);                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                           \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(DST_A[i]) : "v"(stage_ + fa_off[i] + sl_) : "memory");   \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                           \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(DST_B[j]) : "v"(stage_ + fb_off[j] + sl_) : "memory");   \
+    }
+#define OESS_FRAG_MMA(SRC_A, SRC_B)                                                                              \
+    {                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                           \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                       \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SRC_A[i], SRC_B[j], acc[i][j], 0, 0, 0);     \
+    }
+#define OESS_WAIT_FRAGS(N_, FA_, FB_)                                                                            \
+    {                                                                                                            \
+        if constexpr (MT == 2 && NT == 2)                                                                        \
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(FA_[0]), "+v"(FA_[1]), "+v"(FB_[0]), "+v"(FB_[1]) : "n"(N_) : "memory"); \
+        else if constexpr (MT == 1 && NT == 2)                                                                   \
+            asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(FA_[0]), "+v"(FB_[0]), "+v"(FB_[1]) : "n"(N_) : "memory"); \
+        else                                                                                                     \
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(FA_[0]), "+v"(FB_[0]) : "n"(N_) : "memory");             \
+    }
+
+    setup(t);
+    issue(0, 0);
+    int g = 0;                  // ring position of the slab consumed next (runs across tiles)
+    bool drain = true;          // slab 0 of the first tile still has to be waited for
+    for (;;) {
+        f32x16_t acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+        const int m0c = m0, n0c = n0;
+        const int tn = t + nslot;
+        const bool has_next = tn < t_end;
+        for (int kt = 0; kt < KT; ++kt) {
+            if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            drain = true;
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < KT) issue(kt + 1, (g + 1) & 1);
+            else if (has_next) { setup(tn); issue(0, (g + 1) & 1); }
+            const uint32_t stage_ = lds0 + (uint32_t)((g & 1) * STAGE_BYTES);
+            bf16x8_t fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+            OESS_FRAG_READ(fa0, fb0, 0)
+            OESS_FRAG_READ(fa1, fb1, 1)
+            OESS_WAIT_FRAGS(NFRAG, fa0, fb0)
+            OESS_FRAG_MMA(fa0, fb0)
+            OESS_FRAG_READ(fa0, fb0, 2)
+            OESS_WAIT_FRAGS(NFRAG, fa1, fb1)
+            OESS_FRAG_MMA(fa1, fb1)
+            OESS_FRAG_READ(fa1, fb1, 3)
+            OESS_WAIT_FRAGS(NFRAG, fa0, fb0)
+            OESS_FRAG_MMA(fa0, fb0)
+            OESS_WAIT_FRAGS(0, fa1, fb1)
+            OESS_FRAG_MMA(fa1, fb1)
+            ++g;
+        }
+        // retire the prefetched slab 0 of the next tile, then everybody is done with the stage read last
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        conv_epilogue<BMX, BN, BN>(a, acc, smem + ((g - 1) & 1) * STAGE_BYTES, m0c, n0c, wm, wn, lane, tid, red);
+        if (!has_next) break;
+        t = tn;
+        drain = false;          // slab 0 is in LDS already; the epilogue's stores complete under it
+    }
+#undef OESS_FRAG_READ
+#undef OESS_FRAG_MMA
+#undef OESS_WAIT_FRAGS
 }
 
 // ---- weight packing: OIHW fp32 (PyTorch Conv2d.weight) -> Wp[Npad][Kpad] bf16, k = (r, s, ci)
@@ -537,15 +817,18 @@ __global__ __launch_bounds__(BMX * 2) void conv_fwd_dma_kernel(ConvArgs a) {
 __global__ void pack_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ wp, int Cout, int Cin, int R,
                                    int S, int Cin_pad, int Kpad, int Npad, int flip) {
     const long long total = (long long)Npad * Kpad;
-    const int Nlog = flip ? Cin : Cout;      // logical output channels of the packed operator
-    const int Klog_c = flip ? Cout : Cin;    // logical input channels
+    const int Nlog = flip == 1 ? Cin : Cout;      // logical output channels of the packed operator
+    const int Klog_c = flip == 1 ? Cout : Cin;    // logical input channels
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int n = (int)(i / Kpad), k = (int)(i - (long long)n * Kpad);
         const int tap = k / Cin_pad, ci = k - tap * Cin_pad;
         float v = 0.0f;
         if (n < Nlog && tap < R * S && ci < Klog_c) {
             const int r = tap / S, s = tap - r * S;
-            if (!flip) v = w[(((long long)n * Cin + ci) * R + r) * S + s];
+            if (flip == 2) {                    // ConvLSTM gate interleave: packed row n = 4*hc + gate <- Conv2d row gate*C + hc
+                const int src = (n & 3) * (Cout >> 2) + (n >> 2);
+                v = w[(((long long)src * Cin + ci) * R + r) * S + s];
+            } else if (!flip) v = w[(((long long)n * Cin + ci) * R + r) * S + s];
             else v = w[(((long long)ci * Cin + n) * R + (R - 1 - r)) * S + (S - 1 - s)];
         }
         wp[i] = f32_to_bf16(v);
@@ -559,7 +842,8 @@ extern "C" {
 int oess_conv2d_pack_weight(const float* w_oihw, int Cout, int Cin, int R, int S, int flip_for_dgrad, void* packed,
                             size_t packed_bytes, oess_stream_t stream) {
     if (!w_oihw || !packed || Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0) return OESS_EINVAL;
-    const int n_log = flip_for_dgrad ? Cin : Cout, c_log = flip_for_dgrad ? Cout : Cin;
+    if (flip_for_dgrad == 2 && (Cout & 3)) return OESS_EINVAL;
+    const int n_log = flip_for_dgrad == 1 ? Cin : Cout, c_log = flip_for_dgrad == 1 ? Cout : Cin;
     const int cin_pad = (c_log + 7) / 8 * 8;
     const int kpad = (R * S * cin_pad + BK - 1) / BK * BK;
     const int npad = (n_log + 127) / 128 * 128;
@@ -575,17 +859,29 @@ int oess_conv2d_pack_weight(const float* w_oihw, int Cout, int Cin, int R, int S
 
 size_t oess_conv2d_packed_bytes(int Cout, int Cin, int R, int S, int flip_for_dgrad) {
     if (Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0) return 0;
-    const int n_log = flip_for_dgrad ? Cin : Cout, c_log = flip_for_dgrad ? Cout : Cin;
+    const int n_log = flip_for_dgrad == 1 ? Cin : Cout, c_log = flip_for_dgrad == 1 ? Cout : Cin;
     const int cin_pad = (c_log + 7) / 8 * 8;
     const int kpad = (R * S * cin_pad + BK - 1) / BK * BK;
     const int npad = (n_log + 127) / 128 * 128;
     return (size_t)npad * kpad * 2;
 }
 
-int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int Cin, const void* w_packed,
-                         const float* bias, int Cout, int R, int S, int stride, int pad, int dil, int relu,
-                         const void* residual, long long res_pix_stride, void* out_bf16, float* out_f32,
-                         long long out_pix_stride, float* tile_stats, oess_stream_t stream) {
+}  // extern "C"
+
+namespace {
+struct LstmOut { const float* prev; float* cell; void* h; long long h_stride; int C; };
+
+int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, int Cin, const void* w_packed,
+                  const float* bias, int Cout, int R, int S, int stride, int pad, int dil, int relu,
+                  const void* residual, long long res_pix_stride, void* out_bf16, float* out_f32,
+                  long long out_pix_stride, float* tile_stats, const LstmOut* lstm, oess_stream_t stream) {
+    if (lstm) {
+        if (!lstm->cell || !lstm->h || lstm->C <= 0 || (lstm->C & 31) || Cout != 4 * lstm->C || (lstm->h_stride & 1) ||
+            lstm->h_stride < lstm->C || residual || relu || tile_stats || out_f32 || stride != 1)
+            return OESS_EINVAL;
+        out_bf16 = lstm->h;             // satisfies the generic output checks below; the conv epilogue is not used
+        out_pix_stride = Cout;
+    }
     if (!in || !w_packed || (!out_bf16 && !out_f32) || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 7) || Cout <= 0 ||
         R <= 0 || S <= 0 || stride <= 0 || pad < 0 || dil <= 0)
         return OESS_EINVAL;
@@ -609,6 +905,8 @@ int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, 
     if (M > 0x7fffffffll) return OESS_EINVAL;
     a.M = (int)M;
     a.relu = relu;
+    a.lstm_prev = lstm ? lstm->prev : nullptr; a.lstm_cell = lstm ? lstm->cell : nullptr;
+    a.lstm_h = lstm ? (uint16_t*)lstm->h : nullptr; a.lstm_h_stride = lstm ? lstm->h_stride : 0; a.lstm_C = lstm ? lstm->C : 0;
     a.tiles_m = (a.M + BM - 1) / BM;
     hipStream_t st = (hipStream_t)stream;
     // implementation selector (A/B testing): OESS_CONV_IMPL = v1 | dma2 | dma3 | dma4 ; default below
@@ -620,13 +918,17 @@ int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, 
             if (!strcmp(e, "v1")) impl = 0;
             else if (!strcmp(e, "dma2")) impl = 2;
             else if (!strcmp(e, "dma3")) impl = 3;
+            else if (!strcmp(e, "persist")) impl = 4;
         }
         const void* fns[] = {(const void*)&conv_fwd_kernel<128>, (const void*)&conv_fwd_kernel<64>, (const void*)&conv_fwd_kernel<32>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<128, 64, 2, false>, (const void*)&conv_fwd_dma_kernel<128, 32, 2, false>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 2, true>, (const void*)&conv_fwd_dma_kernel<128, 64, 2, true>, (const void*)&conv_fwd_dma_kernel<128, 32, 2, true>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 3, false>, (const void*)&conv_fwd_dma_kernel<128, 64, 3, false>, (const void*)&conv_fwd_dma_kernel<128, 32, 3, false>,
                              (const void*)&conv_fwd_dma_kernel<256, 128, 3, false>, (const void*)&conv_fwd_dma_kernel<256, 128, 3, true>,
-                             (const void*)&conv_fwd_dma_kernel<256, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<256, 128, 2, true>};
+                             (const void*)&conv_fwd_dma_kernel<256, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<256, 128, 2, true>,
+                             (const void*)&conv_fwd_dma_kernel<128, 128, 2, false, 1>, (const void*)&conv_fwd_dma_kernel<128, 128, 2, true, 1>,
+                             (const void*)&conv_fwd_persist_kernel<128, false>, (const void*)&conv_fwd_persist_kernel<64, false>, (const void*)&conv_fwd_persist_kernel<32, false>,
+                             (const void*)&conv_fwd_persist_kernel<128, true>, (const void*)&conv_fwd_persist_kernel<64, true>, (const void*)&conv_fwd_persist_kernel<32, true>};
         for (const void* f : fns)      // > 64 KiB of dynamic LDS needs an explicit opt-in
             (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
@@ -641,6 +943,9 @@ int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, 
         const unsigned maxtap = nkc / cpt + 1;
         for (unsigned t = 0; exact && t <= maxtap; ++t) exact = ((t * a.inv_s) >> 16) == t / (unsigned)S;
         if (!exact) use = 0;
+        a.rcp_hw = 1.0f / (float)(a.Ho * a.Wo);
+        a.rcp_wo = 1.0f / (float)a.Wo;
+        if (use == 4 && M >= (1ll << 22)) use = 2;     // float-reciprocal row decode is exact below 2^22 rows
     }
     // the packed weight has Npad = multiple of 128 rows, so any BN <= 128 tiles it safely
     const int bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
@@ -662,11 +967,28 @@ int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, 
         if (fastk) hipLaunchKernelGGL((conv_fwd_dma_kernel<128, BN_, NS_, true>), grid, block, lds, st, a);   \
         else hipLaunchKernelGGL((conv_fwd_dma_kernel<128, BN_, NS_, false>), grid, block, lds, st, a);        \
     }
+#define OESS_LAUNCH_PERSIST(BN_)                                                             \
+    {                                                                                        \
+        const size_t lds = (size_t)2 * (BM + BN_) * 8 * 16 + 2048;                           \
+        const int nt_ = a.tiles_m * a.tiles_n;                                               \
+        const dim3 pgrid(nt_ >= 512 ? 512 : (nt_ + 7) / 8 * 8);                              \
+        if (fastk) hipLaunchKernelGGL((conv_fwd_persist_kernel<BN_, true>), pgrid, block, lds, st, a);   \
+        else hipLaunchKernelGGL((conv_fwd_persist_kernel<BN_, false>), pgrid, block, lds, st, a);        \
+    }
 #define OESS_DISPATCH(BN_)                                                                   \
     switch (use) {                                                                           \
         case 2: OESS_LAUNCH_DMA(BN_, 2) break;                                               \
+        case 4: OESS_LAUNCH_PERSIST(BN_) break;                                              \
         case 3: OESS_LAUNCH_DMA(BN_, 3) break;                                               \
         default: OESS_LAUNCH_V1(BN_) break;                                                  \
+    }
+    if (lstm) {     // fused ConvLSTM cell update: transposed MFMA + lane-local gate algebra (needs the LDS-DMA kernel)
+        if (use < 2) return OESS_EINVAL;
+        const size_t lds = (size_t)2 * (BM + 128) * 8 * 16;
+        if (fastk) hipLaunchKernelGGL((conv_fwd_dma_kernel<128, 128, 2, true, 1>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((conv_fwd_dma_kernel<128, 128, 2, false, 1>), grid, block, lds, st, a);
+        OESS_HIP(hipGetLastError());
+        return OESS_OK;
     }
     // 256 x 128 tile, 8 waves, 1 workgroup per CU: 25 % fewer L2->LDS bytes per FLOP.  Measured neutral against the
     // 128-row kernel (tools/conv_ablate.py: +-3 % per layer) because the wave tile, hence the LDS fragment traffic,
@@ -695,9 +1017,35 @@ int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, 
     else OESS_DISPATCH(32)
 #undef OESS_DISPATCH
 #undef OESS_LAUNCH_DMA
+#undef OESS_LAUNCH_PERSIST
 #undef OESS_LAUNCH_V1
     OESS_HIP(hipGetLastError());
     return OESS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int Cin, const void* w_packed,
+                         const float* bias, int Cout, int R, int S, int stride, int pad, int dil, int relu,
+                         const void* residual, long long res_pix_stride, void* out_bf16, float* out_f32,
+                         long long out_pix_stride, float* tile_stats, oess_stream_t stream) {
+    return conv_fwd_impl(in, in_pix_stride, B, H, W, Cin, w_packed, bias, Cout, R, S, stride, pad, dil, relu, residual,
+                         res_pix_stride, out_bf16, out_f32, out_pix_stride, tile_stats, nullptr, stream);
+}
+
+int oess_convlstm_fused_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int Cin, const void* w_packed_gates,
+                             const float* bias, int C_hidden, int R, int S, int pad, const float* prev_cell, float* cell,
+                             void* hidden, long long hidden_pix_stride, oess_stream_t stream) {
+    if (!in || !hidden) return OESS_EINVAL;
+    {   // the hidden output must not alias the convolution input (neighbouring tiles still read the old state)
+        const char* i0 = (const char*)in; const char* i1 = i0 + ((long long)B * H * W - 1) * in_pix_stride * 2 + (long long)Cin * 2;
+        const char* h0 = (const char*)hidden; const char* h1 = h0 + ((long long)B * H * W - 1) * hidden_pix_stride * 2 + (long long)C_hidden * 2;
+        if (h0 < i1 && i0 < h1) return OESS_EINVAL;
+    }
+    LstmOut l{prev_cell, cell, hidden, hidden_pix_stride, C_hidden};
+    return conv_fwd_impl(in, in_pix_stride, B, H, W, Cin, w_packed_gates, bias, 4 * C_hidden, R, S, 1, pad, 1, 0, nullptr, 0,
+                         nullptr, nullptr, 0, nullptr, &l, stream);
 }
 
 }  // extern "C"

@@ -2,6 +2,8 @@
 and shapes are identical to the reference so its checkpoints load unchanged; forward passes run on the
 HIP kernels (MFMA conv + fused gate kernel).  Inference only: the reference keeps E2VID frozen and runs
 it under no_grad (e2vid/image_reconstructor.py:81)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -96,16 +98,35 @@ class ConvLSTM(nn.Module):
         pad = kernel_size // 2
         self.Gates = nn.Conv2d(input_size + hidden_size, 4 * hidden_size, kernel_size, padding=pad)
         self._pw = engine.PackedWeight()
+        self._pw_fused = {}
 
     def step(self, state):
-        """state: dict(xh=[B, Cin+Ch, H, W] cl bf16 with x already written, cell=fp32 [B,H,W,Ch], fresh=bool)."""
+        """state: dict(xh=[two cat(x, h) buffers, B x (Cin+Ch) x H x W cl bf16], cur=index of the buffer whose x half
+        was just written and whose h half holds h_prev, cell=fp32 [B,H,W,Ch], fresh=bool).
+        Fused path (hidden % 32 == 0): ONE kernel = Gates conv + cell update; the new h goes to the OTHER cat buffer
+        (the conv still reads h_prev around every tile), which becomes current.  Otherwise conv + gate kernel."""
         g = self.Gates
-        pw = self._pw.get(g.weight, g.bias, None, cin_pad=state['xh'].shape[1])
-        gates = engine.conv2d_infer(state['xh'], pw, g.out_channels, g.kernel_size[0], 1, g.padding[0], 1,
-                                    out=state.get('gates'))
-        state['gates'] = gates
-        h_view = state['xh'][:, self.input_size:]
-        hip.convlstm_gates(engine.nhwc(gates), state['cell'], engine.nhwc(h_view), prev_cell_is_zero=state['fresh'])
+        cur = state['cur']
+        xh = state['xh'][cur]
+        k, pad = g.kernel_size[0], g.padding[0]
+        if self.hidden_size % 32 == 0 and os.environ.get('OESS_LSTM_UNFUSED') is None:
+            pw = self._pw_fused
+            key = (g.weight._version, g.bias._version)
+            if pw.get('key') != key:
+                with torch.no_grad():
+                    pw['packed'] = hip.pack_conv_weight(g.weight, flip=2)
+                    pw['bias'] = g.bias.detach().float().contiguous()
+                pw['key'] = key
+            h_view = state['xh'][1 - cur][:, self.input_size:]
+            hip.convlstm_fused(engine.nhwc(xh), pw['packed'], pw['bias'], state['cell'], engine.nhwc(h_view), k, pad,
+                               prev_cell_is_zero=state['fresh'])
+            state['cur'] = 1 - cur
+        else:
+            pw = self._pw.get(g.weight, g.bias, None, cin_pad=xh.shape[1])
+            gates = engine.conv2d_infer(xh, pw, g.out_channels, k, 1, pad, 1, out=state.get('gates'))
+            state['gates'] = gates
+            h_view = xh[:, self.input_size:]
+            hip.convlstm_gates(engine.nhwc(gates), state['cell'], engine.nhwc(h_view), prev_cell_is_zero=state['fresh'])
         state['fresh'] = False
         return h_view
 
@@ -127,12 +148,12 @@ class RecurrentConvLayer(nn.Module):
         Ho = (H + 2 * c.padding[0] - c.kernel_size[0]) // c.stride[0] + 1
         Wo = (W + 2 * c.padding[0] - c.kernel_size[0]) // c.stride[0] + 1
         Co = c.out_channels
-        return {'xh': engine.zeros_cl(B, 2 * Co, Ho, Wo, x.device),
+        return {'xh': [engine.zeros_cl(B, 2 * Co, Ho, Wo, x.device), engine.zeros_cl(B, 2 * Co, Ho, Wo, x.device)], 'cur': 0,
                 'cell': torch.empty((B, Ho, Wo, Co), dtype=torch.float32, device=x.device), 'fresh': True}
 
     def forward(self, x, prev_state):
         state = prev_state if prev_state is not None else self.new_state(x)
         Co = self.conv.conv2d.out_channels
-        self.conv(x, out=state['xh'][:, :Co])         # x -> first half of the cat(x, h) buffer
+        self.conv(x, out=state['xh'][state['cur']][:, :Co])         # x -> first half of the current cat(x, h) buffer
         h = self.recurrent_block.step(state)
         return h, state

@@ -303,7 +303,8 @@ def conv_packed_bytes(Cout, Cin, R, S, flip=False):
 
 def pack_conv_weight(w, flip=False):
     """Conv2d.weight (OIHW, any float dtype) -> packed bf16 operand for conv2d_nhwc.
-    flip=True packs the data-gradient operator of a stride-1 convolution."""
+    flip=True (1) packs the data-gradient operator of a stride-1 convolution; flip=2 packs the forward operator with
+    ConvLSTM gate-interleaved rows (convlstm_fused)."""
     lib = _lib.load()
     _need_gpu(w)
     w = w.detach().float().contiguous()
@@ -360,6 +361,24 @@ def convlstm_gates(gates, cell, hidden_out, prev_cell_is_zero=False):
         raise ValueError("convlstm_gates: shape mismatch")
     _lib.check(lib.oess_convlstm_gates_bf16(_ptr(gates), gs, None if prev_cell_is_zero else _ptr(cell), _ptr(cell),
                                             _ptr(hidden_out), hs, B * H * W, C, _stream()), "oess_convlstm_gates_bf16")
+    return hidden_out
+
+
+def convlstm_fused(xh, packed_gates, bias, cell, hidden_out, k, pad, prev_cell_is_zero=False):
+    """One ConvLSTM step in one kernel (e2vid/model/submodules.py:199-214): Gates conv over xh = cat(x, h_prev)
+    (NHWC bf16) + cell update; `packed_gates` = pack_conv_weight(Gates.weight, flip=2) (gate-interleaved rows).
+    cell: fp32 [B,H,W,C] updated in place; hidden_out: bf16 NHWC view [B,H,W,C] that must NOT overlap xh."""
+    lib = _lib.load()
+    _need_gpu(xh, packed_gates, cell, hidden_out)
+    B, H, W, Cin, ps = _nhwc_geom(xh)
+    _, _, _, C, hs = _nhwc_geom(hidden_out)
+    if cell.dtype != torch.float32 or not cell.is_contiguous() or cell.numel() != B * H * W * C:
+        raise ValueError("convlstm_fused: cell must be contiguous fp32 [B,H,W,C]")
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() != 4 * C):
+        raise ValueError("convlstm_fused: bias must be contiguous fp32 [4C]")
+    _lib.check(lib.oess_convlstm_fused_bf16(_ptr(xh), ps, B, H, W, Cin, _ptr(packed_gates), None if bias is None else _ptr(bias),
+                                            C, k, k, pad, None if prev_cell_is_zero else _ptr(cell), _ptr(cell),
+                                            _ptr(hidden_out), hs, _stream()), "oess_convlstm_fused_bf16")
     return hidden_out
 
 

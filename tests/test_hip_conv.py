@@ -122,3 +122,70 @@ def test_conv_wgrad_matches_autograd(case):
         xp = torch.cat([x, torch.zeros(B, H, W, 8, device="cuda", dtype=torch.bfloat16)], -1)
         dw2 = hip.conv2d_wgrad(xp, gy.permute(0, 2, 3, 1).contiguous(), Cout, Cin, R, R, stride, pad, dil)
         assert float((dw2 - ref).abs().max() / ref.abs().max()) < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Cx,C", [(2, 9, 11, 32, 32), (1, 13, 10, 64, 64), (3, 8, 8, 96, 32)])
+def test_convlstm_fused_step_matches_torch(B, H, W, Cx, C):
+    """oess_convlstm_fused_bf16 (Gates conv + cell update in one kernel, gate-interleaved weights, transposed MFMA)
+    against a plain fp32 restatement of ConvLSTM.forward (e2vid/model/submodules.py:199-214), three recurrent steps
+    with ping-pong cat(x, h) buffers; also against the unfused conv + gate-kernel pair."""
+    import torch
+    import torch.nn.functional as F
+    from openess_amd import hip
+    torch.manual_seed(B * 100 + C)
+    dev = "cuda"
+    w = torch.randn(4 * C, Cx + C, 3, 3, device=dev) * 0.05
+    bias = torch.randn(4 * C, device=dev) * 0.1
+    packed_f = hip.pack_conv_weight(w, flip=2)
+    packed_u = hip.pack_conv_weight(w)
+    wq = w.bfloat16().float()
+    xh = [torch.zeros(B, H, W, Cx + C, device=dev, dtype=torch.bfloat16) for _ in range(2)]
+    xh_u = torch.zeros(B, H, W, Cx + C, device=dev, dtype=torch.bfloat16)
+    cell = torch.empty(B, H, W, C, device=dev)
+    cell_u = torch.empty(B, H, W, C, device=dev)
+    h_ref = torch.zeros(B, C, H, W, device=dev)
+    c_ref = torch.zeros(B, C, H, W, device=dev)
+    cur = 0
+    for step in range(3):
+        x = torch.randn(B, H, W, Cx, device=dev).bfloat16()
+        xh[cur][..., :Cx] = x
+        xh_u[..., :Cx] = x
+        hip.convlstm_fused(xh[cur], packed_f, bias, cell, xh[1 - cur][..., Cx:], 3, 1, prev_cell_is_zero=(step == 0))
+        cur = 1 - cur
+        gates_u = hip.conv2d_nhwc(xh_u, packed_u, bias, 4 * C, 3, 3, 1, 1, 1)
+        hip.convlstm_gates(gates_u, cell_u, xh_u[..., Cx:], prev_cell_is_zero=(step == 0))
+        # reference: bf16-rounded operands (what the kernel multiplies), fp32 everywhere else
+        stacked = torch.cat([x.float().permute(0, 3, 1, 2), h_ref.bfloat16().float()], 1)
+        g = F.conv2d(stacked, wq, bias, padding=1)
+        gi, gr, go, gc = g.chunk(4, 1)
+        c_ref = torch.sigmoid(gr) * c_ref + torch.sigmoid(gi) * torch.tanh(gc)
+        h_ref = torch.sigmoid(go) * torch.tanh(c_ref)
+        h_hip = xh[cur][..., Cx:].float().permute(0, 3, 1, 2)
+        c_hip = cell.permute(0, 3, 1, 2)
+        # tolerance: h is stored in bf16 (2^-8 relative), c accumulates the bf16 rounding of h_prev over the steps
+        assert torch.allclose(c_hip, c_ref, atol=2e-2, rtol=2e-2), (step, float((c_hip - c_ref).abs().max()))
+        assert torch.allclose(h_hip, h_ref, atol=2e-2, rtol=2e-2), (step, float((h_hip - h_ref).abs().max()))
+        h_ref = h_hip.clone()          # both paths continue from the same (bf16) state: no drift in the comparison
+        assert torch.allclose(cell, cell_u, atol=3e-2, rtol=3e-2)
+        assert torch.allclose(xh[cur][..., Cx:].float(), xh_u[..., Cx:].float(), atol=3e-2, rtol=3e-2)
+
+
+@pytest.mark.gpu
+def test_convlstm_fused_rejects_aliasing_and_bad_shapes():
+    import torch
+    from openess_amd import hip
+    dev = "cuda"
+    C, Cx = 32, 32
+    w = torch.randn(4 * C, Cx + C, 3, 3, device=dev) * 0.05
+    packed = hip.pack_conv_weight(w, flip=2)
+    xh = torch.zeros(1, 8, 8, Cx + C, device=dev, dtype=torch.bfloat16)
+    cell = torch.zeros(1, 8, 8, C, device=dev)
+    with pytest.raises(RuntimeError):          # hidden output inside the conv input: neighbouring tiles would race
+        hip.convlstm_fused(xh, packed, None, cell, xh[..., Cx:], 3, 1)
+    C2 = 16                                       # hidden size not a multiple of 32
+    w2 = torch.randn(4 * C2, Cx + C2, 3, 3, device=dev) * 0.05
+    xh2 = torch.zeros(1, 8, 8, Cx + C2, device=dev, dtype=torch.bfloat16)
+    out2 = torch.zeros(1, 8, 8, C2, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        hip.convlstm_fused(xh2, hip.pack_conv_weight(w2, flip=2), None, torch.zeros(1, 8, 8, C2, device=dev), out2, 3, 1)
