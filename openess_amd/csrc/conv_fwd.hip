@@ -812,6 +812,92 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 #undef OESS_WAIT_FRAGS
 }
 
+// =================================================================================================
+// Small-Cin convolution (Cin == 8: one 16-byte chunk per pixel, e.g. the E2VID head on the 5-bin voxel grid padded
+// to 8 channels; stride 1, dilation 1, R*S <= 32 taps, Cout <= 32).
+// As an implicit GEMM this layer is an im2col blow-up: every output pixel pulls R*S x 16 B through L2 -> LDS (400 B for
+// 16 B of unique input at 5x5), and the generic kernel runs at the L2 gather rate.  Here a workgroup stages the input
+// HALO tile ((8+R-1) x (64+S-1) pixels x 16 B, ~13 KB) in LDS once and the MFMA B-operand (pixels) is read straight
+// out of it: lane p of k-step ks reads the chunk of pixel (ty + r, tx + s), (r, s) = tap ks*2 + (lane>>5).  Consecutive
+// lanes read consecutive 16-byte chunks: conflict free.  The whole packed weight (32 x 256 bf16) lives in 64 VGPRs.
+// The product is computed transposed (weights = MFMA A operand), so a lane owns 4 consecutive output channels of one
+// pixel per register quad and stores them as 8-byte pieces.
+// =================================================================================================
+template <int R, int S>
+__global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvArgs a) {
+    constexpr int TH = 8, TW = 64, HW_ = TW + S - 1, HH_ = TH + R - 1, NTAP = R * S, KS = 16;
+    __shared__ __attribute__((aligned(16))) u32x4_t halo[HH_ * HW_];
+    const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
+    int bid = blockIdx.x;
+    const int tx0 = (bid % tiles_x) * TW; bid /= tiles_x;
+    const int ty0 = (bid % tiles_y) * TH;
+    const int b = bid / tiles_y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 31, hi = lane >> 5;
+
+    // weights: lane (n = p, k-half = hi) keeps its 16 fragments for the whole kernel
+    bf16x8_t wf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        wf[ks] = *reinterpret_cast<const bf16x8_t*>(a.w + (size_t)p * a.Kpad + (ks * 2 + hi) * 8);
+
+    // halo tile, zero outside the image
+    const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+    for (int i = tid; i < HH_ * HW_; i += 256) {
+        const int hy = i / HW_, hx = i - hy * HW_;
+        const int iy = ty0 - a.pad + hy, ix = tx0 - a.pad + hx;
+        u32x4_t v = zero4;
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+            v = *reinterpret_cast<const u32x4_t*>(a.in + (((long long)b * a.H + iy) * a.W + ix) * a.in_pix_stride);
+        halo[i] = v;
+    }
+    __syncthreads();
+
+    // wave w: output rows 2w, 2w+1 of the tile, two 32-pixel halves each
+    f32x16_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        // tap of this lane's k-chunk; taps beyond R*S meet zero weights (any in-range address will do)
+        int tap = ks * 2 + hi;
+        tap = tap < NTAP ? tap : 0;
+        const int r = tap / S, sx = tap - r * S;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ty = wave * 2 + (t >> 1), tx = (t & 1) * 32 + p;
+            const u32x4_t q = halo[(ty + r) * HW_ + tx + sx];
+            bf16x8_t af;
+            __builtin_memcpy(&af, &q, 16);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], af, acc[t], 0, 0, 0);
+        }
+    }
+    // epilogue: lane (pixel p of the m-tile, hi) holds channels (e&3) + 8*(e>>2) + 4*hi
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int oy = ty0 + wave * 2 + (t >> 1), ox = tx0 + (t & 1) * 32 + p;
+        if (oy >= a.Ho || ox >= a.Wo) continue;
+        uint16_t* dst = a.out + (((long long)b * a.Ho + oy) * a.Wo + ox) * a.out_pix_stride;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ch = 8 * q + 4 * hi;
+            if (ch >= a.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k] = acc[t][q * 4 + k] + (a.bias ? a.bias[ch + k] : 0.0f);
+                if (a.relu) v[k] = fmaxf(v[k], 0.0f);
+            }
+            uint2 o;
+            o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+            o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            *reinterpret_cast<uint2*>(dst + ch) = o;
+        }
+    }
+}
+
 // ---- weight packing: OIHW fp32 (PyTorch Conv2d.weight) -> Wp[Npad][Kpad] bf16, k = (r, s, ci)
 // flip != 0 produces the data-gradient operator: Wp[ci][(R-1-r, S-1-s), co] (rotated, in/out swapped).
 __global__ void pack_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ wp, int Cout, int Cin, int R,
@@ -981,6 +1067,16 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
         case 4: OESS_LAUNCH_PERSIST(BN_) break;                                              \
         case 3: OESS_LAUNCH_DMA(BN_, 3) break;                                               \
         default: OESS_LAUNCH_V1(BN_) break;                                                  \
+    }
+    // Cin == 8 stencil layers (E2VID head): LDS halo tile instead of the im2col gather
+    static int smallcin = -1;
+    if (smallcin < 0) { const char* e = getenv("OESS_CONV_SMALLCIN"); smallcin = e ? atoi(e) : 1; }
+    if (smallcin && !lstm && Cin == 8 && stride == 1 && dil == 1 && R == 5 && S == 5 && Cout <= 32 && (Cout & 3) == 0 &&
+        !residual && !out_f32 && !tile_stats && (out_pix_stride & 3) == 0 && a.Kpad == 256) {
+        const int tiles = B * ((a.Ho + 7) / 8) * ((a.Wo + 63) / 64);
+        hipLaunchKernelGGL((conv_smallcin_kernel<5, 5>), dim3(tiles), dim3(256), 0, st, a);
+        OESS_HIP(hipGetLastError());
+        return OESS_OK;
     }
     if (lstm) {     // fused ConvLSTM cell update: transposed MFMA + lane-local gate algebra (needs the LDS-DMA kernel)
         if (use < 2) return OESS_EINVAL;

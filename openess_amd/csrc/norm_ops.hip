@@ -254,6 +254,53 @@ __global__ __launch_bounds__(THREADS) void bilinear_l2_kernel(const uint16_t* __
     }
 }
 
+// vectorised form for C/8 in {8, 16, 32, 64}: LPP = C/8 lanes own one output pixel, 16 bytes (8 channels) each;
+// the four corner reads and the store are whole 16-byte accesses, the channel norm is an LPP-lane butterfly.
+template <int LPP>
+__global__ __launch_bounds__(THREADS) void bilinear_l2_vec_kernel(const uint16_t* __restrict__ in, int64_t ips, int B, int H,
+                                                                  int W, int scale, int normalize,
+                                                                  uint16_t* __restrict__ out, int64_t ops) {
+    const int Ho = H * scale, Wo = W * scale;
+    const float ry = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float rx = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    constexpr int PPB = THREADS / LPP;             // output pixels per block iteration
+    const int sub = threadIdx.x % LPP, pl = threadIdx.x / LPP;
+    const int64_t total = (int64_t)B * Ho * Wo;
+    for (int64_t opix = (int64_t)blockIdx.x * PPB + pl; opix < total; opix += (int64_t)gridDim.x * PPB) {
+        const int ox = (int)(opix % Wo);
+        const int64_t t = opix / Wo;
+        const int oy = (int)(t % Ho);
+        const int64_t b = t / Ho;
+        const float fy = ry * oy, fx = rx * ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = (y0 < H - 1) ? y0 + 1 : y0, x1 = (x0 < W - 1) ? x0 + 1 : x0;
+        const float wy = fy - y0, wx = fx - x0;
+        union U { uint4 q; uint16_t h[8]; } a, bb, c, d, o;
+        a.q = *reinterpret_cast<const uint4*>(in + ((b * H + y0) * W + x0) * ips + sub * 8);
+        bb.q = *reinterpret_cast<const uint4*>(in + ((b * H + y0) * W + x1) * ips + sub * 8);
+        c.q = *reinterpret_cast<const uint4*>(in + ((b * H + y1) * W + x0) * ips + sub * 8);
+        d.q = *reinterpret_cast<const uint4*>(in + ((b * H + y1) * W + x1) * ips + sub * 8);
+        float v[8];
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float fa = bf16_to_f32(a.h[k]), fb = bf16_to_f32(bb.h[k]), fc = bf16_to_f32(c.h[k]), fd = bf16_to_f32(d.h[k]);
+            const float top = fa + (fb - fa) * wx, bot = fc + (fd - fc) * wx;
+            v[k] = top + (bot - top) * wy;
+            ss += v[k] * v[k];
+        }
+        float inv = 1.0f;
+        if (normalize) {
+#pragma unroll
+            for (int m = LPP / 2; m > 0; m >>= 1) ss += __shfl_xor(ss, m, 64);
+            inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o.h[k] = f32_to_bf16(v[k] * inv);
+        *reinterpret_cast<uint4*>(out + opix * ops + sub * 8) = o.q;
+    }
+}
+
 // reduce the conv epilogue's per-tile partials [tiles][2][C] -> sum[C], sumsq[C]   (sum / sumsq pre-zeroed)
 // block = 32 channels x 8 tile lanes; grid.y slices the tile range; one atomic per (block, channel).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int tiles, int C,
@@ -399,6 +446,20 @@ int oess_bilinear_l2norm_nhwc_bf16(const void* in, long long in_pix_stride, int 
                                    int normalize, void* out, long long out_pix_stride, oess_stream_t stream) {
     if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 63) || C > 512 || scale <= 0) return OESS_EINVAL;
     const int64_t total = (int64_t)B * H * scale * W * scale;
+    const int lpp = C / 8;
+    if ((lpp == 8 || lpp == 16 || lpp == 32 || lpp == 64) && (in_pix_stride & 7) == 0 && (out_pix_stride & 7) == 0 &&
+        ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0) {
+        int64_t gv = (total + THREADS / lpp - 1) / (THREADS / lpp);
+        if (gv > 65536) gv = 65536;
+#define OESS_BL(LPP_)                                                                                                  \
+        hipLaunchKernelGGL(bilinear_l2_vec_kernel<LPP_>, dim3((unsigned)gv), dim3(THREADS), 0, (hipStream_t)stream,    \
+                           (const uint16_t*)in, (int64_t)in_pix_stride, B, H, W, scale, normalize, (uint16_t*)out,      \
+                           (int64_t)out_pix_stride)
+        if (lpp == 8) OESS_BL(8); else if (lpp == 16) OESS_BL(16); else if (lpp == 32) OESS_BL(32); else OESS_BL(64);
+#undef OESS_BL
+        OESS_HIP(hipGetLastError());
+        return OESS_OK;
+    }
     int64_t g = (total + 3) / 4;
     if (g > 16384) g = 16384;
     hipLaunchKernelGGL(bilinear_l2_kernel, dim3((unsigned)g), dim3(THREADS), 0, (hipStream_t)stream, (const uint16_t*)in,

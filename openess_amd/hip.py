@@ -448,6 +448,25 @@ def conv2d_nhwc(x, packed, bias, Cout, R, S, stride=1, pad=0, dil=1, relu=False,
     return y
 
 
+_convlstm_fused_raw = convlstm_fused
+
+
+def convlstm_fused(xh, packed_gates, bias, cell, hidden_out, k, pad, prev_cell_is_zero=False):
+    t = _CONV_TIMING
+    if t is None:
+        return _convlstm_fused_raw(xh, packed_gates, bias, cell, hidden_out, k, pad, prev_cell_is_zero)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    y = _convlstm_fused_raw(xh, packed_gates, bias, cell, hidden_out, k, pad, prev_cell_is_zero)
+    e1.record()
+    Cout = 4 * hidden_out.shape[3]
+    fl = 2.0 * xh.shape[0] * xh.shape[1] * xh.shape[2] * Cout * xh.shape[3] * k * k     # the gate convolution's FLOPs only
+    t["events"].append((e0, e1))
+    t["flops"] += fl
+    t.setdefault("keys", []).append(((xh.shape[1], xh.shape[2], xh.shape[3], Cout, k, 1, "lstm"), fl))
+    return y
+
+
 # ------------------------------------------------------------------------------------------ norms / resampling
 def _norm_forward(x_nhwc, G, gamma, beta, eps, relu, residual, running=None, momentum=0.1, out=None):
     """Shared BatchNorm(train)/InstanceNorm forward on an NHWC bf16 view.  Returns (out, mean, rstd)."""

@@ -189,3 +189,24 @@ def test_convlstm_fused_rejects_aliasing_and_bad_shapes():
     out2 = torch.zeros(1, 8, 8, C2, device=dev, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError):
         hip.convlstm_fused(xh2, hip.pack_conv_weight(w2, flip=2), None, torch.zeros(1, 8, 8, C2, device=dev), out2, 3, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Cout,relu", [(2, 70, 130, 32, True), (1, 9, 65, 12, False), (3, 8, 64, 32, True)])
+def test_conv_small_cin_halo_kernel(B, H, W, Cout, relu):
+    """Cin = 8, 5x5, stride 1 (E2VID head): the LDS halo-tile kernel (conv_smallcin_kernel), several tiles with ragged
+    edges, bias + ReLU in bf16, output written into a channel slice of a wider buffer."""
+    from openess_amd import hip
+    torch.manual_seed(H * W + Cout)
+    x = torch.randn(B, H, W, 8, device="cuda").bfloat16()
+    x[..., 5:] = 0                                   # 5 event bins padded to 8 channels
+    w = torch.randn(Cout, 8, 5, 5, device="cuda") / np.sqrt(5 * 25)
+    b = torch.randn(Cout, device="cuda")
+    packed = hip.pack_conv_weight(w)
+    wide = torch.full((B, H, W, Cout + 16), 7.0, device="cuda", dtype=torch.bfloat16)
+    y = hip.conv2d_nhwc(x, packed, b, Cout, 5, 5, 1, 2, 1, relu=relu, out=wide[..., 8:8 + Cout])
+    ref = ref_conv(x, w, b, 1, 2, 1)
+    if relu:
+        ref = ref.clamp_min(0)
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=1e-2)
+    assert float((wide[..., :8].float() - 7).abs().max()) == 0 and float((wide[..., 8 + Cout:].float() - 7).abs().max()) == 0

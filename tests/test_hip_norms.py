@@ -74,10 +74,11 @@ def test_upsample_concat_fwd_bwd():
     np.testing.assert_allclose(x.grad.float().cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-2, atol=1e-2)
 
 
-def test_bilinear_l2norm():
+@pytest.mark.parametrize("C", [64, 128, 256, 512, 192])     # 192: scalar fallback (C/8 lanes is not a power of two)
+def test_bilinear_l2norm(C):
     from openess_amd import hip
     torch.manual_seed(4)
-    x = cl(torch.randn(2, 256, 11, 16, device="cuda"))
+    x = cl(torch.randn(2, C, 11, 16, device="cuda"))
     y = hip.bilinear_l2norm(x, 4, True)
     ref = F.normalize(F.interpolate(x.float(), scale_factor=4, mode="bilinear", align_corners=True), p=2, dim=1)
     np.testing.assert_allclose(y.float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=2e-3)

@@ -1,0 +1,20 @@
+"""What does the vendor GEMM (hipBLASLt via torch.mm) reach on the conv-equivalent GEMM shapes with random data?
+A practical ceiling for the implicit-GEMM kernel (same M, N, K; no im2col gather, no epilogue fusion)."""
+import torch
+shapes = {"lstm1": (563200, 256, 1152), "lstm2": (140800, 512, 2304), "lstm3": (35200, 1024, 4608),
+          "pw 256->1024": (140800, 1024, 256), "big square": (8192, 8192, 8192)}
+for name, (M, N, K) in shapes.items():
+    for mode in ("randn", "zeros"):
+        a = torch.randn(M, K, device="cuda").bfloat16()
+        b = torch.randn(N, K, device="cuda").bfloat16()
+        if mode == "zeros":
+            a.zero_(); b.zero_()
+        for _ in range(5):
+            c = a @ b.t()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            c = a @ b.t()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 50
+        print(f"{name:14s} {mode:6s} M={M} N={N} K={K}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.0f} TF/s", flush=True)
