@@ -137,6 +137,24 @@ int oess_task_loss_bwd(const void* logits, int is_bf16, const int64_t* target, i
                        void* grad_logits, int grad_is_bf16, oess_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * a16 Consistency losses of the joint OpenESS stage (training/openess_trainer.py:497-503):
+ *   oess_l1_mean_*      cons_feat_loss = nn.L1Loss()(feat_a, feat_b)  (mean |a - b| over n elements, same memory order)
+ *   oess_cosine_mean_*  cons_pred_loss = mean(1 - F.cosine_similarity(logits_a, logits_b, dim=1)) over P pixels x C
+ *                       channels, NHWC with pixel strides in elements, eps = 1e-8 per-norm clamp (torch 2.x formula).
+ * Operands bf16 (is_bf16 != 0) or fp32; gradients are written in the operand dtype (either may be null).
+ * partials: scratch of oess_loss_partials_bytes() bytes (deterministic two-stage sum); loss / grad_out: device scalars.
+ * ------------------------------------------------------------------------------------------ */
+size_t oess_loss_partials_bytes(void);
+int oess_l1_mean_fwd(const void* a, const void* b, int64_t n, int is_bf16, void* partials, float* loss, oess_stream_t stream);
+int oess_l1_mean_bwd(const void* a, const void* b, int64_t n, int is_bf16, const float* grad_out, void* grad_a, void* grad_b,
+                     oess_stream_t stream);
+int oess_cosine_mean_fwd(const void* a, long long a_pix_stride, const void* b, long long b_pix_stride, int64_t P, int C,
+                         int is_bf16, float eps, void* partials, float* loss, oess_stream_t stream);
+int oess_cosine_mean_bwd(const void* a, long long a_pix_stride, const void* b, long long b_pix_stride, int64_t P, int C,
+                         int is_bf16, float eps, const float* grad_out, void* grad_a, long long ga_pix_stride, void* grad_b,
+                         long long gb_pix_stride, oess_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * K11 Confusion matrix (evaluation/metrics.py:4-23): conf[gt*K + pred] += 1 over gt != ignore.
  * conf: K*K int64, ACCUMULATED into (caller zeroes once per validation epoch).
  * ------------------------------------------------------------------------------------------ */

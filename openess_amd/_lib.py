@@ -44,6 +44,11 @@ SIGNATURES = {
     "oess_convlstm_gates_bf16": (c_int, [c_vp, c_ll, c_vp, c_vp, c_vp, c_ll, c_ll, c_int, c_vp]),
     "oess_convlstm_fused_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp,
                                          c_vp, c_vp, c_ll, c_vp]),
+    "oess_loss_partials_bytes": (c_sz, []),
+    "oess_l1_mean_fwd": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
+    "oess_l1_mean_bwd": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "oess_cosine_mean_fwd": (c_int, [c_vp, c_ll, c_vp, c_ll, c_i64, c_int, c_int, c_f, c_vp, c_vp, c_vp]),
+    "oess_cosine_mean_bwd": (c_int, [c_vp, c_ll, c_vp, c_ll, c_i64, c_int, c_int, c_f, c_vp, c_vp, c_ll, c_vp, c_ll, c_vp]),
     "oess_masked_stats_slice_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp]),
     "oess_event_slice_to_nhwc8_bf16": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_ll, c_vp, c_int, c_vp, c_vp]),
     "oess_norm_stats_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_ll, c_int, c_vp, c_vp, c_vp]),

@@ -1,0 +1,184 @@
+// a16 consistency losses (training/openess_trainer.py:497-503), HBM-bound, deterministic two-stage reductions:
+//   cons_feat_loss = L1Loss(feat_a, feat_b)                       = mean |a - b|
+//   cons_pred_loss = mean(1 - cosine_similarity(la, lb, dim=1))   , cos = sum_c (a / max(|a|, eps)) (b / max(|b|, eps))
+// (the per-tensor norm clamp is torch >= 1.12's formula, the one the reference's pinned torch 2.1 runs).
+// Operands are NHWC (channels contiguous, explicit pixel stride), bf16 or fp32; gradients keep the operand dtype.
+// Algorithmic bytes: forward 2 reads, backward 2 reads + 2 writes of the operands.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "oess.h"
+#include "oess_common.h"
+
+namespace {
+using namespace oess;
+constexpr int THREADS = 256;
+constexpr int MAX_PARTIALS = 1024;
+
+template <bool BF16>
+__device__ __forceinline__ float ld(const void* p, int64_t i) {
+    if constexpr (BF16) return bf16_to_f32(reinterpret_cast<const uint16_t*>(p)[i]);
+    else return reinterpret_cast<const float*>(p)[i];
+}
+template <bool BF16>
+__device__ __forceinline__ void st(void* p, int64_t i, float v) {
+    if constexpr (BF16) reinterpret_cast<uint16_t*>(p)[i] = f32_to_bf16(v);
+    else reinterpret_cast<float*>(p)[i] = v;
+}
+
+__device__ __forceinline__ void block_partial(double v, double* partials) {
+    __shared__ double red[THREADS / 64];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < THREADS / 64; ++w) s += red[w];
+        partials[blockIdx.x] = s;
+    }
+}
+
+// second stage: one block sums the partials in a fixed order -> loss = offset + scale * sum
+__global__ __launch_bounds__(THREADS) void finish_kernel(const double* __restrict__ partials, int n, double offset, double scale,
+                                                         float* __restrict__ loss) {
+    __shared__ double red[THREADS];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += THREADS) s += partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = THREADS / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (float)(offset + scale * red[0]);
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(THREADS) void l1_fwd_kernel(const void* __restrict__ a, const void* __restrict__ b, int64_t n,
+                                                         double* __restrict__ partials) {
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS)
+        s += (double)fabsf(ld<BF16>(a, i) - ld<BF16>(b, i));
+    block_partial(s, partials);
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(THREADS) void l1_bwd_kernel(const void* __restrict__ a, const void* __restrict__ b, int64_t n,
+                                                         const float* __restrict__ gout, float inv_n, void* __restrict__ ga,
+                                                         void* __restrict__ gb) {
+    const float g = gout[0] * inv_n;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS) {
+        const float d = ld<BF16>(a, i) - ld<BF16>(b, i);
+        const float s = d > 0.f ? g : (d < 0.f ? -g : 0.f);          // sign(0) = 0 like torch
+        if (ga) st<BF16>(ga, i, s);
+        if (gb) st<BF16>(gb, i, -s);
+    }
+}
+
+// one wave per pixel, lanes stride over channels; accumulates sum over pixels of cos
+template <bool BF16>
+__global__ __launch_bounds__(THREADS) void cos_fwd_kernel(const void* __restrict__ a, int64_t as, const void* __restrict__ b,
+                                                          int64_t bs, int64_t P, int C, float eps, double* __restrict__ partials) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double acc = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * (THREADS / 64) + wave; p < P; p += (int64_t)gridDim.x * (THREADS / 64)) {
+        float ab = 0.f, aa = 0.f, bb = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float x = ld<BF16>(a, p * as + c), y = ld<BF16>(b, p * bs + c);
+            ab += x * y; aa += x * x; bb += y * y;
+        }
+        ab = wave_sum(ab); aa = wave_sum(aa); bb = wave_sum(bb);
+        if (lane == 0) acc += (double)(ab / (fmaxf(sqrtf(aa), eps) * fmaxf(sqrtf(bb), eps)));
+    }
+    block_partial(acc, partials);        // lanes other than 0 contribute 0
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(THREADS) void cos_bwd_kernel(const void* __restrict__ a, int64_t as, const void* __restrict__ b,
+                                                          int64_t bs, int64_t P, int C, float eps, const float* __restrict__ gout,
+                                                          float inv_p, void* __restrict__ ga, int64_t gas, void* __restrict__ gb,
+                                                          int64_t gbs) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float g = -gout[0] * inv_p;                    // d loss / d cos
+    for (int64_t p = (int64_t)blockIdx.x * (THREADS / 64) + wave; p < P; p += (int64_t)gridDim.x * (THREADS / 64)) {
+        float ab = 0.f, aa = 0.f, bb = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float x = ld<BF16>(a, p * as + c), y = ld<BF16>(b, p * bs + c);
+            ab += x * y; aa += x * x; bb += y * y;
+        }
+        ab = wave_sum(ab); aa = wave_sum(aa); bb = wave_sum(bb);
+        const float na = sqrtf(aa), nb = sqrtf(bb);
+        const float ca = fmaxf(na, eps), cb = fmaxf(nb, eps);
+        const float inv = 1.0f / (ca * cb), cosv = ab * inv;
+        // d cos / dx = y / (ca cb) - cos * x / (ca * |x|) while the norm is above eps (the clamp has zero gradient below)
+        const float ka = na > eps ? cosv / (ca * na) : 0.f, kb = nb > eps ? cosv / (cb * nb) : 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float x = ld<BF16>(a, p * as + c), y = ld<BF16>(b, p * bs + c);
+            if (ga) st<BF16>(ga, p * gas + c, g * (y * inv - ka * x));
+            if (gb) st<BF16>(gb, p * gbs + c, g * (x * inv - kb * y));
+        }
+    }
+}
+
+int grid_of(int64_t work_items, int per_block) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > MAX_PARTIALS) g = MAX_PARTIALS;
+    return (int)g;
+}
+}  // namespace
+
+extern "C" {
+
+size_t oess_loss_partials_bytes(void) { return MAX_PARTIALS * sizeof(double); }
+
+int oess_l1_mean_fwd(const void* a, const void* b, int64_t n, int is_bf16, void* partials, float* loss, oess_stream_t stream) {
+    if (!a || !b || !partials || !loss || n <= 0) return OESS_EINVAL;
+    const int grid = grid_of(n, THREADS * 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (is_bf16) hipLaunchKernelGGL(l1_fwd_kernel<true>, dim3(grid), dim3(THREADS), 0, st, a, b, n, (double*)partials);
+    else hipLaunchKernelGGL(l1_fwd_kernel<false>, dim3(grid), dim3(THREADS), 0, st, a, b, n, (double*)partials);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(THREADS), 0, st, (const double*)partials, grid, 0.0, 1.0 / (double)n, loss);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_l1_mean_bwd(const void* a, const void* b, int64_t n, int is_bf16, const float* grad_out, void* grad_a, void* grad_b,
+                     oess_stream_t stream) {
+    if (!a || !b || !grad_out || (!grad_a && !grad_b) || n <= 0) return OESS_EINVAL;
+    int64_t g = (n + THREADS * 4 - 1) / (THREADS * 4);
+    if (g > 65536) g = 65536;
+    hipStream_t st = (hipStream_t)stream;
+    const float inv_n = (float)(1.0 / (double)n);
+    if (is_bf16) hipLaunchKernelGGL(l1_bwd_kernel<true>, dim3((unsigned)g), dim3(THREADS), 0, st, a, b, n, grad_out, inv_n, grad_a, grad_b);
+    else hipLaunchKernelGGL(l1_bwd_kernel<false>, dim3((unsigned)g), dim3(THREADS), 0, st, a, b, n, grad_out, inv_n, grad_a, grad_b);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_cosine_mean_fwd(const void* a, long long a_pix_stride, const void* b, long long b_pix_stride, int64_t P, int C,
+                         int is_bf16, float eps, void* partials, float* loss, oess_stream_t stream) {
+    if (!a || !b || !partials || !loss || P <= 0 || C <= 0 || a_pix_stride < C || b_pix_stride < C) return OESS_EINVAL;
+    const int grid = grid_of(P, (THREADS / 64) * 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (is_bf16) hipLaunchKernelGGL(cos_fwd_kernel<true>, dim3(grid), dim3(THREADS), 0, st, a, (int64_t)a_pix_stride, b, (int64_t)b_pix_stride, P, C, eps, (double*)partials);
+    else hipLaunchKernelGGL(cos_fwd_kernel<false>, dim3(grid), dim3(THREADS), 0, st, a, (int64_t)a_pix_stride, b, (int64_t)b_pix_stride, P, C, eps, (double*)partials);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(THREADS), 0, st, (const double*)partials, grid, 1.0, -1.0 / (double)P, loss);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_cosine_mean_bwd(const void* a, long long a_pix_stride, const void* b, long long b_pix_stride, int64_t P, int C,
+                         int is_bf16, float eps, const float* grad_out, void* grad_a, long long ga_pix_stride, void* grad_b,
+                         long long gb_pix_stride, oess_stream_t stream) {
+    if (!a || !b || !grad_out || (!grad_a && !grad_b) || P <= 0 || C <= 0 || a_pix_stride < C || b_pix_stride < C) return OESS_EINVAL;
+    int64_t g = (P + (THREADS / 64) * 4 - 1) / ((THREADS / 64) * 4);
+    if (g > 65536) g = 65536;
+    hipStream_t st = (hipStream_t)stream;
+    const float inv_p = (float)(1.0 / (double)P);
+    if (is_bf16) hipLaunchKernelGGL(cos_bwd_kernel<true>, dim3((unsigned)g), dim3(THREADS), 0, st, a, (int64_t)a_pix_stride, b, (int64_t)b_pix_stride, P, C, eps, grad_out, inv_p, grad_a, (int64_t)ga_pix_stride, grad_b, (int64_t)gb_pix_stride);
+    else hipLaunchKernelGGL(cos_bwd_kernel<false>, dim3((unsigned)g), dim3(THREADS), 0, st, a, (int64_t)a_pix_stride, b, (int64_t)b_pix_stride, P, C, eps, grad_out, inv_p, grad_a, (int64_t)ga_pix_stride, grad_b, (int64_t)gb_pix_stride);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+}  // extern "C"

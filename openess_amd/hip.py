@@ -272,6 +272,91 @@ def task_loss(logits, target, num_classes, ignore_index=255, losses=("dice", "cr
     return _TaskLoss.apply(logits, target, K, int(ignore_index), flags, strides)
 
 
+# ------------------------------------------------------------------------------------------ a16 consistency losses
+def _loss_scratch(device):
+    lib = _lib.load()
+    return torch.empty(lib.oess_loss_partials_bytes() // 8, dtype=torch.float64, device=device)
+
+
+class _L1Mean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = _lib.load()
+        loss = torch.empty(1, dtype=torch.float32, device=a.device)
+        _lib.check(lib.oess_l1_mean_fwd(_ptr(a), _ptr(b), a.numel(), int(a.dtype == torch.bfloat16), _ptr(_loss_scratch(a.device)),
+                                        _ptr(loss), _stream()), "oess_l1_mean_fwd")
+        ctx.save_for_backward(a, b)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        a, b = ctx.saved_tensors
+        ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        gdev = g.reshape(1).float().contiguous()
+        _lib.check(lib.oess_l1_mean_bwd(_ptr(a), _ptr(b), a.numel(), int(a.dtype == torch.bfloat16), _ptr(gdev),
+                                        None if ga is None else _ptr(ga), None if gb is None else _ptr(gb), _stream()),
+                   "oess_l1_mean_bwd")
+        return ga, gb
+
+
+def l1_mean(a, b):
+    """nn.L1Loss()(a, b) (training/openess_trainer.py:497).  a, b: same shape, dtype (fp32 / bf16) and memory layout."""
+    _need_gpu(a, b)
+    if a.shape != b.shape or a.dtype != b.dtype or a.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("l1_mean: operands must share shape and dtype (float32 or bfloat16)")
+    if a.stride() != b.stride() or not (a.is_contiguous() or a.is_contiguous(memory_format=torch.channels_last)):
+        a, b = a.contiguous(), b.contiguous()
+    return _L1Mean.apply(a, b)
+
+
+class _CosMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, eps):
+        lib = _lib.load()
+        (B, H, W, C), sa, sb = a.shape, a.stride(2), b.stride(2)
+        loss = torch.empty(1, dtype=torch.float32, device=a.device)
+        _lib.check(lib.oess_cosine_mean_fwd(_ptr(a), sa, _ptr(b), sb, B * H * W, C, int(a.dtype == torch.bfloat16), eps,
+                                            _ptr(_loss_scratch(a.device)), _ptr(loss), _stream()), "oess_cosine_mean_fwd")
+        ctx.save_for_backward(a, b)
+        ctx.eps = eps
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        a, b = ctx.saved_tensors
+        (B, H, W, C), sa, sb = a.shape, a.stride(2), b.stride(2)
+        ga = torch.empty((B, H, W, C), dtype=a.dtype, device=a.device) if ctx.needs_input_grad[0] else None
+        gb = torch.empty((B, H, W, C), dtype=b.dtype, device=b.device) if ctx.needs_input_grad[1] else None
+        gdev = g.reshape(1).float().contiguous()
+        _lib.check(lib.oess_cosine_mean_bwd(_ptr(a), sa, _ptr(b), sb, B * H * W, C, int(a.dtype == torch.bfloat16), ctx.eps,
+                                            _ptr(gdev), None if ga is None else _ptr(ga), C, None if gb is None else _ptr(gb), C,
+                                            _stream()), "oess_cosine_mean_bwd")
+        return ga, gb, None
+
+
+def cosine_mean_loss(a, b, eps=1e-8):
+    """mean(1 - F.cosine_similarity(a, b, dim=1)) (training/openess_trainer.py:501) for logical B x C x H x W tensors;
+    computed on NHWC views (a channels_last input is used in place, an NCHW one is re-laid out once)."""
+    _need_gpu(a, b)
+    if a.shape != b.shape or a.dtype != b.dtype or a.dtype not in (torch.float32, torch.bfloat16) or a.ndim != 4:
+        raise ValueError("cosine_mean_loss: operands must be 4-D with the same shape and dtype (float32 or bfloat16)")
+    an, bn = a.permute(0, 2, 3, 1), b.permute(0, 2, 3, 1)
+    if an.stride(3) != 1 or not _uniform_pix_stride(an):
+        an = an.contiguous()
+    if bn.stride(3) != 1 or not _uniform_pix_stride(bn):
+        bn = bn.contiguous()
+    return _CosMean.apply(an, bn, float(eps))
+
+
+def _uniform_pix_stride(x):
+    B, H, W, C = x.shape
+    ps = x.stride(2)
+    return x.stride(1) == W * ps and (B == 1 or x.stride(0) == H * W * ps) and ps >= C
+
+
 # ------------------------------------------------------------------------------------------ K11
 def confusion_accumulate(pred, label, num_classes, ignore_label, conf):
     lib = _lib.load()

@@ -50,10 +50,10 @@ class OpenESSModel(BaseTrainer):
         l = self.task_loss(logits_recon, pl) * s.weight_task_loss
         losses['semseg_recon_loss'] = l.detach()
         t_loss = t_loss + l
-        l = self.l1_loss(feat_frame.float(), feat_recon.float())
+        l = hip.l1_mean(feat_frame, feat_recon)                              # nn.L1Loss (:497)
         losses['cons_feat_loss'] = l.detach()
         t_loss = t_loss + l
-        l = torch.mean(1 - f.cosine_similarity(logits_frame, logits_recon, dim=1))
+        l = hip.cosine_mean_loss(logits_frame, logits_recon)                 # mean(1 - cosine_similarity) (:501)
         losses['cons_pred_loss'] = l.detach()
         t_loss = t_loss + l
         if getattr(s, 'if_spatial_contrastive', False):

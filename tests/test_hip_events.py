@@ -192,3 +192,30 @@ def test_histogram_and_normalize(golden_events):
     x = torch.randn(2, 10, 6, 8, device="cuda") * (torch.rand(2, 10, 6, 8, device="cuda") > 0.6)
     a = hip.masked_normalize_slice(x, 5, 5).cpu().numpy()
     np.testing.assert_allclose(a, oe.masked_normalize(x[:, 5:10].cpu().numpy()), rtol=2e-5, atol=2e-6)
+
+
+def test_e2vid_voxel_grid_golden(golden_events):
+    """a6: e2vid events_to_voxel_grid (inference_utils.py:405-449) and its torch variant (:452-515) on the HIP
+    nearest voxelizer vs the reference golden and the oracle; the caller's array must stay untouched."""
+    from openess_amd.e2vid.utils import inference_utils as iu
+    g = golden_events
+    H, W = (int(v) for v in g["near_hw"])
+    ev = np.array(g["e2v_ev"], dtype=np.float64, copy=True)
+    keep = ev.copy()
+    out = iu.events_to_voxel_grid(ev, 5, W, H)
+    assert out.dtype == np.float32 and out.shape == (5, H, W)
+    np.testing.assert_allclose(out, g["e2v_out"], rtol=0, atol=ATOL)
+    assert np.array_equal(ev, keep)
+    out_t = iu.events_to_voxel_grid_pytorch(ev, 5, W, H, torch.device("cuda"))
+    assert out_t.is_cuda
+    np.testing.assert_allclose(out_t.cpu().numpy(), g["e2v_out"], rtol=0, atol=ATOL)
+    # single timestamp (deltaT == 0 -> 1.0) and a larger random set against the oracle
+    rng = np.random.default_rng(77)
+    n = 20000
+    ev2 = np.stack([np.sort(rng.integers(0, 50000, n)).astype(np.float64), rng.integers(0, W, n).astype(np.float64),
+                    rng.integers(0, H, n).astype(np.float64), rng.integers(0, 2, n).astype(np.float64)], 1)
+    np.testing.assert_allclose(iu.events_to_voxel_grid(ev2, 5, W, H), oe.e2vid_voxel_grid(ev2, 5, W, H), rtol=0, atol=ATOL)
+    ev3 = ev2[:100].copy(); ev3[:, 0] = 1234.0
+    np.testing.assert_allclose(iu.events_to_voxel_grid(ev3, 5, W, H), oe.e2vid_voxel_grid(ev3, 5, W, H), rtol=0, atol=ATOL)
+    with pytest.raises(RuntimeError):
+        iu.events_to_voxel_grid_pytorch(ev, 5, W, H, torch.device("cpu"))

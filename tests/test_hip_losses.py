@@ -104,3 +104,49 @@ def test_confusion_matrix(golden_losses):
     conf.zero_()
     hip.confusion_accumulate(pred, gt, 11, 255, conf)
     assert np.array_equal(conf.view(11, 11).cpu().numpy(), ol.confusion_matrix(pred.cpu().numpy(), gt.cpu().numpy(), 11))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["feat", "logit"])
+@pytest.mark.parametrize("layout", ["nchw", "channels_last"])
+def test_consistency_losses_golden(tag, layout):
+    """a16 (openess_trainer.py:497-503): HIP L1-mean and cosine-mean losses + input gradients vs the golden torch
+    values (fp32: 1e-6 relative on the loss, 1e-6 absolute on the gradients = summation order only), and bf16 operands
+    against the same formulas evaluated on the bf16-rounded inputs."""
+    import os
+    import torch
+    import torch.nn.functional as F
+    from openess_amd import hip
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "consistency.npz"))
+
+    def prep(x, dtype=torch.float32):
+        t = torch.from_numpy(x).cuda().to(dtype)
+        if layout == "channels_last":
+            t = t.contiguous(memory_format=torch.channels_last)
+        return t.requires_grad_(True)
+
+    a, b = prep(g[f"{tag}_a"]), prep(g[f"{tag}_b"])
+    l1 = hip.l1_mean(a, b)
+    ga, gb = torch.autograd.grad(l1, (a, b))
+    np.testing.assert_allclose(l1.item(), g[f"{tag}_l1"], rtol=1e-6)
+    np.testing.assert_allclose(ga.cpu().numpy(), g[f"{tag}_l1_ga"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(gb.cpu().numpy(), g[f"{tag}_l1_gb"], rtol=0, atol=1e-8)
+    lc = hip.cosine_mean_loss(a, b)
+    ga, gb = torch.autograd.grad(lc, (a, b))
+    np.testing.assert_allclose(lc.item(), g[f"{tag}_cos"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(ga.cpu().numpy(), g[f"{tag}_cos_ga"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(gb.cpu().numpy(), g[f"{tag}_cos_gb"], rtol=1e-4, atol=1e-7)
+    # bf16 operands
+    a16, b16 = prep(g[f"{tag}_a"], torch.bfloat16), prep(g[f"{tag}_b"], torch.bfloat16)
+    ar, br = a16.detach().float().requires_grad_(True), b16.detach().float().requires_grad_(True)
+    ref1 = F.l1_loss(ar, br)
+    refc = torch.mean(1 - F.cosine_similarity(ar, br, dim=1))
+    rga, rgb = torch.autograd.grad(refc, (ar, br))
+    l1 = hip.l1_mean(a16, b16)
+    lc = hip.cosine_mean_loss(a16, b16)
+    ga, gb = torch.autograd.grad(lc, (a16, b16))
+    np.testing.assert_allclose(l1.item(), ref1.item(), rtol=1e-5)
+    np.testing.assert_allclose(lc.item(), refc.item(), rtol=1e-5, atol=1e-6)
+    assert ga.dtype == torch.bfloat16
+    np.testing.assert_allclose(ga.float().cpu().numpy(), rga.cpu().numpy(), rtol=1e-2, atol=1e-6)
+    np.testing.assert_allclose(gb.float().cpu().numpy(), rgb.cpu().numpy(), rtol=1e-2, atol=1e-6)

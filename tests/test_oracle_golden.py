@@ -147,3 +147,16 @@ def test_c_port_dsec_sample_matches_numpy_oracle():
     np.testing.assert_allclose(a, b, rtol=0, atol=2e-6)
     assert np.array_equal(cport.dsec_event_tensor(x, y, t, p, rm, nwin, C, H, W, crop, True),
                           oe.dsec_event_tensor(x, y, t, p, rm, nwin, C, H, W, crop, count_mode=True))
+
+
+def test_consistency_losses_golden():
+    """a16: oracle restatement vs the torch calls the reference makes (tests/golden/gen_golden_consistency.py)."""
+    import os
+    import torch
+    from oracle import losses as ol
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "consistency.npz"))
+    for tag in ("feat", "logit"):
+        a, b = torch.from_numpy(g[f"{tag}_a"]), torch.from_numpy(g[f"{tag}_b"])
+        l1, lc = ol.consistency_losses(a, b, a, b)
+        np.testing.assert_allclose(l1.numpy(), g[f"{tag}_l1"], rtol=1e-6)
+        np.testing.assert_allclose(lc.numpy(), g[f"{tag}_cos"], rtol=1e-6, atol=1e-7)
