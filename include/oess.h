@@ -239,10 +239,36 @@ int oess_instnorm_bwd_nhwc_bf16(const void* x, long long x_pix_stride, const voi
                                 float* s1, float* s2, void* dx, long long dx_pix_stride, oess_stream_t stream);
 int oess_upsample_nearest2x_nhwc_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int C, void* out,
                                       long long out_pix_stride, oess_stream_t stream);
+/* z[b, s*y, s*x, :] = in[b, y, x, :], zero elsewhere on an Hz x Wz grid: turns the data gradient of a stride-s convolution
+ * into the stride-1 product dX = conv(z, oess_conv2d_pack_weight(flip_for_dgrad = 1), pad = dil*(R-1) - pad) with
+ * Hz = H_in - dil*(R-1) + 2*pad (replaces aten::convolution_backward for the stride-2 3x3 / 1x1 convolutions of
+ * models/_resnet.py:74-114; MIOpen resolved those to a naive 9.4 ms kernel on gfx950). */
+int oess_zero_insert_nhwc_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int C, int stride, int Hz, int Wz,
+                               void* out, long long out_pix_stride, oess_stream_t stream);
 int oess_downsample_sum2x_nhwc_bf16(const void* gout, long long gout_pix_stride, int B, int H, int W, int C, void* gin,
                                     long long gin_pix_stride, oess_stream_t stream);
 int oess_bilinear_l2norm_nhwc_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int C, int scale,
                                    int normalize, void* out, long long out_pix_stride, oess_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Bilinear resampling (any size, both align_corners modes) and channel L2 normalisation, forward + adjoint.
+ * Replace F.interpolate(size=input_shape, mode='bilinear', align_corners=False) on DeepLabv3's logits and features
+ * (models/deeplabv3.py:179-189) and nn.Upsample(x4, bilinear, align_corners=True) + F.normalize(p=2, dim=1) of the
+ * teacher (models/image_model.py:121-143) including their autograd backward.  NHWC, pixel strides in elements,
+ * bf16 (is_bf16 != 0) or fp32 (same dtype in and out).  The backward is a two-pass deterministic gather; workspace =
+ * oess_resize_bilinear_bwd_workspace_bytes(B, W, C, Ho) bytes (fp32 [B, Ho, W, C]).
+ * inv_norm: fp32 [P] = 1 / max(|x|, eps) per pixel, written by the forward (nullable) and read by the backward.
+ * ------------------------------------------------------------------------------------------ */
+int oess_resize_bilinear_nhwc_fwd(const void* in, long long in_pix_stride, int B, int H, int W, int C, int is_bf16, int Ho, int Wo,
+                                  int align_corners, void* out, long long out_pix_stride, oess_stream_t stream);
+size_t oess_resize_bilinear_bwd_workspace_bytes(int B, int W, int C, int Ho);
+int oess_resize_bilinear_nhwc_bwd(const void* grad_out, long long gout_pix_stride, int B, int H, int W, int C, int is_bf16, int Ho,
+                                  int Wo, int align_corners, void* workspace, size_t workspace_bytes, void* grad_in,
+                                  long long gin_pix_stride, oess_stream_t stream);
+int oess_l2norm_nhwc_fwd(const void* x, long long x_pix_stride, int64_t P, int C, int is_bf16, float eps, void* y,
+                         long long y_pix_stride, float* inv_norm, oess_stream_t stream);
+int oess_l2norm_nhwc_bwd(const void* y, long long y_pix_stride, const void* grad_y, long long gy_pix_stride, const float* inv_norm,
+                         int64_t P, int C, int is_bf16, float eps, void* grad_x, long long gx_pix_stride, oess_stream_t stream);
 
 /* Weight gradient of oess_conv2d_fwd_bf16's convolution: dW (OIHW fp32, ACCUMULATED into: zero it first)
  * from x (NHWC bf16, Cin_x >= Cin channels present, Cin_x % 8 == 0) and dy (NHWC bf16, Cout % 8 == 0).

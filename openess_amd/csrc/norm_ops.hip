@@ -181,6 +181,26 @@ __global__ __launch_bounds__(THREADS) void up2_kernel(const uint16_t* __restrict
     }
 }
 
+// zero insertion (the "dilate" half of a strided convolution's data gradient): z[b, s*y, s*x, :] = in[b, y, x, :],
+// every other pixel of the Hz x Wz grid is zero.  dX of a stride-s conv = stride-1 conv of z with the rotated weights.
+__global__ __launch_bounds__(THREADS) void zero_insert_kernel(const uint16_t* __restrict__ in, int64_t ips, int B, int H, int W,
+                                                              int C, int s, int Hz, int Wz, uint16_t* __restrict__ out, int64_t ops) {
+    const int cl = C >> 3;
+    const int64_t total = (int64_t)B * Hz * Wz * cl;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * THREADS) {
+        const int64_t opix = i / cl;
+        const int c0 = (int)(i - opix * cl) * 8;
+        const int ox = (int)(opix % Wz);
+        const int64_t t = opix / Wz;
+        const int oy = (int)(t % Hz);
+        const int64_t b = t / Hz;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        const int iy = oy / s, ix = ox / s;
+        if (iy * s == oy && ix * s == ox && iy < H && ix < W) v = *reinterpret_cast<const uint4*>(in + ((b * H + iy) * W + ix) * ips + c0);
+        *reinterpret_cast<uint4*>(out + opix * ops + c0) = v;
+    }
+}
+
 // adjoint: gin[b, y, x, :] = sum of the 2x2 block of gout
 __global__ __launch_bounds__(THREADS) void down2_sum_kernel(const uint16_t* __restrict__ gout, int64_t gps, int B, int H, int W,
                                                             int C, uint16_t* __restrict__ gin, int64_t ips) {
@@ -428,6 +448,17 @@ int oess_upsample_nearest2x_nhwc_bf16(const void* in, long long in_pix_stride, i
         return OESS_EINVAL;
     hipLaunchKernelGGL(up2_kernel, dim3(grid_for((int64_t)B * 4 * H * W * (C >> 3))), dim3(THREADS), 0, (hipStream_t)stream,
                        (const uint16_t*)in, (int64_t)in_pix_stride, B, H, W, C, (uint16_t*)out, (int64_t)out_pix_stride);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_zero_insert_nhwc_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int C, int stride, int Hz, int Wz,
+                               void* out, long long out_pix_stride, oess_stream_t stream) {
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || (in_pix_stride & 7) || (out_pix_stride & 7) || stride <= 0 ||
+        Hz < (H - 1) * stride + 1 || Wz < (W - 1) * stride + 1)
+        return OESS_EINVAL;
+    hipLaunchKernelGGL(zero_insert_kernel, dim3(grid_for((int64_t)B * Hz * Wz * (C >> 3))), dim3(THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)in, (int64_t)in_pix_stride, B, H, W, C, stride, Hz, Wz, (uint16_t*)out, (int64_t)out_pix_stride);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }

@@ -94,7 +94,7 @@ def conv2d_infer(x, pw, Cout, k, stride=1, pad=0, dil=1, relu=False, residual=No
 
 class _ConvTrainFn(torch.autograd.Function):
     """Trainable conv, all three products on hand-written MFMA kernels: forward (conv_fwd.hip), data gradient
-    (the same kernel on the rotated / transposed packed weight; stride-2 dgrad still falls back to ATen) and
+    (the same kernel on the rotated / transposed packed weight; strided convs first dilate dY with zeros) and
     weight gradient (conv_wgrad.hip, LDS transpose-read operands, split-K)."""
 
     @staticmethod
@@ -113,13 +113,13 @@ class _ConvTrainFn(torch.autograd.Function):
         gx = gw = gb = None
         Cin_x = x.shape[1]
         if ctx.needs_input_grad[0]:
-            if stride == 1:
-                gy8 = gy if gy.shape[1] % 8 == 0 else to_cl_bf16(gy)
-                gx = hip.conv2d_nhwc(nhwc(gy8), pw.flip(), None, Cin_x, k, k, 1, dil * (k - 1) - pad, dil)
-                gx = from_nhwc(gx)
-            else:
-                gx = torch.ops.aten.convolution_backward(gy, x, weight.to(x.dtype), None, [stride, stride], [pad, pad],
-                                                         [dil, dil], False, [0, 0], 1, [True, False, False])[0]
+            gy8 = gy if gy.shape[1] % 8 == 0 else to_cl_bf16(gy)
+            g_in = nhwc(gy8)
+            if stride != 1:         # strided conv: dilate dY with zeros, then the same stride-1 product
+                Hz = x.shape[2] - dil * (k - 1) + 2 * pad
+                Wz = x.shape[3] - dil * (k - 1) + 2 * pad
+                g_in = hip.zero_insert(g_in, stride, Hz, Wz)
+            gx = from_nhwc(hip.conv2d_nhwc(g_in, pw.flip(), None, Cin_x, k, k, 1, dil * (k - 1) - pad, dil))
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             Cout, Cin = weight.shape[0], weight.shape[1]
             gy8 = gy if gy.shape[1] % 8 == 0 else to_cl_bf16(gy)

@@ -315,7 +315,7 @@ class _CosMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, eps):
         lib = _lib.load()
-        (B, H, W, C), sa, sb = a.shape, a.stride(2), b.stride(2)
+        (B, H, W, C), sa, sb = a.shape, _pix_stride(a), _pix_stride(b)
         loss = torch.empty(1, dtype=torch.float32, device=a.device)
         _lib.check(lib.oess_cosine_mean_fwd(_ptr(a), sa, _ptr(b), sb, B * H * W, C, int(a.dtype == torch.bfloat16), eps,
                                             _ptr(_loss_scratch(a.device)), _ptr(loss), _stream()), "oess_cosine_mean_fwd")
@@ -327,7 +327,7 @@ class _CosMean(torch.autograd.Function):
     def backward(ctx, g):
         lib = _lib.load()
         a, b = ctx.saved_tensors
-        (B, H, W, C), sa, sb = a.shape, a.stride(2), b.stride(2)
+        (B, H, W, C), sa, sb = a.shape, _pix_stride(a), _pix_stride(b)
         ga = torch.empty((B, H, W, C), dtype=a.dtype, device=a.device) if ctx.needs_input_grad[0] else None
         gb = torch.empty((B, H, W, C), dtype=b.dtype, device=b.device) if ctx.needs_input_grad[1] else None
         gdev = g.reshape(1).float().contiguous()
@@ -351,10 +351,22 @@ def cosine_mean_loss(a, b, eps=1e-8):
     return _CosMean.apply(an, bn, float(eps))
 
 
+def _pix_stride(x):
+    """Pixel stride (elements) of an NHWC view; size-1 dims carry arbitrary strides in torch, so skip them."""
+    B, H, W, C = x.shape
+    if W > 1:
+        return x.stride(2)
+    if H > 1:
+        return x.stride(1)
+    if B > 1:
+        return x.stride(0)
+    return C
+
+
 def _uniform_pix_stride(x):
     B, H, W, C = x.shape
-    ps = x.stride(2)
-    return x.stride(1) == W * ps and (B == 1 or x.stride(0) == H * W * ps) and ps >= C
+    ps = _pix_stride(x)
+    return (H == 1 or W == 1 or x.stride(1) == W * ps) and (B == 1 or x.stride(0) == H * W * ps) and ps >= C
 
 
 # ------------------------------------------------------------------------------------------ K11
@@ -674,6 +686,17 @@ def upsample2x_concat(x, skip=None):
     return _UpsampleConcatFn.apply(x, skip)
 
 
+def zero_insert(x_nhwc, stride, Hz, Wz):
+    """z[:, ::stride, ::stride] = x on a zero Hz x Wz grid (NHWC bf16 views): the dilate step of a strided conv's dgrad."""
+    lib = _lib.load()
+    _need_gpu(x_nhwc)
+    B, H, W, C, ps = _nhwc_geom(x_nhwc)
+    out = torch.empty((B, Hz, Wz, C), dtype=torch.bfloat16, device=x_nhwc.device)
+    _lib.check(lib.oess_zero_insert_nhwc_bf16(_ptr(x_nhwc), ps, B, H, W, C, stride, Hz, Wz, _ptr(out), C, _stream()),
+               "oess_zero_insert_nhwc_bf16")
+    return out
+
+
 def bilinear_l2norm(x, scale=4, normalize=True):
     """nn.Upsample(scale, bilinear, align_corners=True) + F.normalize(dim=1), inference form (no autograd)."""
     lib = _lib.load()
@@ -684,6 +707,87 @@ def bilinear_l2norm(x, scale=4, normalize=True):
     _lib.check(lib.oess_bilinear_l2norm_nhwc_bf16(_ptr(xn), ps, B, H, W, C, scale, int(normalize), _ptr(out), C, _stream()),
                "oess_bilinear_l2norm_nhwc_bf16")
     return out.permute(0, 3, 1, 2)
+
+
+def _nhwc_any(x):
+    """Logical NCHW fp32/bf16 tensor -> NHWC view with dense channels and uniformly strided pixels (copy if needed)."""
+    if x.dtype not in (torch.float32, torch.bfloat16) or x.ndim != 4:
+        raise ValueError("expected a 4-D float32 / bfloat16 tensor")
+    xn = x.permute(0, 2, 3, 1)
+    if xn.stride(3) != 1 or not _uniform_pix_stride(xn):
+        xn = xn.contiguous()
+    return xn
+
+
+class _BilinearResize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, align):
+        lib = _lib.load()
+        xn = _nhwc_any(x)
+        B, H, W, C = xn.shape
+        out = torch.empty((B, Ho, Wo, C), dtype=x.dtype, device=x.device)
+        _lib.check(lib.oess_resize_bilinear_nhwc_fwd(_ptr(xn), _pix_stride(xn), B, H, W, C, int(x.dtype == torch.bfloat16), Ho, Wo,
+                                                     int(align), _ptr(out), C, _stream()), "oess_resize_bilinear_nhwc_fwd")
+        ctx.meta = (B, H, W, C, Ho, Wo, int(align))
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        B, H, W, C, Ho, Wo, align = ctx.meta
+        gn = _nhwc_any(g)
+        gin = torch.empty((B, H, W, C), dtype=g.dtype, device=g.device)
+        nbytes = lib.oess_resize_bilinear_bwd_workspace_bytes(B, W, C, Ho)
+        ws = _workspace(nbytes, g.device, tag="resize")
+        _lib.check(lib.oess_resize_bilinear_nhwc_bwd(_ptr(gn), _pix_stride(gn), B, H, W, C, int(g.dtype == torch.bfloat16), Ho, Wo,
+                                                     align, _ptr(ws), ws.numel(), _ptr(gin), C, _stream()),
+                   "oess_resize_bilinear_nhwc_bwd")
+        return gin.permute(0, 3, 1, 2), None, None, None
+
+
+def bilinear_resize(x, size=None, scale_factor=None, align_corners=False):
+    """F.interpolate(x, size | scale_factor, mode='bilinear', align_corners) for logical B x C x H x W fp32 / bf16
+    tensors, differentiable.  Result is logically NCHW, physically channels_last."""
+    _need_gpu(x)
+    if (size is None) == (scale_factor is None):
+        raise ValueError("give exactly one of size / scale_factor")
+    if size is None:
+        if int(scale_factor) != scale_factor:
+            raise ValueError("integer scale factors only (a fractional factor changes ATen's index rule)")
+        size = (x.shape[2] * int(scale_factor), x.shape[3] * int(scale_factor))
+    return _BilinearResize.apply(x, int(size[0]), int(size[1]), bool(align_corners))
+
+
+class _L2Normalize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        lib = _lib.load()
+        xn = _nhwc_any(x)
+        B, H, W, C = xn.shape
+        y = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+        inv = torch.empty(B * H * W, dtype=torch.float32, device=x.device)
+        _lib.check(lib.oess_l2norm_nhwc_fwd(_ptr(xn), _pix_stride(xn), B * H * W, C, int(x.dtype == torch.bfloat16), eps, _ptr(y), C,
+                                            _ptr(inv), _stream()), "oess_l2norm_nhwc_fwd")
+        ctx.save_for_backward(y, inv)
+        ctx.eps = eps
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        y, inv = ctx.saved_tensors
+        B, H, W, C = y.shape
+        gn = _nhwc_any(g.to(y.dtype))
+        gx = torch.empty_like(y)
+        _lib.check(lib.oess_l2norm_nhwc_bwd(_ptr(y), C, _ptr(gn), _pix_stride(gn), _ptr(inv), B * H * W, C,
+                                            int(y.dtype == torch.bfloat16), ctx.eps, _ptr(gx), C, _stream()), "oess_l2norm_nhwc_bwd")
+        return gx.permute(0, 3, 1, 2), None
+
+
+def l2_normalize(x, eps=1e-12):
+    """F.normalize(x, p=2, dim=1, eps) for logical B x C x H x W fp32 / bf16 tensors, differentiable."""
+    _need_gpu(x)
+    return _L2Normalize.apply(x, float(eps))
 
 
 def conv2d_wgrad(x, gy, Cout, Cin, R, S, stride=1, pad=0, dil=1):

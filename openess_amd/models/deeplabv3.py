@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import engine
+from .. import engine, hip
 from . import _resnet as resnet
 from ._resnet import HipConv2d, conv_bn
 
@@ -152,8 +152,8 @@ class deeplabv3_resnet50(nn.Module):
         input_shape = x.shape[-2:]
         features = self.backbone(x)
         logist, feats = self.classifier(features)
-        logist = F.interpolate(logist.float(), size=input_shape, mode='bilinear', align_corners=False)
-        feats = F.interpolate(feats, size=input_shape, mode='bilinear', align_corners=False)
+        logist = hip.bilinear_resize(logist.float(), size=input_shape, align_corners=False)      # deeplabv3.py:183
+        feats = hip.bilinear_resize(feats, size=input_shape, align_corners=False)                # deeplabv3.py:184
         if self.if_linear_probing:
             logist = self.linear_probe(logist)
         return logist, feats

@@ -45,7 +45,7 @@ class DilationFeatureExtractor(nn.Module):
             x = self.encoder(x)
         x = self.decoder[0](x)
         if torch.is_grad_enabled() and x.requires_grad:
-            # differentiable path (contrastive loss active): library resampler until the adjoint kernel lands
-            x = F.interpolate(x, scale_factor=4, mode="bilinear", align_corners=True)
-            return F.normalize(x, p=2, dim=1) if self.normalize_feature else x
+            # differentiable path (contrastive loss active): resize + normalise kernels with their adjoints
+            x = hip.bilinear_resize(x, scale_factor=4, align_corners=True)
+            return hip.l2_normalize(x) if self.normalize_feature else x
         return hip.bilinear_l2norm(x, 4, self.normalize_feature)

@@ -192,14 +192,17 @@ def test_deeplab_eval_and_train(g, keys):
 
 
 def test_conv_train_fn_gradients():
-    """conv2d_train (HIP forward + HIP dgrad for stride 1, library wgrad) vs PyTorch autograd of the same
+    """conv2d_train (HIP forward, HIP dgrad incl. the zero-insert form for strided convs, HIP wgrad) vs PyTorch autograd of the same
     bf16-rounded operands: every gradient direction must agree to fp32-accumulation noise."""
     import torch.nn.functional as F
     from openess_amd import engine
     torch.manual_seed(0)
     for (Cin, Cout, k, st, pad, dil, H, W) in ((256, 512, 3, 1, 1, 1, 6, 8), (512, 11, 1, 1, 0, 1, 6, 8),
                                                (64, 64, 3, 2, 1, 1, 16, 24), (2048, 256, 3, 1, 6, 6, 6, 8),
-                                               (32, 256, 1, 1, 0, 1, 20, 28)):
+                                               (32, 256, 1, 1, 0, 1, 20, 28),
+                                               (64, 128, 3, 2, 1, 1, 15, 23),       # stride 2, odd sizes (output_padding 0)
+                                               (128, 256, 1, 2, 0, 1, 14, 21),      # 1x1 stride-2 downsample branch
+                                               (32, 64, 5, 2, 2, 1, 18, 26)):       # 5x5 stride 2
         x = torch.randn(2, Cin, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
         wgt = torch.randn(Cout, Cin, k, k, device="cuda") / (Cin * k * k) ** 0.5
         bias = torch.randn(Cout, device="cuda")

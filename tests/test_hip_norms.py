@@ -85,3 +85,55 @@ def test_bilinear_l2norm(C):
     y2 = hip.bilinear_l2norm(x, 4, False)
     ref2 = F.interpolate(x.float(), scale_factor=4, mode="bilinear", align_corners=True)
     np.testing.assert_allclose(y2.float().cpu().numpy(), ref2.cpu().numpy(), rtol=1e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("case", [
+    # B, C, H, W, Ho, Wo, align, dtype
+    (2, 256, 7, 10, 110, 160, False, torch.bfloat16),     # DeepLabv3 features: OS16 -> input size (vector path)
+    (2, 11, 7, 10, 110, 157, False, torch.float32),       # logits, K = 11 (scalar path), non-integer ratio
+    (1, 64, 11, 16, 44, 64, True, torch.bfloat16),        # teacher x4, align_corners=True
+    (1, 8, 9, 5, 9, 5, False, torch.float32),             # identity size
+    (2, 12, 6, 6, 3, 4, False, torch.float32),            # downsampling (footprints skip input pixels)
+    (1, 16, 1, 1, 5, 7, True, torch.float32),             # single input pixel
+])
+def test_bilinear_resize_fwd_bwd(case):
+    """oess_resize_bilinear_nhwc_fwd / _bwd vs F.interpolate + autograd on the same operands (fp32 math in both)."""
+    from openess_amd import hip
+    B, C, H, W, Ho, Wo, align, dtype = case
+    torch.manual_seed(Ho * Wo + C)
+    x = torch.randn(B, C, H, W, device="cuda").to(dtype)
+    if dtype == torch.bfloat16:
+        x = cl(x)
+    x.requires_grad_(True)
+    y = hip.bilinear_resize(x, size=(Ho, Wo), align_corners=align)
+    xr = x.detach().float().requires_grad_(True)
+    ref = F.interpolate(xr, size=(Ho, Wo), mode="bilinear", align_corners=align)
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+    assert y.shape == ref.shape and y.dtype == dtype
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), ref.detach().cpu().numpy(), rtol=tol, atol=tol)
+    g = torch.randn_like(ref)
+    y.backward(g.to(dtype))
+    ref.backward(g.to(dtype).float())
+    # backward tolerance: fp32 sums of <= (2*scale+2)^2 terms in a different order; bf16 rounds the result once
+    np.testing.assert_allclose(x.grad.float().cpu().numpy(), xr.grad.cpu().numpy(), rtol=2e-2 if dtype == torch.bfloat16 else 1e-4,
+                               atol=5e-2 if dtype == torch.bfloat16 else 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_l2_normalize_fwd_bwd(dtype):
+    from openess_amd import hip
+    torch.manual_seed(9)
+    x = torch.randn(2, 96, 5, 7, device="cuda").to(dtype)
+    x[0, :, 0, 0] = 0                                   # zero vector: eps clamp (y = 0, gradient = g / eps)
+    x.requires_grad_(True)
+    y = hip.l2_normalize(x)
+    xr = x.detach().float().requires_grad_(True)
+    ref = F.normalize(xr, p=2, dim=1)
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-6
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), ref.detach().cpu().numpy(), rtol=tol, atol=tol)
+    g = torch.randn_like(ref)
+    g[0, :, 0, 0] = 0                                   # keep the 1/eps branch finite in the comparison
+    y.backward(g.to(dtype))
+    ref.backward(g.to(dtype).float())
+    np.testing.assert_allclose(x.grad.float().cpu().numpy(), xr.grad.cpu().numpy(), rtol=3e-2 if dtype == torch.bfloat16 else 1e-4,
+                               atol=2e-2 if dtype == torch.bfloat16 else 1e-5)
