@@ -5,6 +5,7 @@
 // reductions, one global atomic per (workgroup, accumulator).  No MFMA (integer / byte / fp32 work).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "oess.h"
 #include "oess_common.h"
 
@@ -211,6 +212,109 @@ __global__ __launch_bounds__(THREADS) void segmean_fwd_kernel(const void* __rest
         if (gid < 0 || gid >= S) continue;
         if (c_ok) atomicAdd(&k[gid * Cf + c], acc[i][threadIdx.x & 63]);
         if ((threadIdx.x & 63) == 0 && slice == 0) atomicAdd(&count[gid], (float)cnt[i]);
+    }
+}
+
+// Vectorised form (C/CPL lanes per pixel, CPL = 8 bf16 / 4 fp32 channels = one 16-byte load per lane): a wave covers
+// 64/LPP whole pixel rows per load instruction and keeps U of them in flight; each LPP-lane group walks its own
+// contiguous pixel run with a register run-accumulator and only touches the LDS table [VLOCAL ids][C] when the id
+// changes.  One workgroup per CU (the table is up to 128 KB); 8 groups x 8 loads x 512 B = 32 KB in flight per CU.
+constexpr int SEGV_PIX_PER_WG = 2048;
+template <bool BF16, int LPP>
+__global__ __launch_bounds__(THREADS) void segmean_fwd_vec_kernel(const void* __restrict__ feat, const int64_t* __restrict__ ids,
+                                                                  int64_t P, int64_t pps, int sps, int S, int vlocal,
+                                                                  float* __restrict__ k, float* __restrict__ count) {
+    constexpr int CPL = BF16 ? 8 : 4;
+    constexpr int Cf = LPP * CPL;
+    constexpr int GROUPS = THREADS / LPP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char seg_smem[];
+    float* acc = reinterpret_cast<float*>(seg_smem);                    // [vlocal][Cf]
+    int* cnt = reinterpret_cast<int*>(acc + (size_t)vlocal * Cf);       // [vlocal]
+    const int sub = threadIdx.x % LPP, grp = threadIdx.x / LPP;
+    const int64_t chunks_per_sample = (pps + SEGV_PIX_PER_WG - 1) / SEGV_PIX_PER_WG;
+    const int64_t b = blockIdx.x / chunks_per_sample, ch = blockIdx.x - b * chunks_per_sample;
+    const int64_t p_beg = b * pps + ch * SEGV_PIX_PER_WG;
+    int64_t p_end = p_beg + SEGV_PIX_PER_WG;
+    if (p_end > (b + 1) * pps) p_end = (b + 1) * pps;
+    if (p_end > P) p_end = P;
+    for (int i = threadIdx.x; i < vlocal * Cf; i += THREADS) acc[i] = 0.0f;
+    for (int i = threadIdx.x; i < vlocal; i += THREADS) cnt[i] = 0;
+    __syncthreads();
+    const int64_t id_off = b * (int64_t)sps;
+    const int64_t len = p_end - p_beg;
+    const int64_t q = (len + GROUPS - 1) / GROUPS;
+    int64_t g_beg = p_beg + grp * q, g_end = g_beg + q;
+    if (g_end > p_end) g_end = p_end;
+    int64_t cur = -1;
+    float run[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) run[c] = 0.f;
+    int run_n = 0;
+    auto flush = [&]() {
+        if (run_n == 0) return;
+        if (cur >= 0 && cur < vlocal) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) atomicAdd(&acc[cur * Cf + sub * CPL + c], run[c]);
+            if (sub == 0) atomicAdd(&cnt[cur], run_n);
+        } else {
+            const int64_t gid = cur + id_off;
+            if (gid >= 0 && gid < S) {
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) atomicAdd(&k[gid * Cf + sub * CPL + c], run[c]);
+                if (sub == 0) atomicAdd(&count[gid], (float)run_n);
+            }
+        }
+    };
+    constexpr int U = 8;
+    for (int64_t p = g_beg; p < g_end; p += U) {
+        float v[U][CPL];
+        int64_t id[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t pu = p + u;
+            const bool ok = pu < g_end;
+            id[u] = ok ? ids[pu] : cur;
+            if (ok) {
+                if constexpr (BF16) {
+                    union { uint4 q4; uint16_t h[8]; } r;
+                    r.q4 = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(feat) + pu * Cf + sub * 8);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[u][c] = bf16_to_f32(r.h[c]);
+                } else {
+                    const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(feat) + pu * Cf + sub * 4);
+                    v[u][0] = r.x; v[u][1] = r.y; v[u][2] = r.z; v[u][3] = r.w;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) v[u][c] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (p + u < g_end) {
+                if (id[u] != cur) {
+                    flush();
+                    cur = id[u];
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) run[c] = 0.f;
+                    run_n = 0;
+                }
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) run[c] += v[u][c];
+                run_n += 1;
+            }
+        }
+    }
+    flush();
+    __syncthreads();
+    for (int i = grp; i < vlocal; i += GROUPS) {
+        const int n = cnt[i];
+        if (n == 0) continue;
+        const int64_t gid = i + id_off;
+        if (gid < 0 || gid >= S) continue;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) atomicAdd(&k[gid * Cf + sub * CPL + c], acc[i * Cf + sub * CPL + c]);
+        if (sub == 0) atomicAdd(&count[gid], (float)n);
     }
 }
 
@@ -454,6 +558,31 @@ int oess_segment_mean_fwd(const void* feat, int is_bf16, const int64_t* ids, int
     OESS_HIP(hipMemsetAsync(k, 0, (size_t)S * Cf * sizeof(float), st));
     OESS_HIP(hipMemsetAsync(count, 0, (size_t)S * sizeof(float), st));
     const int64_t B = P / pixels_per_sample;
+    {   // vectorised kernel: Cf = LPP * (8 bf16 | 4 fp32 channels per lane), LPP in {8, 16, 32, 64}, 16-byte aligned rows
+        const int cpl = is_bf16 ? 8 : 4;
+        const int lpp = (Cf % cpl == 0) ? Cf / cpl : 0;
+        static int use_vec = -1;
+        if (use_vec < 0) { const char* e = getenv("OESS_SEGMEAN_VEC"); use_vec = e ? atoi(e) : 1; }
+        if (use_vec && (lpp == 8 || lpp == 16 || lpp == 32 || lpp == 64) && ((uintptr_t)feat & 15) == 0) {
+            int vlocal = (int)((128 * 1024) / ((size_t)Cf * 4 + 4));      // ids held in the LDS table (<= 128 KB)
+            if (vlocal > 256) vlocal = 256;
+            const size_t lds = (size_t)vlocal * ((size_t)Cf * 4 + 4);
+            const int64_t vchunks = (pixels_per_sample + SEGV_PIX_PER_WG - 1) / SEGV_PIX_PER_WG;
+            const dim3 vgrid((unsigned)(B * vchunks));
+#define OESS_SEGV(BF, L)                                                                                                     \
+            {                                                                                                                \
+                (void)hipFuncSetAttribute((const void*)&segmean_fwd_vec_kernel<BF, L>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                hipLaunchKernelGGL((segmean_fwd_vec_kernel<BF, L>), vgrid, dim3(THREADS), lds, st, feat, ids, P, pixels_per_sample, \
+                                   superpixel_size, S, vlocal, k, count);                                                   \
+            }
+            if (is_bf16) { if (lpp == 8) OESS_SEGV(true, 8) else if (lpp == 16) OESS_SEGV(true, 16) else if (lpp == 32) OESS_SEGV(true, 32) else OESS_SEGV(true, 64) }
+            else { if (lpp == 8) OESS_SEGV(false, 8) else if (lpp == 16) OESS_SEGV(false, 16) else if (lpp == 32) OESS_SEGV(false, 32) else OESS_SEGV(false, 64) }
+#undef OESS_SEGV
+            hipLaunchKernelGGL(segmean_finalize_kernel, dim3(stream_grid((int64_t)S * Cf, THREADS)), dim3(THREADS), 0, st, k, count, S, Cf);
+            OESS_HIP(hipGetLastError());
+            return OESS_OK;
+        }
+    }
     const int64_t chunks = (pixels_per_sample + SEG_PIX_PER_WG - 1) / SEG_PIX_PER_WG;
     dim3 grid((unsigned)(B * chunks), (unsigned)((Cf + SEG_CH - 1) / SEG_CH));
     if (is_bf16)

@@ -218,6 +218,52 @@ __global__ __launch_bounds__(THREADS) void l2norm_bwd_kernel(const void* __restr
     }
 }
 
+// vectorised forms: LPP = C / VEC lanes own one pixel (LPP in {8, 16, 32, 64}), one 16-byte access per lane
+template <bool BF16, int LPP>
+__global__ __launch_bounds__(THREADS) void l2norm_fwd_vec_kernel(const void* __restrict__ x, int64_t xs, int64_t P, float eps,
+                                                                 void* __restrict__ y, int64_t ys, float* __restrict__ inv_out) {
+    constexpr int VEC = BF16 ? 8 : 4;
+    constexpr int PPB = THREADS / LPP;
+    const int sub = threadIdx.x % LPP, pl = threadIdx.x / LPP;
+    for (int64_t p = (int64_t)blockIdx.x * PPB + pl; p < P; p += (int64_t)gridDim.x * PPB) {
+        float v[VEC];
+        loadv<BF16, VEC>(x, p * xs + sub * VEC, v);
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) ss += v[k] * v[k];
+#pragma unroll
+        for (int m = LPP / 2; m > 0; m >>= 1) ss += __shfl_xor(ss, m, 64);
+        const float inv = 1.0f / fmaxf(sqrtf(ss), eps);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[k] *= inv;
+        storev<BF16, VEC>(y, p * ys + sub * VEC, v);
+        if (sub == 0 && inv_out) inv_out[p] = inv;
+    }
+}
+template <bool BF16, int LPP>
+__global__ __launch_bounds__(THREADS) void l2norm_bwd_vec_kernel(const void* __restrict__ y, int64_t ys, const void* __restrict__ g,
+                                                                 int64_t gs, const float* __restrict__ inv_in, int64_t P, float eps,
+                                                                 void* __restrict__ gx, int64_t gxs) {
+    constexpr int VEC = BF16 ? 8 : 4;
+    constexpr int PPB = THREADS / LPP;
+    const int sub = threadIdx.x % LPP, pl = threadIdx.x / LPP;
+    for (int64_t p = (int64_t)blockIdx.x * PPB + pl; p < P; p += (int64_t)gridDim.x * PPB) {
+        float a[VEC], b[VEC], r[VEC];
+        loadv<BF16, VEC>(y, p * ys + sub * VEC, a);
+        loadv<BF16, VEC>(g, p * gs + sub * VEC, b);
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) dot += a[k] * b[k];
+#pragma unroll
+        for (int m = LPP / 2; m > 0; m >>= 1) dot += __shfl_xor(dot, m, 64);
+        const float inv = inv_in[p];
+        const bool clamped = inv >= 1.0f / eps;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) r[k] = clamped ? inv * b[k] : inv * (b[k] - a[k] * dot);
+        storev<BF16, VEC>(gx, p * gxs + sub * VEC, r);
+    }
+}
+
 Axis make_axis(int in, int out, int align) {
     Axis a; a.in = in; a.out = out; a.align = align;
     a.scale = align ? (out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.0f) : (float)in / (float)out;
@@ -287,8 +333,20 @@ int oess_resize_bilinear_nhwc_bwd(const void* grad_out, long long gout_pix_strid
 int oess_l2norm_nhwc_fwd(const void* x, long long x_pix_stride, int64_t P, int C, int is_bf16, float eps, void* y,
                          long long y_pix_stride, float* inv_norm, oess_stream_t stream) {
     if (!x || !y || P <= 0 || C <= 0 || x_pix_stride < C || y_pix_stride < C || eps <= 0.f) return OESS_EINVAL;
-    const unsigned g = grid_for(P * 64);
     hipStream_t st = (hipStream_t)stream;
+    {
+        const int vecw = is_bf16 ? 8 : 4, lpp = (C % vecw == 0) ? C / vecw : 0;
+        if ((lpp == 8 || lpp == 16 || lpp == 32 || lpp == 64) && vec_ok(x, x_pix_stride, C, is_bf16) && vec_ok(y, y_pix_stride, C, is_bf16)) {
+            const unsigned gv = grid_for(P * lpp);
+#define OESS_LN(BF, L) hipLaunchKernelGGL((l2norm_fwd_vec_kernel<BF, L>), dim3(gv), dim3(THREADS), 0, st, x, (int64_t)x_pix_stride, P, eps, y, (int64_t)y_pix_stride, inv_norm)
+            if (is_bf16) { if (lpp == 8) OESS_LN(true, 8); else if (lpp == 16) OESS_LN(true, 16); else if (lpp == 32) OESS_LN(true, 32); else OESS_LN(true, 64); }
+            else { if (lpp == 8) OESS_LN(false, 8); else if (lpp == 16) OESS_LN(false, 16); else if (lpp == 32) OESS_LN(false, 32); else OESS_LN(false, 64); }
+#undef OESS_LN
+            OESS_HIP(hipGetLastError());
+            return OESS_OK;
+        }
+    }
+    const unsigned g = grid_for(P * 64);
     if (is_bf16) hipLaunchKernelGGL(l2norm_fwd_kernel<true>, dim3(g), dim3(THREADS), 0, st, x, (int64_t)x_pix_stride, P, C, eps, y, (int64_t)y_pix_stride, inv_norm);
     else hipLaunchKernelGGL(l2norm_fwd_kernel<false>, dim3(g), dim3(THREADS), 0, st, x, (int64_t)x_pix_stride, P, C, eps, y, (int64_t)y_pix_stride, inv_norm);
     OESS_HIP(hipGetLastError());
@@ -299,8 +357,21 @@ int oess_l2norm_nhwc_bwd(const void* y, long long y_pix_stride, const void* grad
                          int64_t P, int C, int is_bf16, float eps, void* grad_x, long long gx_pix_stride, oess_stream_t stream) {
     if (!y || !grad_y || !inv_norm || !grad_x || P <= 0 || C <= 0 || y_pix_stride < C || gy_pix_stride < C || gx_pix_stride < C || eps <= 0.f)
         return OESS_EINVAL;
-    const unsigned g = grid_for(P * 64);
     hipStream_t st = (hipStream_t)stream;
+    {
+        const int vecw = is_bf16 ? 8 : 4, lpp = (C % vecw == 0) ? C / vecw : 0;
+        if ((lpp == 8 || lpp == 16 || lpp == 32 || lpp == 64) && vec_ok(y, y_pix_stride, C, is_bf16) && vec_ok(grad_y, gy_pix_stride, C, is_bf16) &&
+            vec_ok(grad_x, gx_pix_stride, C, is_bf16)) {
+            const unsigned gv = grid_for(P * lpp);
+#define OESS_LN(BF, L) hipLaunchKernelGGL((l2norm_bwd_vec_kernel<BF, L>), dim3(gv), dim3(THREADS), 0, st, y, (int64_t)y_pix_stride, grad_y, (int64_t)gy_pix_stride, inv_norm, P, eps, grad_x, (int64_t)gx_pix_stride)
+            if (is_bf16) { if (lpp == 8) OESS_LN(true, 8); else if (lpp == 16) OESS_LN(true, 16); else if (lpp == 32) OESS_LN(true, 32); else OESS_LN(true, 64); }
+            else { if (lpp == 8) OESS_LN(false, 8); else if (lpp == 16) OESS_LN(false, 16); else if (lpp == 32) OESS_LN(false, 32); else OESS_LN(false, 64); }
+#undef OESS_LN
+            OESS_HIP(hipGetLastError());
+            return OESS_OK;
+        }
+    }
+    const unsigned g = grid_for(P * 64);
     if (is_bf16) hipLaunchKernelGGL(l2norm_bwd_kernel<true>, dim3(g), dim3(THREADS), 0, st, y, (int64_t)y_pix_stride, grad_y, (int64_t)gy_pix_stride, inv_norm, P, C, eps, grad_x, (int64_t)gx_pix_stride);
     else hipLaunchKernelGGL(l2norm_bwd_kernel<false>, dim3(g), dim3(THREADS), 0, st, y, (int64_t)y_pix_stride, grad_y, (int64_t)gy_pix_stride, inv_norm, P, C, eps, grad_x, (int64_t)gx_pix_stride);
     OESS_HIP(hipGetLastError());

@@ -61,7 +61,8 @@ class ASPPPooling(nn.Sequential):
     def forward(self, x):
         size = x.shape[-2:]
         y = x.float().mean(dim=(2, 3), keepdim=True)                       # AdaptiveAvgPool2d(1)
-        y = F.relu(self[2](F.conv2d(y, self[1].weight)))                   # B x C x 1 x 1: a GEMV, not a conv
+        y = torch.matmul(y.flatten(1), self[1].weight.flatten(1).t())[:, :, None, None]   # B x C x 1 x 1: a GEMV, not a conv
+        y = F.relu(self[2](y))
         return y.to(x.dtype).expand(-1, -1, size[0], size[1])              # bilinear from 1x1 == broadcast
 
 

@@ -87,6 +87,29 @@ def test_superpixel_pool_full_size():
         np.testing.assert_allclose(k.cpu().numpy(), refd.numpy(), rtol=tol, atol=tol * 1e-2)
 
 
+@pytest.mark.parametrize("C,dt", [(64, torch.bfloat16), (128, torch.float32), (256, torch.bfloat16), (40, torch.float32)])
+def test_superpixel_pool_random_ids(C, dt):
+    """Adversarial ids (no spatial coherence: every pixel ends a run), values up to 255 (> superpixel_size and beyond
+    the LDS table of the vectorised kernel), ragged pixel counts; C = 40 takes the generic lane-per-channel kernel."""
+    from openess_amd import hip
+    torch.manual_seed(C)
+    B, H, W, sps = 3, 37, 53, 100
+    feat = torch.randn(B, C, H, W)
+    ids = torch.randint(0, 256, (B, H, W))
+    ids[0, :, :20] = 7                                        # one long run as well
+    f = feat.to(dt).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    k = hip.superpixel_pool(f, ids.cuda(), sps)
+    fr = feat.to(dt).float().requires_grad_(True)
+    ref = ol.superpixel_pool(fr, ids, sps)
+    assert k.shape == ref.shape
+    np.testing.assert_allclose(k.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=2e-6)
+    w = torch.randn_like(ref)
+    (k * w.cuda()).sum().backward()
+    (ref * w).sum().backward()
+    tol = 1e-2 if dt == torch.bfloat16 else 1e-5
+    np.testing.assert_allclose(f.grad.float().cpu().numpy(), fr.grad.numpy(), rtol=tol, atol=tol * 1e-2)
+
+
 def test_confusion_matrix(golden_losses):
     from openess_amd import hip
     g = golden_losses

@@ -120,10 +120,11 @@ def test_bilinear_resize_fwd_bwd(case):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_l2_normalize_fwd_bwd(dtype):
+@pytest.mark.parametrize("C", [96, 256, 64])          # 96: generic wave-per-pixel kernel; 256 / 64: 16-byte vector kernels
+def test_l2_normalize_fwd_bwd(dtype, C):
     from openess_amd import hip
     torch.manual_seed(9)
-    x = torch.randn(2, 96, 5, 7, device="cuda").to(dtype)
+    x = torch.randn(2, C, 5, 7, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
     x[0, :, 0, 0] = 0                                   # zero vector: eps clamp (y = 0, gradient = g / eps)
     x.requires_grad_(True)
     y = hip.l2_normalize(x)
