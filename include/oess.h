@@ -237,6 +237,16 @@ int oess_norm_apply_nhwc_bf16(const void* x, long long x_pix_stride, const float
 int oess_instnorm_bwd_nhwc_bf16(const void* x, long long x_pix_stride, const void* dy, long long dy_pix_stride,
                                 const float* mean, const float* rstd, int relu, int G, long long pixels_per_group, int C,
                                 float* s1, float* s2, void* dx, long long dx_pix_stride, oess_stream_t stream);
+/* nn.BatchNorm2d TRAIN-mode backward fused with the ReLU mask and the residual branch of a Bottleneck
+ * (models/_resnet.py:96-114: out = relu(bn3(conv3) + identity)):  g = dy * (y_out > 0 if relu);  d(residual) = g;
+ * dbeta[C] = sum g;  dgamma[C] = sum g * xhat;  dx = gamma * rstd * (g - dbeta/N - xhat * dgamma/N).
+ * x = the BatchNorm input, y_out = the stored forward output (needed when relu != 0), mean / rstd = the batch statistics
+ * of the forward (oess_norm_finalize).  dresidual nullable.  Replaces MIOpenBatchNormBwdSpatial* + the ATen ReLU / add
+ * backward kernels on the trainable DeepLabv3 path. */
+int oess_batchnorm_bwd_nhwc_bf16(const void* x, long long x_pix_stride, const void* dy, long long dy_pix_stride, const void* y_out,
+                                 long long y_pix_stride, const float* mean, const float* rstd, const float* gamma, int relu,
+                                 long long pixels, int C, float* dbeta, float* dgamma, void* dx, long long dx_pix_stride,
+                                 void* dresidual, long long dres_pix_stride, oess_stream_t stream);
 int oess_upsample_nearest2x_nhwc_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int C, void* out,
                                       long long out_pix_stride, oess_stream_t stream);
 /* z[b, s*y, s*x, :] = in[b, y, x, :], zero elsewhere on an Hz x Wz grid: turns the data gradient of a stride-s convolution

@@ -56,6 +56,8 @@ SIGNATURES = {
     "oess_l2norm_nhwc_fwd": (c_int, [c_vp, c_ll, c_i64, c_int, c_int, c_f, c_vp, c_ll, c_vp, c_vp]),
     "oess_l2norm_nhwc_bwd": (c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_i64, c_int, c_int, c_f, c_vp, c_ll, c_vp]),
     "oess_zero_insert_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_ll, c_vp]),
+    "oess_batchnorm_bwd_nhwc_bf16": (c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_int, c_ll, c_int, c_vp, c_vp,
+                                             c_vp, c_ll, c_vp, c_ll, c_vp]),
     "oess_masked_stats_slice_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp]),
     "oess_event_slice_to_nhwc8_bf16": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_ll, c_vp, c_int, c_vp, c_vp]),
     "oess_norm_stats_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_ll, c_int, c_vp, c_vp, c_vp]),

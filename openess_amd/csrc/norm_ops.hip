@@ -29,7 +29,8 @@ __global__ __launch_bounds__(THREADS) void stats_kernel(const uint16_t* __restri
                                                         const uint16_t* __restrict__ dy, int64_t dps,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         int relu, int64_t ppg, int C, float* __restrict__ o1,
-                                                        float* __restrict__ o2) {
+                                                        float* __restrict__ o2, const uint16_t* __restrict__ yout = nullptr,
+                                                        int64_t yps = 0) {
     extern __shared__ float red[];                 // [rows][C][2]
     const int cl = C >> 3;
     const int rows = THREADS / cl;
@@ -56,13 +57,15 @@ __global__ __launch_bounds__(THREADS) void stats_kernel(const uint16_t* __restri
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const float f = bf16_to_f32(v.h[k]); a1[k] += f; a2[k] += f * f; }
             } else {
-                Pack8 d;
+                Pack8 d, yo;
                 d.q = *reinterpret_cast<const uint4*>(dy + pix * dps + lane_c * 8);
+                if (relu && yout) yo.q = *reinterpret_cast<const uint4*>(yout + pix * yps + lane_c * 8);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const float xh = (bf16_to_f32(v.h[k]) - mu[k]) * rs[k];
                     float gg = bf16_to_f32(d.h[k]);
-                    if (relu && !(xh > 0.f)) gg = 0.f;
+                    // ReLU mask: from the stored output when there is an affine / residual, else y > 0 <=> xhat > 0
+                    if (relu && !(yout ? bf16_to_f32(yo.h[k]) > 0.f : xh > 0.f)) gg = 0.f;
                     a1[k] += gg; a2[k] += gg * xh;
                 }
             }
@@ -134,13 +137,17 @@ __global__ __launch_bounds__(THREADS) void apply_kernel(const uint16_t* __restri
     }
 }
 
-// InstanceNorm (affine-free) backward: dx = rstd * (g - s1/N - xhat * s2/N)
+// Normalisation backward: g = dy * mask;  dx = gamma * rstd * (g - s1/N - xhat * s2/N);  d(residual) = g
+// (gamma == nullptr: affine-free InstanceNorm; yout != nullptr: ReLU mask taken from the stored output)
 __global__ __launch_bounds__(THREADS) void in_bwd_apply_kernel(const uint16_t* __restrict__ x, int64_t xps,
                                                                const uint16_t* __restrict__ dy, int64_t dps,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ s1, const float* __restrict__ s2,
                                                                int relu, int64_t ppg, int G, int C,
-                                                               uint16_t* __restrict__ dx, int64_t gps) {
+                                                               uint16_t* __restrict__ dx, int64_t gps,
+                                                               const uint16_t* __restrict__ yout = nullptr, int64_t yps = 0,
+                                                               const float* __restrict__ gamma = nullptr,
+                                                               uint16_t* __restrict__ dres = nullptr, int64_t drps = 0) {
     const int cl = C >> 3;
     const float invn = 1.0f / (float)ppg;
     const int64_t total = (int64_t)G * ppg * cl;
@@ -148,19 +155,23 @@ __global__ __launch_bounds__(THREADS) void in_bwd_apply_kernel(const uint16_t* _
         const int64_t pix = i / cl;
         const int c0 = (int)(i - pix * cl) * 8;
         const int64_t g = pix / ppg;
-        Pack8 v, d, o;
+        Pack8 v, d, o, yo, ro;
         v.q = *reinterpret_cast<const uint4*>(x + pix * xps + c0);
         d.q = *reinterpret_cast<const uint4*>(dy + pix * dps + c0);
+        if (relu && yout) yo.q = *reinterpret_cast<const uint4*>(yout + pix * yps + c0);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int64_t gc = g * C + c0 + k;
             const float r = rstd[gc];
             const float xh = (bf16_to_f32(v.h[k]) - mean[gc]) * r;
             float gg = bf16_to_f32(d.h[k]);
-            if (relu && !(xh > 0.f)) gg = 0.f;
-            o.h[k] = f32_to_bf16(r * (gg - s1[gc] * invn - xh * s2[gc] * invn));
+            if (relu && !(yout ? bf16_to_f32(yo.h[k]) > 0.f : xh > 0.f)) gg = 0.f;
+            const float ga = gamma ? gamma[c0 + k] : 1.0f;
+            o.h[k] = f32_to_bf16(ga * r * (gg - s1[gc] * invn - xh * s2[gc] * invn));
+            ro.h[k] = f32_to_bf16(gg);
         }
         *reinterpret_cast<uint4*>(dx + pix * gps + c0) = o.q;
+        if (dres) *reinterpret_cast<uint4*>(dres + pix * drps + c0) = ro.q;
     }
 }
 
@@ -438,6 +449,34 @@ int oess_instnorm_bwd_nhwc_bf16(const void* x, long long x_pix_stride, const voi
     hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(grid_for((int64_t)G * pixels_per_group * cl)), dim3(THREADS), 0, st,
                        (const uint16_t*)x, (int64_t)x_pix_stride, (const uint16_t*)dy, (int64_t)dy_pix_stride, mean, rstd, s1,
                        s2, relu, (int64_t)pixels_per_group, G, C, (uint16_t*)dx, (int64_t)dx_pix_stride);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_batchnorm_bwd_nhwc_bf16(const void* x, long long x_pix_stride, const void* dy, long long dy_pix_stride, const void* y_out,
+                                 long long y_pix_stride, const float* mean, const float* rstd, const float* gamma, int relu,
+                                 long long pixels, int C, float* dbeta, float* dgamma, void* dx, long long dx_pix_stride,
+                                 void* dresidual, long long dres_pix_stride, oess_stream_t stream) {
+    if (!x || !dy || !mean || !rstd || !dbeta || !dgamma || !dx || pixels <= 0 || C <= 0 || (C & 7) || C > 2048 ||
+        (x_pix_stride & 7) || (dy_pix_stride & 7) || (dx_pix_stride & 7) || (relu && !y_out) || (y_out && (y_pix_stride & 7)) ||
+        (dresidual && (dres_pix_stride & 7)))
+        return OESS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    OESS_HIP(hipMemsetAsync(dbeta, 0, (size_t)C * sizeof(float), st));
+    OESS_HIP(hipMemsetAsync(dgamma, 0, (size_t)C * sizeof(float), st));
+    const int cl = C >> 3;
+    if (cl > THREADS) return OESS_EINVAL;
+    const int rows = THREADS / cl;
+    const size_t lds = (size_t)rows * C * 2 * sizeof(float);
+    dim3 grid(stats_chunks(pixels, 1), 1u);
+    // dbeta = sum g, dgamma = sum g * xhat (exactly the two sums dx needs)
+    hipLaunchKernelGGL(stats_kernel<1>, grid, dim3(THREADS), lds, st, (const uint16_t*)x, (int64_t)x_pix_stride,
+                       (const uint16_t*)dy, (int64_t)dy_pix_stride, mean, rstd, relu, (int64_t)pixels, C, dbeta, dgamma,
+                       (const uint16_t*)y_out, (int64_t)y_pix_stride);
+    hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(grid_for((int64_t)pixels * cl)), dim3(THREADS), 0, st, (const uint16_t*)x,
+                       (int64_t)x_pix_stride, (const uint16_t*)dy, (int64_t)dy_pix_stride, mean, rstd, dbeta, dgamma, relu,
+                       (int64_t)pixels, 1, C, (uint16_t*)dx, (int64_t)dx_pix_stride, (const uint16_t*)y_out, (int64_t)y_pix_stride,
+                       gamma, (uint16_t*)dresidual, (int64_t)dres_pix_stride);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }

@@ -602,6 +602,59 @@ def batch_norm_train_nhwc(x_nhwc, bn, relu=False, residual=None):
     return out
 
 
+class _BatchNormTrainFn(torch.autograd.Function):
+    """nn.BatchNorm2d in train mode [+ residual add] [+ ReLU], forward and backward on the norm kernels."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, relu, eps, momentum, running_mean, running_var):
+        xn = x.permute(0, 2, 3, 1)
+        rn = None if residual is None else residual.permute(0, 2, 3, 1)
+        out, mean, rstd = _norm_forward(xn, 1, gamma.detach(), beta.detach(), eps, relu, rn,
+                                        running=(running_mean, running_var), momentum=momentum)
+        ctx.save_for_backward(x, gamma, mean, rstd, out if relu else None)
+        ctx.relu = relu
+        ctx.has_res = residual is not None
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, gamma, mean, rstd, out = ctx.saved_tensors
+        gy = gy.to(torch.bfloat16)
+        if gy.stride(1) != 1:
+            gy = gy.contiguous(memory_format=torch.channels_last)
+        xn, gn = x.permute(0, 2, 3, 1), gy.permute(0, 2, 3, 1)
+        B, H, W, C, xps = _nhwc_geom(xn)
+        _, _, _, _, gps = _nhwc_geom(gn)
+        dx = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=x.device)
+        dres = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=x.device) if (ctx.has_res and ctx.relu) else None
+        dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        g32 = gamma.detach().float().contiguous()
+        _lib.check(lib.oess_batchnorm_bwd_nhwc_bf16(_ptr(xn), xps, _ptr(gn), gps, None if out is None else _ptr(out), C, _ptr(mean),
+                                                    _ptr(rstd), _ptr(g32), int(ctx.relu), B * H * W, C, _ptr(dgb[0]), _ptr(dgb[1]),
+                                                    _ptr(dx), C, None if dres is None else _ptr(dres), C, _stream()),
+                   "oess_batchnorm_bwd_nhwc_bf16")
+        gres = None
+        if ctx.has_res:
+            gres = dres.permute(0, 3, 1, 2) if dres is not None else gy       # no ReLU: the residual sees dy itself
+        return dx.permute(0, 3, 1, 2), dgb[1].to(gamma.dtype), dgb[0].to(gamma.dtype), gres, None, None, None, None, None
+
+
+def batch_norm_train(x, bn, relu=False, residual=None):
+    """Differentiable nn.BatchNorm2d (train mode: batch statistics + running-stat update) [+ residual] [+ ReLU] on a
+    logical-NCHW channels_last bf16 tensor (models/_resnet.py:96-114, models/deeplabv3.py:295-348)."""
+    _need_gpu(x)
+    if x.dtype != torch.bfloat16 or x.stride(1) != 1:
+        x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    if residual is not None and (residual.dtype != torch.bfloat16 or residual.stride(1) != 1):
+        residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = _BatchNormTrainFn.apply(x, bn.weight, bn.bias, residual, bool(relu), float(bn.eps),
+                                0.0 if bn.momentum is None else float(bn.momentum), bn.running_mean, bn.running_var)
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return y
+
+
 class _InstanceNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, relu, residual, eps):

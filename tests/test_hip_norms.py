@@ -138,3 +138,42 @@ def test_l2_normalize_fwd_bwd(dtype, C):
     ref.backward(g.to(dtype).float())
     np.testing.assert_allclose(x.grad.float().cpu().numpy(), xr.grad.cpu().numpy(), rtol=3e-2 if dtype == torch.bfloat16 else 1e-4,
                                atol=2e-2 if dtype == torch.bfloat16 else 1e-5)
+
+
+@pytest.mark.parametrize("relu,with_res", [(True, True), (True, False), (False, False), (False, True)])
+def test_batch_norm_train_fwd_bwd(relu, with_res):
+    """oess_batchnorm_bwd_nhwc_bf16 + the forward norm kernels vs nn.BatchNorm2d(train) [+ residual] [+ ReLU] in fp32 on
+    the same bf16-rounded operands: output, running statistics, dx, dgamma, dbeta, d(residual)."""
+    from openess_amd import hip
+    torch.manual_seed(3)
+    B, C, H, W = 4, 64, 9, 13
+    x = cl(torch.randn(B, C, H, W, device="cuda") * 2 + 0.5).requires_grad_(True)
+    res = cl(torch.randn(B, C, H, W, device="cuda")).requires_grad_(True) if with_res else None
+    bn = torch.nn.BatchNorm2d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C) + 0.5); bn.bias.copy_(torch.randn(C) * 0.2)
+    ref_bn = torch.nn.BatchNorm2d(C).cuda().train()
+    ref_bn.load_state_dict(bn.state_dict())
+    y = hip.batch_norm_train(x, bn, relu=relu, residual=res)
+    xr = x.detach().float().requires_grad_(True)
+    rr = res.detach().float().requires_grad_(True) if with_res else None
+    yr = ref_bn(xr)
+    if with_res:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), yr.detach().cpu().numpy(), rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), ref_bn.running_mean.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), ref_bn.running_var.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    assert int(bn.num_batches_tracked) == 1
+    g = torch.randn_like(yr)
+    # use the HIP output's own ReLU mask for the reference too (values within bf16 rounding of 0 may flip)
+    if relu:
+        g = g * (y.detach().float() > 0) * (yr.detach() > 0)
+    y.backward(g.to(torch.bfloat16))
+    yr.backward(g.to(torch.bfloat16).float())
+    np.testing.assert_allclose(x.grad.float().cpu().numpy(), xr.grad.cpu().numpy(), rtol=3e-2, atol=3e-2)
+    np.testing.assert_allclose(bn.weight.grad.cpu().numpy(), ref_bn.weight.grad.cpu().numpy(), rtol=2e-2, atol=5e-2)
+    np.testing.assert_allclose(bn.bias.grad.cpu().numpy(), ref_bn.bias.grad.cpu().numpy(), rtol=2e-2, atol=5e-2)
+    if with_res:
+        np.testing.assert_allclose(res.grad.float().cpu().numpy(), rr.grad.cpu().numpy(), rtol=1e-2, atol=1e-2)
