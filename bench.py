@@ -86,6 +86,21 @@ def cpu_baseline(sample_events, rectify_map):
                       f"{t_net:.2f}s = {total:.1f}s"}
 
 
+def _pmc_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
+    (profiles/r01_conv_hbm_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 read correction applied).
+    PMC counters cannot be sampled from inside the timed process, so the number travels with the repo; None when the
+    profile is absent or belongs to another workload."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_conv_hbm_traffic.json")
+    if workload != "frame2voxel_pixel_distill" or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return round(json.load(f)["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,7 +181,7 @@ def main():
             ach = conv_stats["flops"] / (conv_stats["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "conv_fwd_dma_kernel<128,128,2> (implicit-GEMM bf16 MFMA, LDS-DMA; all fwd + dgrad launches with Cout > 64, incl. the fused ConvLSTM-epilogue variant: conv FLOPs only)",
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": _pmc_traffic(a.workload),
                     "launches_per_step": conv_stats["launches"] // a.steps,
                     "avg_launch_us": round(conv_stats["ms"] * 1e3 / max(conv_stats["launches"], 1), 2),
                     "share_of_step_time": round(conv_stats["ms"] / (dt * 1e3), 3)}
