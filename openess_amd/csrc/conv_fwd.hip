@@ -825,8 +825,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 // =================================================================================================
 template <int R, int S>
 __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvArgs a) {
-    constexpr int TH = 8, TW = 64, HW_ = TW + S - 1, HH_ = TH + R - 1, NTAP = R * S, KS = 16;
-    __shared__ __attribute__((aligned(16))) u32x4_t halo[HH_ * HW_];
+    constexpr int TH = 8, TW = 64, HW_ = TW + S - 1, HH_ = TH + R - 1, NTAP = R * S;
+    constexpr int KS = (NTAP + 1) / 2;                       // k-steps of 16 = 2 taps; taps >= NTAP carry zero weights
+    constexpr int OP = 36;                                   // output image pitch in elements (32 ch + 4: conflict-free 8-byte writes)
+    constexpr int HALO_BYTES = HH_ * HW_ * 16, IMG_BYTES = TH * TW * OP * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char sm[HALO_BYTES > IMG_BYTES ? HALO_BYTES : IMG_BYTES];
+    u32x4_t* halo = reinterpret_cast<u32x4_t*>(sm);
     const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
     int bid = blockIdx.x;
     const int tx0 = (bid % tiles_x) * TW; bid /= tiles_x;
@@ -835,7 +839,7 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = lane & 31, hi = lane >> 5;
 
-    // weights: lane (n = p, k-half = hi) keeps its 16 fragments for the whole kernel
+    // weights: lane (n = p, k-half = hi) keeps its fragments for the whole kernel
     bf16x8_t wf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
@@ -861,9 +865,8 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvArgs a) {
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        // tap of this lane's k-chunk; taps beyond R*S meet zero weights (any in-range address will do)
         int tap = ks * 2 + hi;
-        tap = tap < NTAP ? tap : 0;
+        tap = tap < NTAP ? tap : 0;                          // zero weights there: any in-range address will do
         const int r = tap / S, sx = tap - r * S;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -874,26 +877,44 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvArgs a) {
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], af, acc[t], 0, 0, 0);
         }
     }
-    // epilogue: lane (pixel p of the m-tile, hi) holds channels (e&3) + 8*(e>>2) + 4*hi
+    __syncthreads();                                         // halo no longer needed: the output image reuses its LDS
+    // epilogue: lane (pixel p of the m-tile, hi) holds channels (e&3) + 8*(e>>2) + 4*hi -> 8-byte pieces into the image
+    uint16_t* img = reinterpret_cast<uint16_t*>(sm);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const int oy = ty0 + wave * 2 + (t >> 1), ox = tx0 + (t & 1) * 32 + p;
-        if (oy >= a.Ho || ox >= a.Wo) continue;
-        uint16_t* dst = a.out + (((long long)b * a.Ho + oy) * a.Wo + ox) * a.out_pix_stride;
+        const int pl = (wave * 2 + (t >> 1)) * TW + (t & 1) * 32 + p;          // pixel index inside the tile
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int ch = 8 * q + 4 * hi;
-            if (ch >= a.Cout) continue;
             float v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                v[k] = acc[t][q * 4 + k] + (a.bias ? a.bias[ch + k] : 0.0f);
+                v[k] = acc[t][q * 4 + k] + ((a.bias && ch + k < a.Cout) ? a.bias[ch + k] : 0.0f);
                 if (a.relu) v[k] = fmaxf(v[k], 0.0f);
             }
             uint2 o;
             o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
             o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-            *reinterpret_cast<uint2*>(dst + ch) = o;
+            *reinterpret_cast<uint2*>(img + pl * OP + ch) = o;
+        }
+    }
+    __syncthreads();
+    // coalesced stores: 4 lanes x 16 bytes per pixel row (Cout <= 32), consecutive lanes = consecutive pixels
+    const int cchunks = (a.Cout + 7) >> 3;
+    const bool al16 = (((uintptr_t)a.out) & 15) == 0 && (a.out_pix_stride & 7) == 0;
+    for (int i = tid; i < TH * TW * 4; i += 256) {
+        const int pl = i >> 2, cc = i & 3;
+        if (cc >= cchunks) continue;
+        const int oy = ty0 + pl / TW, ox = tx0 + (pl % TW);
+        if (oy >= a.Ho || ox >= a.Wo) continue;
+        uint16_t* dst = a.out + (((long long)b * a.Ho + oy) * a.Wo + ox) * a.out_pix_stride + cc * 8;
+        const uint2 lo = *reinterpret_cast<const uint2*>(img + pl * OP + cc * 8);
+        const uint2 hi2 = *reinterpret_cast<const uint2*>(img + pl * OP + cc * 8 + 4);
+        if (cc * 8 + 8 <= a.Cout && al16) {
+            *reinterpret_cast<uint4*>(dst) = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+        } else {                                             // ragged channel tail (Cout % 8 == 4) or 8-byte aligned rows
+            *reinterpret_cast<uint2*>(dst) = lo;
+            if (cc * 8 + 4 < a.Cout) *reinterpret_cast<uint2*>(dst + 4) = hi2;
         }
     }
 }

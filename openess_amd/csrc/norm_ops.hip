@@ -374,6 +374,14 @@ int grid_for(int64_t work) {
 
 }  // namespace
 
+// zero two fp32 accumulators; one memset when they are adjacent (the wrappers allocate them as one tensor)
+static hipError_t zero_pair(float* a, float* b, size_t n, hipStream_t st) {
+    if (b == a + n) return hipMemsetAsync(a, 0, 2 * n * sizeof(float), st);
+    hipError_t e = hipMemsetAsync(a, 0, n * sizeof(float), st);
+    if (e != hipSuccess) return e;
+    return hipMemsetAsync(b, 0, n * sizeof(float), st);
+}
+
 extern "C" {
 
 int oess_norm_stats_nhwc_bf16(const void* x, long long x_pix_stride, int G, long long pixels_per_group, int C,
@@ -381,8 +389,7 @@ int oess_norm_stats_nhwc_bf16(const void* x, long long x_pix_stride, int G, long
     if (!x || !sum || !sumsq || G <= 0 || pixels_per_group <= 0 || C <= 0 || (C & 7) || C > 2048 || (x_pix_stride & 7))
         return OESS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    OESS_HIP(hipMemsetAsync(sum, 0, (size_t)G * C * sizeof(float), st));
-    OESS_HIP(hipMemsetAsync(sumsq, 0, (size_t)G * C * sizeof(float), st));
+    OESS_HIP(zero_pair(sum, sumsq, (size_t)G * C, st));
     const int cl = C >> 3;
     if (cl > THREADS) return OESS_EINVAL;
     const int rows = THREADS / cl;
@@ -397,8 +404,7 @@ int oess_norm_stats_nhwc_bf16(const void* x, long long x_pix_stride, int G, long
 int oess_norm_reduce_tile_stats(const float* tile_stats, int tiles, int C, float* sum, float* sumsq, oess_stream_t stream) {
     if (!tile_stats || !sum || !sumsq || tiles <= 0 || C <= 0) return OESS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    OESS_HIP(hipMemsetAsync(sum, 0, (size_t)C * sizeof(float), st));
-    OESS_HIP(hipMemsetAsync(sumsq, 0, (size_t)C * sizeof(float), st));
+    OESS_HIP(zero_pair(sum, sumsq, (size_t)C, st));
     int gy = (tiles + 63) / 64;                    // >= 8 tiles per tile lane
     if (gy > 32) gy = 32;
     if (gy < 1) gy = 1;
@@ -437,8 +443,7 @@ int oess_instnorm_bwd_nhwc_bf16(const void* x, long long x_pix_stride, const voi
         C > 2048 || (x_pix_stride & 7) || (dy_pix_stride & 7) || (dx_pix_stride & 7))
         return OESS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    OESS_HIP(hipMemsetAsync(s1, 0, (size_t)G * C * sizeof(float), st));
-    OESS_HIP(hipMemsetAsync(s2, 0, (size_t)G * C * sizeof(float), st));
+    OESS_HIP(zero_pair(s1, s2, (size_t)G * C, st));
     const int cl = C >> 3;
     if (cl > THREADS) return OESS_EINVAL;
     const int rows = THREADS / cl;
@@ -462,8 +467,7 @@ int oess_batchnorm_bwd_nhwc_bf16(const void* x, long long x_pix_stride, const vo
         (dresidual && (dres_pix_stride & 7)))
         return OESS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    OESS_HIP(hipMemsetAsync(dbeta, 0, (size_t)C * sizeof(float), st));
-    OESS_HIP(hipMemsetAsync(dgamma, 0, (size_t)C * sizeof(float), st));
+    OESS_HIP(zero_pair(dbeta, dgamma, (size_t)C, st));
     const int cl = C >> 3;
     if (cl > THREADS) return OESS_EINVAL;
     const int rows = THREADS / cl;

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openess_amd import hip
 SHAPES = {"gates": (8, 110, 160, 256, 512, 3, 1, 1, 1), "l3": (8, 55, 80, 256, 256, 3, 1, 4, 4),
           "pw": (8, 55, 80, 256, 1024, 1, 1, 0, 1), "l4": (8, 55, 80, 512, 512, 3, 1, 8, 8),
-          "gk4": (8, 110, 160, 1024, 512, 3, 1, 1, 1), "gk1": (8, 110, 160, 64, 512, 3, 1, 1, 1)}
+          "head": (8, 440, 640, 8, 32, 5, 1, 2, 1), "gk4": (8, 110, 160, 1024, 512, 3, 1, 1, 1), "gk1": (8, 110, 160, 64, 512, 3, 1, 1, 1)}
 for name in sys.argv[1:]:
     B, H, W, Cin, Cout, R, st, pad, dil = SHAPES[name]
     mode = os.environ.get("ABL_DATA", "randn")
