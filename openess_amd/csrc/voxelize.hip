@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include "oess.h"
 #include "oess_common.h"
 
@@ -514,6 +515,216 @@ __global__ __launch_bounds__(THREADS) void near_splat_kernel(const float4* __res
     write_tile(acc, out, g, s, separate_pol ? 2 * nbins : nbins, tx, ty, !separate_pol);
 }
 
+// =============================================================================================
+// v2 tri-linear pipeline: SLICE-LOCAL SORT + multi-run splat (2 kernels instead of 5).
+//   S  sort   workgroup (segment, slice of 2048 events): load the events ONCE, LDS histogram per tile, LDS
+//             exclusive scan, rank by LDS integer atomic into an LDS record buffer, then ONE coalesced block
+//             copy of the slice's records (sorted by tile) to a region obtained with one global atomic; the
+//             per-slice table row {start[tile], ..., total, base} is stored with plain stores.
+//   D  splat  workgroup (segment, tile): gathers its run from every slice of the segment (run table -> LDS
+//             prefix -> flat index -> binary search), accumulates as before and writes every voxel once.
+// vs v1 (count, 2 scans, scatter, splat): the events are read once (not twice), the records leave the sort
+// workgroup as full, exclusively owned cache lines (v1 wrote 16-byte records into 300 private ~450-byte cursor
+// ranges per workgroup whose boundary lines were shared between workgroups on different XCDs), and both scan
+// kernels disappear.
+// =============================================================================================
+constexpr int SORT_THREADS = 512;        // two sort workgroups per CU (one loads while the other ranks / copies out)
+constexpr int SSL = SORT_THREADS * EPT;  // 4096 events per sort slice (one batch of EPT per thread)
+constexpr int LCAP = 4608;               // records staged in LDS (72 KB); a slice needs 4096 * ~1.08 on real data,
+                                         // up to 4 * 4096 on adversarial input (overflow goes straight to HBM)
+
+__device__ __forceinline__ int block_incl_scan_256(int v, int* wsum) {
+    // inclusive scan over all threads of the block (<= 16 waves); wsum: 16 ints of LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int add = 0;
+    for (int w = 0; w < wave; ++w) add += wsum[w];
+    __syncthreads();
+    return x + add;
+}
+
+// table row layout per (segment, slice): [0 .. nTiles] = ABSOLUTE record index where each tile's run starts (entry
+// nTiles = end of the slice's region); [nTiles + 1] unused padding
+template <typename Src>
+__global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const int64_t* __restrict__ seg_off, Geom g, int nSl,
+                                                           int* __restrict__ table, unsigned int* __restrict__ alloc,
+                                                           float4* __restrict__ recs, unsigned int cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_sort[];
+    const int nT = g.nTiles;
+    int* cur = reinterpret_cast<int*>(sm_sort);                                   // [nT + 1]
+    int* wsum = cur + nT + 1;                                                     // [16]
+    float4* buf = reinterpret_cast<float4*>(sm_sort + (((size_t)(nT + 1 + 16) * 4 + 15) & ~(size_t)15));   // [LCAP]
+    const int s = blockIdx.y, slice = blockIdx.x;
+    const int64_t b = seg_off[s], e = seg_off[s + 1];
+    const int64_t n = e - b;
+    int* tab = table + ((size_t)s * nSl + slice) * (nT + 2);
+    const int64_t sl_beg = (int64_t)slice * SSL;
+    for (int i = threadIdx.x; i <= nT; i += SORT_THREADS) cur[i] = 0;
+    if (sl_beg >= n) {                                   // empty slice (ragged segments): all-zero row
+        for (int i = threadIdx.x; i < nT + 2; i += SORT_THREADS) tab[i] = 0;
+        return;
+    }
+    __syncthreads();
+    int64_t sl_end = sl_beg + SSL;
+    if (sl_end > n) sl_end = n;
+    const typename Src::Seg sg = src.seg(s, b, e);
+    TriRec rec[EPT];
+    bool ok[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {                      // the only read of the events: EPT independent loads per lane
+        const int64_t i = sl_beg + k * SORT_THREADS + threadIdx.x;
+        ok[k] = i < sl_end;
+        rec[k] = src.load(b + (ok[k] ? i : sl_end - 1), sg, g.C);
+    }
+    // phase A: histogram, shifted by one so that the inclusive scan below yields exclusive starts
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        if (!ok[k]) continue;
+        int tiles[4];
+        const int nt = tri_tiles(rec[k].x, rec[k].y, g, tiles);
+        for (int j = 0; j < nt; ++j) atomicAdd(&cur[tiles[j] + 1], 1);
+    }
+    __syncthreads();
+    {   // inclusive scan of cur[0 .. nT] in place
+        const int per = (nT + 1 + SORT_THREADS - 1) / SORT_THREADS;
+        const int lo = threadIdx.x * per;
+        int sum = 0;
+        for (int i = lo; i < lo + per && i <= nT; ++i) sum += cur[i];
+        const int incl = block_incl_scan_256(sum, wsum);
+        int run = incl - sum;
+        for (int i = lo; i < lo + per && i <= nT; ++i) { run += cur[i]; cur[i] = run; }
+    }
+    __syncthreads();
+    const int total = cur[nT];
+    __shared__ unsigned int base_sh;
+    if (threadIdx.x == 0) base_sh = atomicAdd(alloc, (unsigned int)total);
+    __syncthreads();
+    const unsigned int base = base_sh;
+    for (int i = threadIdx.x; i <= nT; i += SORT_THREADS) tab[i] = (int)(base + (unsigned int)cur[i]);    // absolute starts
+    __syncthreads();                                     // rows stored before the cursors start moving
+    float4* region = recs + base;
+    // phase B: rank inside the tile by LDS integer atomic, stage in LDS
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        if (!ok[k]) continue;
+        int tiles[4];
+        const int nt = tri_tiles(rec[k].x, rec[k].y, g, tiles);
+        const float4 r4 = make_float4(rec[k].x, rec[k].y, rec[k].tn, rec[k].v);
+        for (int j = 0; j < nt; ++j) {
+            const int pos = atomicAdd(&cur[tiles[j]], 1);
+            if (pos < LCAP) buf[pos] = r4; else if (base + (unsigned int)pos < cap) region[pos] = r4;
+        }
+    }
+    __syncthreads();
+    const int staged = total < LCAP ? total : LCAP;
+    for (int i = threadIdx.x; i < staged; i += SORT_THREADS)
+        if (base + (unsigned int)i < cap) region[i] = buf[i];                      // whole, exclusively owned lines
+}
+
+constexpr int RUN_CHUNK = 64;            // slices whose runs are gathered per splat iteration: one per lane, kept in
+                                         // registers (wave scan + ds_bpermute search): no LDS beyond the accumulators, so
+                                         // four splat workgroups still fit a CU
+
+__global__ __launch_bounds__(THREADS) void tri_splat2_kernel(const float4* __restrict__ recs, const int* __restrict__ table,
+                                                             Geom g, int nSl, int count_mode, unsigned int cap,
+                                                             float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) long long acc[];
+    const int tile = blockIdx.x, s = blockIdx.y;
+    const int ty = tile / g.tilesX, tx = tile - ty * g.tilesX;
+    const int lds_n = g.C * g.TH * TW;
+    const int x_lo = tx * TW, y_lo = ty * g.TH;
+    auto splat = [&](const float4 r) {
+        const float x = r.x, y = r.y, tn = r.z, val = r.w;
+        const float fx = fminf(fmaxf(x, -8.0f), (float)g.W + 8.0f);
+        const float fy = fminf(fmaxf(y, -8.0f), (float)g.H + 8.0f);
+        // NaN/inf time: Tensor.int() gives INT_MIN on the CPU -> every corner masked
+        const int x0 = (int)fx, y0 = (int)fy, t0 = (fabsf(tn) < 1.0e9f) ? (int)tn : 0x40000000;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int xl = x0 + dx;
+            const int lx = xl - x_lo;
+            if (xl < 0 || xl >= g.W || lx < 0 || lx >= TW) continue;
+            // representations.py:39  value * (1-|xlim-x|) * (1-|ylim-y|) * (1-|tlim-t_norm|), float32
+            const float wx = __fmul_rn(val, __fsub_rn(1.0f, fabsf(__fsub_rn((float)xl, x))));
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const int yl = y0 + dy;
+                const int ly = yl - y_lo;
+                if (yl < 0 || yl >= g.Hout || ly < 0 || ly >= g.TH) continue;
+                const float wxy = __fmul_rn(wx, __fsub_rn(1.0f, fabsf(__fsub_rn((float)yl, y))));
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int tl = t0 + dt;
+                    if (tl < 0 || tl >= g.C) continue;
+                    float w = __fmul_rn(wxy, __fsub_rn(1.0f, fabsf(__fsub_rn((float)tl, tn))));
+                    if (count_mode) w = 1.0f;
+                    lds_add(&acc[(tl * g.TH + ly) * TW + lx], to_fix(w));
+                }
+            }
+        }
+    };
+    const int lane = threadIdx.x & 63;
+    for (int c0 = 0; c0 < nSl; c0 += RUN_CHUNK) {
+        const int nc = (nSl - c0 < RUN_CHUNK) ? nSl - c0 : RUN_CHUNK;
+        int cnt = 0;
+        unsigned int beg = 0;
+        if (lane < nc) {                                           // every wave keeps its own copy of the run table
+            const int* row = table + ((size_t)s * nSl + c0 + lane) * (g.nTiles + 2);
+            const int st = row[tile], en = row[tile + 1];            // absolute record indices
+            cnt = en - st;
+            beg = (unsigned int)st;
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += y;
+        }
+        const int excl = incl - cnt;
+        const int total = __shfl(incl, 63, 64);
+        // record jw0 + lane of the concatenated runs.  A wave's 64 consecutive indices span only a few runs: the first
+        // one is found with a scalar walk over readlane()d run starts (monotonic across calls), the following ones are
+        // folded in with one compare + select each - no per-lane search.
+        int r_wave = 0;                                            // wave-uniform cursor: last run with excl <= jw0
+        auto fetch = [&](int jw0) -> float4 {
+            const int j = jw0 + lane;
+            while (r_wave + 1 < nc && __builtin_amdgcn_readlane(excl, r_wave + 1) <= jw0) ++r_wave;
+            int my_ex = __builtin_amdgcn_readlane(excl, r_wave);
+            unsigned int my_beg = (unsigned int)__builtin_amdgcn_readlane((int)beg, r_wave);
+            for (int rr = r_wave + 1; rr < nc; ++rr) {
+                const int e = __builtin_amdgcn_readlane(excl, rr);
+                if (e > jw0 + 63) break;
+                const unsigned int b = (unsigned int)__builtin_amdgcn_readlane((int)beg, rr);
+                if (j >= e) { my_ex = e; my_beg = b; }
+            }
+            const unsigned int ri = my_beg + (unsigned int)(j - my_ex);
+            return (j < total && ri < cap) ? recs[ri] : make_float4(0.f, 0.f, 2.0e9f, 0.f);    // tn sentinel: no valid bin
+        };
+        const int wbase = (int)(threadIdx.x & ~63u);
+        float4 pre[PRE];
+#pragma unroll
+        for (int k = 0; k < PRE; ++k)                              // in flight under the LDS zero fill
+            pre[k] = (k * THREADS < total) ? fetch(k * THREADS + wbase) : make_float4(0.f, 0.f, 2.0e9f, 0.f);
+        if (c0 == 0) {
+            for (int i = threadIdx.x; i < lds_n; i += THREADS) acc[i] = 0;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < PRE; ++k)
+            if (k * THREADS < total) splat(pre[k]);
+        for (int j0 = PRE * THREADS; j0 < total; j0 += THREADS) splat(fetch(j0 + wbase));
+    }
+    __syncthreads();
+    write_tile(acc, out, g, s, g.C, tx, ty, false);
+}
+
 // Event histogram (a4): tiny; direct global atomics on a zeroed 2 x H x W image per segment.
 __global__ __launch_bounds__(THREADS) void hist_kernel(const int64_t* __restrict__ ev, const int64_t* __restrict__ seg_off,
                                                        int H, int W, float* __restrict__ out) {
@@ -553,8 +764,63 @@ size_t ws_layout(int64_t n_events, int n_seg, const Geom& g, Workspace* ws, void
     return need;
 }
 
+// v2 workspace: [alloc counter (256 B)] [table: n_seg x nSl x (nTiles + 2) ints] [records: up to 4 per event]
+size_t ws_layout_v2(int64_t n_events, int n_seg, const Geom& g, int nSl, size_t* o_table, size_t* o_recs) {
+    const size_t ot = 256;
+    const size_t orr = oess::align_up(ot + (size_t)n_seg * nSl * (g.nTiles + 2) * 4, 256);
+    if (o_table) *o_table = ot;
+    if (o_recs) *o_recs = orr;
+    return orr + (size_t)n_events * 4 * sizeof(float4);
+}
+
+template <typename Src>
+int run_tri_v1(Src src, const int64_t* seg_off, int n_seg, int64_t max_seg_len, int C, int H, int W, int crop_rows,
+               int count_mode, float* out, void* workspace, size_t workspace_bytes, hipStream_t st);
+
 template <typename Src>
 int run_tri(Src src, const int64_t* seg_off, int n_seg, int64_t max_seg_len, int C, int H, int W, int crop_rows,
+            int count_mode, float* out, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (n_seg <= 0 || C <= 0 || C > 64 || H <= 0 || W <= 0 || crop_rows < 0 || crop_rows >= H || !out || !seg_off)
+        return OESS_EINVAL;
+    if (max_seg_len < 0 || max_seg_len > 0x3fffffffll) return OESS_EINVAL;
+    static int impl = -1;
+    if (impl < 0) { const char* e = getenv("OESS_VOX_IMPL"); impl = (e && !strcmp(e, "v1")) ? 1 : 2; }
+    if (impl == 1)
+        return run_tri_v1(src, seg_off, n_seg, max_seg_len, C, H, W, crop_rows, count_mode, out, workspace, workspace_bytes, st);
+    Geom g = make_geom(C, H, W, crop_rows, max_seg_len);
+    if (g.nTiles > 8192) return OESS_EINVAL;
+    int64_t nsl64 = (max_seg_len + SSL - 1) / SSL;
+    if (nsl64 < 1) nsl64 = 1;
+    const int nSl = (int)nsl64;
+    size_t o_table, o_recs;
+    ws_layout_v2(0, n_seg, g, nSl, &o_table, &o_recs);
+    if (!workspace || workspace_bytes < o_recs + sizeof(float4)) return OESS_ENOMEM;
+    // record capacity of the caller's workspace (oess_voxelize_workspace_bytes sizes it for 4 records per event, the
+    // worst case); records beyond it are dropped rather than written out of bounds
+    size_t cap_sz = (workspace_bytes - o_recs) / sizeof(float4);
+    if (cap_sz > 0xffff0000ull) cap_sz = 0xffff0000ull;
+    const unsigned int cap = (unsigned int)cap_sz;
+    char* wb = (char*)workspace;
+    unsigned int* alloc = (unsigned int*)wb;
+    int* table = (int*)(wb + o_table);
+    float4* recs = (float4*)(wb + o_recs);
+    OESS_HIP(hipMemsetAsync(alloc, 0, 4, st));
+    Src src_c = src;
+    src_c.seg_base_index = 0;
+    const size_t sort_lds = (((size_t)(g.nTiles + 1 + 16) * 4 + 15) & ~(size_t)15) + (size_t)LCAP * sizeof(float4);
+    if (sort_lds + 64 > 160 * 1024)  // very fine tilings: the tile table does not fit beside the record buffer
+        return run_tri_v1(src, seg_off, n_seg, max_seg_len, C, H, W, crop_rows, count_mode, out, workspace, workspace_bytes, st);
+    OESS_HIP(hipFuncSetAttribute((const void*)&tri_sort_kernel<Src>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
+    hipLaunchKernelGGL((tri_sort_kernel<Src>), dim3(nSl, n_seg), dim3(SORT_THREADS), sort_lds, st, src_c, seg_off, g, nSl, table, alloc,
+                       recs, cap);
+    hipLaunchKernelGGL(tri_splat2_kernel, dim3(g.nTiles, n_seg), dim3(THREADS), (size_t)g.C * g.TH * TW * sizeof(long long), st,
+                       (const float4*)recs, (const int*)table, g, nSl, count_mode, cap, out);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+template <typename Src>
+int run_tri_v1(Src src, const int64_t* seg_off, int n_seg, int64_t max_seg_len, int C, int H, int W, int crop_rows,
             int count_mode, float* out, void* workspace, size_t workspace_bytes, hipStream_t st) {
     if (n_seg <= 0 || C <= 0 || C > 64 || H <= 0 || W <= 0 || crop_rows < 0 || crop_rows >= H || !out || !seg_off)
         return OESS_EINVAL;
@@ -629,7 +895,11 @@ size_t oess_voxelize_workspace_bytes(int64_t n_events, int n_seg, int64_t max_se
     if (n_events < 0 || n_seg <= 0 || max_seg_len < 0 || C <= 0 || H <= 0 || W <= 0 || crop_rows < 0 || crop_rows >= H)
         return 0;
     Geom g = make_geom(C, H, W, crop_rows, max_seg_len);
-    return ws_layout(n_events, n_seg, g, nullptr, nullptr, 0);
+    const size_t v1 = ws_layout(n_events, n_seg, g, nullptr, nullptr, 0);
+    int64_t nsl = (max_seg_len + SSL - 1) / SSL;
+    if (nsl < 1) nsl = 1;
+    const size_t v2 = ws_layout_v2(n_events, n_seg, g, (int)nsl, nullptr, nullptr);
+    return v1 > v2 ? v1 : v2;
 }
 
 int oess_voxelize_trilinear_f32(const float* x, const float* y, const float* p, const float* t,
