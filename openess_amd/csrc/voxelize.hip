@@ -4,14 +4,17 @@
 //   The reference scatters 8 (tri-linear) or 2 (nearest) read-modify-writes per event into a
 //   C x H x W grid.  Global fp32 atomics across the 8 non-coherent XCD L2s would execute
 //   memory-side, so the splat is made OUTPUT-STATIONARY and free of global atomics:
-//     A  count    workgroup (segment, slice): LDS histogram of its events per spatial tile,
-//                 stored (plain stores) to counts[segment][slice][tile]
-//     B  scan     per segment: exclusive scan in (tile, slice) order -> private cursor ranges;
-//                 then one scan over segment totals
-//     C  scatter  workgroup (segment, slice): cursors in LDS, rank = LDS integer atomic,
-//                 events -> tile-binned 16-byte records
-//     D  splat    workgroup (segment, tile): records -> LDS accumulators, then every output
-//                 voxel is written ONCE, coalesced (float4 per lane); no pre-zeroing pass.
+//     S  sort     workgroup (segment, slice of 4096 events): the events are loaded ONCE; LDS histogram per
+//                 spatial tile, LDS scan, rank by LDS integer atomic into an LDS record buffer, then one
+//                 coalesced block copy of the slice's tile-sorted 16-byte records (region from one global
+//                 atomic) + a row of absolute run starts per tile (plain stores)
+//     D  splat    workgroup (segment, tile): gathers its run from every slice of the segment (run starts
+//                 one per lane, wave scan, ds_bpermute search), records -> LDS accumulators, then every
+//                 output voxel is written ONCE, coalesced (float4 per lane); no pre-zeroing pass.
+//   (v1, kept for the nearest-xy path and as OESS_VOX_IMPL=v1: count -> two scans -> scatter -> splat; it reads
+//   the events twice and writes records into ~450-byte private cursor ranges whose boundary cache lines are
+//   shared between workgroups.  Measured B=8 x 2 M events: v1 0.578 / 0.780 ms (fp32 SoA / raw+rectify),
+//   v2 0.513 / 0.583 ms.)
 //   An event whose 2x2 pixel footprint straddles a tile edge is binned into each tile it touches
 //   (<= 4); each tile only accumulates the corners it owns.
 //
@@ -689,29 +692,27 @@ __global__ __launch_bounds__(THREADS) void tri_splat2_kernel(const float4* __res
         }
         const int excl = incl - cnt;
         const int total = __shfl(incl, 63, 64);
-        // record jw0 + lane of the concatenated runs.  A wave's 64 consecutive indices span only a few runs: the first
-        // one is found with a scalar walk over readlane()d run starts (monotonic across calls), the following ones are
-        // folded in with one compare + select each - no per-lane search.
-        int r_wave = 0;                                            // wave-uniform cursor: last run with excl <= jw0
-        auto fetch = [&](int jw0) -> float4 {
-            const int j = jw0 + lane;
-            while (r_wave + 1 < nc && __builtin_amdgcn_readlane(excl, r_wave + 1) <= jw0) ++r_wave;
-            int my_ex = __builtin_amdgcn_readlane(excl, r_wave);
-            unsigned int my_beg = (unsigned int)__builtin_amdgcn_readlane((int)beg, r_wave);
-            for (int rr = r_wave + 1; rr < nc; ++rr) {
-                const int e = __builtin_amdgcn_readlane(excl, rr);
-                if (e > jw0 + 63) break;
-                const unsigned int b = (unsigned int)__builtin_amdgcn_readlane((int)beg, rr);
-                if (j >= e) { my_ex = e; my_beg = b; }
+        // record j of the concatenated runs: per-lane binary search over the run starts held one per lane (ds_bpermute).
+        // All lanes take part in the shuffles (fixed trip count, j clamped); only the load is predicated.
+        // (Measured alternatives: run table in LDS + barriers 405 us - and 3 instead of 4 workgroups per CU -; a
+        // wave-uniform readlane walk 441 us; this form 348 us.)
+        auto fetch = [&](int j) -> float4 {
+            const bool valid = j < total;
+            const int jj = valid ? j : 0;
+            int lo = 0, hi = nc;                                   // largest run index with excl[idx] <= jj
+#pragma unroll
+            for (int step = 0; step < 6; ++step) {
+                const int mid = (lo + hi) >> 1;
+                const int v = __shfl(excl, mid, 64);
+                if (hi - lo > 1) { if (v <= jj) lo = mid; else hi = mid; }
             }
-            const unsigned int ri = my_beg + (unsigned int)(j - my_ex);
-            return (j < total && ri < cap) ? recs[ri] : make_float4(0.f, 0.f, 2.0e9f, 0.f);    // tn sentinel: no valid bin
+            const unsigned int ri = (unsigned int)__shfl((int)beg, lo, 64) + (unsigned int)(jj - __shfl(excl, lo, 64));
+            return (valid && ri < cap) ? recs[ri] : make_float4(0.f, 0.f, 2.0e9f, 0.f);    // tn sentinel: no valid bin
         };
-        const int wbase = (int)(threadIdx.x & ~63u);
         float4 pre[PRE];
 #pragma unroll
         for (int k = 0; k < PRE; ++k)                              // in flight under the LDS zero fill
-            pre[k] = (k * THREADS < total) ? fetch(k * THREADS + wbase) : make_float4(0.f, 0.f, 2.0e9f, 0.f);
+            pre[k] = (k * THREADS < total) ? fetch(k * THREADS + (int)threadIdx.x) : make_float4(0.f, 0.f, 2.0e9f, 0.f);
         if (c0 == 0) {
             for (int i = threadIdx.x; i < lds_n; i += THREADS) acc[i] = 0;
             __syncthreads();
@@ -719,7 +720,7 @@ __global__ __launch_bounds__(THREADS) void tri_splat2_kernel(const float4* __res
 #pragma unroll
         for (int k = 0; k < PRE; ++k)
             if (k * THREADS < total) splat(pre[k]);
-        for (int j0 = PRE * THREADS; j0 < total; j0 += THREADS) splat(fetch(j0 + wbase));
+        for (int j0 = PRE * THREADS; j0 < total; j0 += THREADS) splat(fetch(j0 + (int)threadIdx.x));
     }
     __syncthreads();
     write_tile(acc, out, g, s, g.C, tx, ty, false);
