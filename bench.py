@@ -17,6 +17,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC for RCCL on this host driver (before torch loads HIP)
+
 import numpy as np
 import torch
 import torch.distributed as dist
