@@ -173,7 +173,7 @@ int oess_confusion_accumulate(const int64_t* pred, const int64_t* label, int64_t
  *   with ConvLSTM gate-interleaved rows for oess_convlstm_fused_bf16.
  * oess_conv2d_fwd_bf16: out = act(conv(in, w) + bias [+ residual]); Cin must be a multiple of 8
  *   (pad the channel dimension; padded weights are zero).  Exactly one of out_bf16 / out_f32 is used
- *   (out_f32 wins when non-null).  Pixel strides are in ELEMENTS.
+ *   (out_f32 wins when non-null).  Pixel strides are in ELEMENTS.  relu: 0 = none, 1 = ReLU, 2 = GELU (erf form).
  * ------------------------------------------------------------------------------------------ */
 size_t oess_conv2d_packed_bytes(int Cout, int Cin, int R, int S, int flip_for_dgrad);
 int oess_conv2d_pack_weight(const float* w_oihw, int Cout, int Cin, int R, int S, int flip_for_dgrad, void* packed,
@@ -279,6 +279,22 @@ int oess_l2norm_nhwc_fwd(const void* x, long long x_pix_stride, int64_t P, int C
                          long long y_pix_stride, float* inv_norm, oess_stream_t stream);
 int oess_l2norm_nhwc_bwd(const void* y, long long y_pix_stride, const void* grad_y, long long gy_pix_stride, const float* inv_norm,
                          int64_t P, int C, int is_bf16, float eps, void* grad_x, long long gx_pix_stride, oess_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MaskCLIP ViT-B/16 image tower (models/maskclip_model.py:448-541 TransformerEncoderLayer, :545-851 VisionTransformer):
+ * the non-GEMM pieces.  The linear layers (patch embedding, in_proj, out_proj, FFN, proj) run on oess_conv2d_fwd_bf16 as
+ * 1x1 / 16x16 convolutions over the token axis (bias, residual and GELU fused in the epilogue).
+ *   oess_layernorm_bf16: y = (x - mean) * rsqrt(var + eps) * gamma + beta over C channels of each of `rows` tokens
+ *     (nn.LayerNorm, eps 1e-6 in the ViT; build_norm_layer(dict(type='LN', eps=1e-6)) :486-501,:706-718).
+ *   oess_attention_d64_bf16: softmax(Q K^T * scale) V for head dimension 64; qkv = nn.MultiheadAttention's packed
+ *     in_proj output [B, L, 3 * heads * 64] (q | k | v), out = [B, L, heads * 64] before out_proj
+ *     (mmcv MultiheadAttention -> nn.MultiheadAttention.forward, :496-497,:538).
+ * Row strides in elements (multiples of 8), pointers 16-byte aligned.
+ * ------------------------------------------------------------------------------------------ */
+int oess_layernorm_bf16(const void* x, long long x_row_stride, int64_t rows, int C, const float* gamma, const float* beta, float eps,
+                        void* y, long long y_row_stride, oess_stream_t stream);
+int oess_attention_d64_bf16(const void* qkv, long long qkv_row_stride, int B, int L, int heads, float scale, void* out,
+                            long long out_row_stride, oess_stream_t stream);
 
 /* Weight gradient of oess_conv2d_fwd_bf16's convolution: dW (OIHW fp32, ACCUMULATED into: zero it first)
  * from x (NHWC bf16, Cin_x >= Cin channels present, Cin_x % 8 == 0) and dy (NHWC bf16, Cout % 8 == 0).

@@ -65,6 +65,13 @@ struct ConvArgs {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
+// epilogue activation: 0 none, 1 ReLU, 2 GELU (exact erf form = nn.GELU(), the ViT FFN of models/maskclip_model.py)
+__device__ __forceinline__ float conv_act(float v, int mode) {
+    if (mode == 1) return fmaxf(v, 0.0f);
+    if (mode == 2) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    return v;
+}
+
 // PITCH: row pitch (elements) of the bf16 LDS image.  BN + 8 pads the image; BN (no padding) makes it exactly one
 // ring stage (the persistent kernel parks it in the stage it has just finished reading) and still reads conflict
 // free: the 16-lane groups of ds_read_b128 cover 16 distinct 16-byte chunks of a 256-byte row pair.
@@ -93,7 +100,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
                     const int m = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                     if (m < a.M && n < a.Cout) {
                         float v = acc[i][j][e] + bv;
-                        if (a.relu) v = fmaxf(v, 0.0f);
+                        v = conv_act(v, a.relu);
                         a.out_f32[(long long)m * a.out_pix_stride + n] = v;
                     }
                 }
@@ -175,7 +182,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
             for (int q = 0; q < 8; ++q) {
                 float f = bf16_to_f32(u.h[q]);
                 if (a.residual) f += bf16_to_f32(rs.h[q]);
-                if (a.relu) f = fmaxf(f, 0.0f);
+                f = conv_act(f, a.relu);
                 u.h[q] = f32_to_bf16(f);
             }
         }
@@ -890,7 +897,7 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvArgs a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 v[k] = acc[t][q * 4 + k] + ((a.bias && ch + k < a.Cout) ? a.bias[ch + k] : 0.0f);
-                if (a.relu) v[k] = fmaxf(v[k], 0.0f);
+                v[k] = conv_act(v[k], a.relu);
             }
             uint2 o;
             o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);

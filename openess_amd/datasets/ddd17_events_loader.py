@@ -108,7 +108,8 @@ class DDD17Events(Dataset):
         if self.normalize_event:
             vox = torch.stack([hip.masked_normalize(v.contiguous()) for v in vox])
         if self.resize:
-            vox = f.interpolate(vox, size=tuple(self.shape_resize), mode='bilinear', align_corners=True)
+            # F.interpolate(bilinear, align_corners=True) 260x346 -> 260x352 (:183-189) on the HIP resampler
+            vox = hip.bilinear_resize(vox, size=tuple(self.shape_resize), align_corners=True).contiguous()
         vox = vox.reshape(len(events_list), nwin * C, vox.shape[-2], vox.shape[-1])
         return vox[:, :, :-60, :].contiguous()
 

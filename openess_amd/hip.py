@@ -564,6 +564,36 @@ def convlstm_fused(xh, packed_gates, bias, cell, hidden_out, k, pad, prev_cell_i
     return y
 
 
+# ------------------------------------------------------------------------------------------ ViT pieces (MaskCLIP tower)
+def layer_norm_tokens(x, gamma, beta, eps=1e-6, out=None):
+    """nn.LayerNorm over the last axis of a bf16 token matrix [rows, C] (row-strided views are fine)."""
+    lib = _lib.load()
+    _need_gpu(x)
+    if x.dtype != torch.bfloat16 or x.ndim != 2 or x.stride(1) != 1:
+        raise ValueError("layer_norm_tokens: bf16 [rows, C] with dense channels")
+    rows, C = x.shape
+    if out is None:
+        out = torch.empty((rows, C), dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.oess_layernorm_bf16(_ptr(x), x.stride(0), rows, C, _ptr(gamma), _ptr(beta), float(eps), _ptr(out), out.stride(0),
+                                       _stream()), "oess_layernorm_bf16")
+    return out
+
+
+def attention_d64(qkv, B, L, heads, out=None):
+    """softmax(Q K^T / 8) V per head (head dim 64) from nn.MultiheadAttention's packed in_proj output [B*L, 3*heads*64]
+    (bf16) -> [B*L, heads*64] (bf16), i.e. the attention output before out_proj."""
+    lib = _lib.load()
+    _need_gpu(qkv)
+    C = heads * 64
+    if qkv.dtype != torch.bfloat16 or qkv.ndim != 2 or qkv.shape != (B * L, 3 * C) or qkv.stride(1) != 1:
+        raise ValueError("attention_d64: qkv must be bf16 [B*L, 3*heads*64]")
+    if out is None:
+        out = torch.empty((B * L, C), dtype=torch.bfloat16, device=qkv.device)
+    _lib.check(lib.oess_attention_d64_bf16(_ptr(qkv), qkv.stride(0), B, L, heads, 0.125, _ptr(out), out.stride(0), _stream()),
+               "oess_attention_d64_bf16")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ norms / resampling
 def _norm_forward(x_nhwc, G, gamma, beta, eps, relu, residual, running=None, momentum=0.1, out=None):
     """Shared BatchNorm(train)/InstanceNorm forward on an NHWC bf16 view.  Returns (out, mean, rstd)."""
