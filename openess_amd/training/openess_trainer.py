@@ -6,8 +6,11 @@ Only the `frame2recon` option with `if_spatial_contrastive: True` is runnable in
 (openess_trainer.py:478-529): `recon2voxel` references an undefined `superpixels` (:379 vs :408-409) and
 `frame2voxel` computes an unused contrastive value while trainEpoch reads a key that was never written
 (:464-475, :307-308).  Those two branches raise NotImplementedError here instead of being silently "fixed".
-The MaskCLIP tower the reference constructs (:107-114) is never called by any step and is not built
-(SURVEY.md 8f row 1)."""
+The MaskCLIP tower the reference constructs (:107-114) is never called by any of its steps; it is built here (frozen,
+`models_dict['model_clip']`) when the three files it needs exist, and is available as an online teacher
+(`self.model_clip(frame) -> logits`), see openess_amd/models/maskclip_model.py."""
+import os
+
 import torch
 import torch.nn.functional as f
 
@@ -27,6 +30,12 @@ class OpenESSModel(BaseTrainer):
                                         output_stride=s.output_stride, pretrained_backbone=s.pretrained_backbone)
         self.model_recon, self.model_frame = mk(), mk()
         self.models_dict = {'model_recon': self.model_recon, 'model_frame': self.model_frame}
+        paths = [getattr(s, k, None) for k in ('text_embeddings_path', 'visual_projs_path', 'maskclip_checkpoint')]
+        if all(p and os.path.isfile(p) for p in paths):                     # openess_trainer.py:107-114
+            from ..models.maskclip_model import maskClipFeatureExtractor
+            self.model_clip = maskClipFeatureExtractor(text_embeddings_path=paths[0], visual_projs_path=paths[1],
+                                                       text_categories=s.semseg_num_classes, maskclip_checkpoint=paths[2])
+            self.models_dict['model_clip'] = self.model_clip
         for m in self.models_dict.values():
             m.to(self.device)
         self.task_loss = TaskLoss(losses=list(s.task_loss), gamma=2.0, num_classes=s.semseg_num_classes, ignore_index=255)
