@@ -38,12 +38,14 @@ def test_layernorm_and_attention_kernels():
     y = hip.layer_norm_tokens(x, g, b, 1e-6)
     ref = torch.nn.functional.layer_norm(x.float(), (C,), g, b, 1e-6)
     np.testing.assert_allclose(y.float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=1e-2)
-    qkv = (torch.randn(B * L, 3 * C, device="cuda") * 1.5).bfloat16()
-    o = hip.attention_d64(qkv, B, L, heads)
-    q, k, v = (t.view(B, L, heads, 64).permute(0, 2, 1, 3) for t in qkv.float().split(C, dim=1))
-    att = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v
-    ref = att.permute(0, 2, 1, 3).reshape(B * L, C)
-    np.testing.assert_allclose(o.float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=1e-2)
+    for B, L in ((2, 77), (1, 32), (3, 130), (1, 1121)):          # ragged key / query tiles, the full-size token count
+        qkv = (torch.randn(B * L, 3 * C, device="cuda") * 1.5).bfloat16()
+        o = hip.attention_d64(qkv, B, L, heads)
+        q, k, v = (t.view(B, L, heads, 64).permute(0, 2, 1, 3) for t in qkv.float().split(C, dim=1))
+        att = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v
+        ref = att.permute(0, 2, 1, 3).reshape(B * L, C)
+        # P is rounded to bf16 before the P V product (MFMA operand): 2^-8 relative on each weight
+        np.testing.assert_allclose(o.float().cpu().numpy(), ref.cpu().numpy(), rtol=2e-2, atol=2e-2)
 
 
 @pytest.mark.parametrize("img_size,hw", [((32, 32), (48, 80)), ((32, 48), (40, 70))])
