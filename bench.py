@@ -109,7 +109,10 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="frame2voxel_pixel_distill",
-                    choices=["frame2voxel_pixel_distill", "frame2voxel_full", "frame2recon_full"])
+                    choices=["frame2voxel_pixel_distill", "frame2voxel_full", "frame2recon_full",
+                             "frame2voxel_pixel_distill_online"],
+                    help="..._online: the pseudo-labels are argmax of the frozen MaskCLIP ViT-B/16 tower run inside the step "
+                         "(SURVEY 8f rank 1) instead of the offline PNG labels the reference reads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -128,7 +131,12 @@ def main():
     from openess_amd.training.ddp import GradAllReduce, broadcast_module_states
     from openess_amd.training.pretrain_step import PretrainStep
 
-    contrastive = a.workload != "frame2voxel_pixel_distill"
+    contrastive = a.workload in ("frame2voxel_full", "frame2recon_full")
+    online_teacher = None
+    if a.workload.endswith("_online"):
+        from openess_amd.models.maskclip_model import maskClipFeatureExtractor
+        torch.manual_seed(1205)
+        online_teacher = maskClipFeatureExtractor(text_categories=11).to(device).eval()
     option = "frame2recon" if a.workload.startswith("frame2recon") else "frame2voxel"
     step = PretrainStep(config_option=option, img_size=(H_NET, W_SENSOR), nr_events_data=NWIN, nr_temporal_bins=C,
                         if_spatial_contrastive=contrastive, superpixel_size=100, device=device)
@@ -143,7 +151,8 @@ def main():
         hip.voxelize_dsec_raw(ev["x"], ev["y"], ev["t"], ev["p"], ev["maps"], ev["seg_map"], ev["seg"], C, H_SENSOR,
                               W_SENSOR, crop_rows=CROP, out=voxels.view(B * NWIN * C, H_NET, W_SENSOR))
         first = frame if option == "frame2recon" else voxels
-        batch = (first, None, frame, pl, sp, S)
+        labels = pl if online_teacher is None else online_teacher(frame).argmax(dim=1)
+        batch = (first, None, frame, labels, sp, S)
         for opt in step.optimizers_dict.values():
             opt.zero_grad()
         t_loss, losses, _ = step.task_train_step(batch)
