@@ -606,6 +606,186 @@ __global__ __launch_bounds__(BMX * 2) void conv_fwd_dma_kernel(ConvArgs a) {
 }
 
 // =================================================================================================
+// v4: BK = 32 slabs in a 4-deep LDS ring (same 64 KB per workgroup, still 2 workgroups per CU).
+// The 2-stage BK = 64 kernel has ONE slab in flight per workgroup and must hide the whole L2 -> LDS round trip
+// (~1.0-1.3 us under load) behind one slab of MFMAs (0.54 us when two workgroups share the CU): it is latency bound
+// (tools/conv_ablate.py).  Here three 32-wide slabs are in flight (48 KB instead of 32 KB per workgroup) and a slab
+// is issued three compute phases before it is needed.  64-byte LDS rows: chunk c of row r lives at
+// c ^ ((r >> 2) & 3) (conflict free for the ds_read_b128 lane groups), one wave DMA instruction covers 16 rows.
+// =================================================================================================
+template <int BN, bool FASTK, int EPI = 0>
+__global__ __launch_bounds__(256) void conv_fwd_dma32_kernel(ConvArgs a) {
+    constexpr int BMX = 128, BKS = 32, NST = 4, NWAVES = 4;
+    constexpr int WAVES_N = (BN == 128) ? 2 : 1;
+    constexpr int WAVES_M = NWAVES / WAVES_N;
+    constexpr int WM = BMX / WAVES_M;
+    constexpr int WN = BN / WAVES_N;
+    constexpr int MT = WM / 32, NT = WN / 32;
+    constexpr int A_INSTR = BMX / 16 / NWAVES;        // 2: 16 rows x 64 B per wave instruction
+    constexpr int B_INSTR = BN / 16 / NWAVES;         // 2 (BN = 128) or 1 (BN = 64)
+    constexpr int IPS = A_INSTR + B_INSTR;
+    constexpr int A_BYTES = BMX * 64;
+    constexpr int STAGE_BYTES = (BMX + BN) * 64;
+    constexpr int NFRAG = MT + NT;
+    static_assert(BN == 128 || BN == 64, "BN");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nwg = a.tiles_m * a.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
+    const int m0 = tile_m * BMX, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int KT = a.Kpad / BKS;
+    const int cpt = a.Cin >> 3, ntaps = a.R * a.S;
+
+    const long long in_bytes = (((long long)a.B * a.H * a.W - 1) * a.in_pix_stride + a.Cin) * 2;
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7ffffff0, 0x00020000);
+
+    const int lrow = lane >> 2, slot = lane & 3;       // 16 rows x 4 chunk slots per wave instruction
+    int iy0[A_INSTR], ix0[A_INSTR], rowoff[A_INSTR], csrc[A_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int r = (wave * A_INSTR + i) * 16 + lrow;
+        const int m = m0 + r;
+        const bool valid = m < a.M;
+        const int mm = valid ? m : 0;
+        const int hw = a.Ho * a.Wo;
+        const int b = mm / hw, rem = mm - b * hw;
+        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        iy0[i] = valid ? oy * a.stride - a.pad : -0x4000;
+        ix0[i] = ox * a.stride - a.pad;
+        rowoff[i] = (int)((((long long)b * a.H + (oy * a.stride - a.pad)) * a.W + ix0[i]) * a.in_pix_stride * 2);
+        csrc[i] = slot ^ ((r >> 2) & 3);
+    }
+    int boff[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int r = (wave * B_INSTR + i) * 16 + lrow;
+        boff[i] = ((n0 + r) * a.Kpad + (slot ^ ((r >> 2) & 3)) * 8) * 2;
+    }
+
+    auto issue = [&](int kt) {
+        unsigned char* st = smem + (kt & (NST - 1)) * STAGE_BYTES;
+        if constexpr (FASTK) {
+            const unsigned kc0 = (unsigned)(kt * 4);
+            const unsigned tap = (kc0 * a.inv_cpt) >> 20;
+            const int cc0 = (int)(kc0 - tap * cpt);
+            const unsigned r = (tap * a.inv_s) >> 16;
+            const int sx = (int)(tap - r * a.S);
+            const int dy = (int)r * a.dil, dx = sx * a.dil;
+            const int tapoff = ((dy * a.W + dx) * (int)a.in_pix_stride + cc0 * 8) * 2;
+            const bool tap_ok = (int)tap < ntaps;
+#pragma unroll
+            for (int i = 0; i < A_INSTR; ++i) {
+                const bool ok = tap_ok && (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
+                const unsigned voff = ok ? (unsigned)(rowoff[i] + csrc[i] * 16 + tapoff) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave * A_INSTR + i) * 1024),
+                                                         16, voff, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_INSTR; ++i) {
+                const unsigned kc = (unsigned)(kt * 4 + csrc[i]);
+                const unsigned tap = (kc * a.inv_cpt) >> 20;
+                const int cc = (int)(kc - tap * cpt);
+                const unsigned r = (tap * a.inv_s) >> 16;
+                const int sx = (int)(tap - r * a.S);
+                const int dy = (int)r * a.dil, dx = sx * a.dil;
+                const bool ok = (int)tap < ntaps && (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
+                const unsigned voff = ok ? (unsigned)(rowoff[i] + ((dy * a.W + dx) * (int)a.in_pix_stride + cc * 8) * 2) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave * A_INSTR + i) * 1024),
+                                                         16, voff, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(st + A_BYTES + (wave * B_INSTR + i) * 1024),
+                                                     16, (unsigned)(boff[i] + kt * BKS * 2), 0, 0, 0);
+    };
+
+    f32x16_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    uint32_t fa_off[MT], fb_off[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa_off[i] = (uint32_t)(wm * WM + i * 32 + (lane & 31)) * 64;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb_off[j] = (uint32_t)(A_BYTES + (wn * WN + j * 32 + (lane & 31)) * 64);
+    const int half = lane >> 5;
+    const int rsw = ((lane & 31) >> 2) & 3;
+    const uint32_t sl0 = (uint32_t)(((0 + half) ^ rsw) * 16), sl1 = (uint32_t)(((2 + half) ^ rsw) * 16);
+
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < KT) issue(s);
+
+#define OESS_FR32(DST_A, DST_B, SL)                                                                              \
+    {                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                           \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(DST_A[i]) : "v"(stage_ + fa_off[i] + SL) : "memory");     \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                           \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(DST_B[j]) : "v"(stage_ + fb_off[j] + SL) : "memory");     \
+    }
+#define OESS_MMA32(SRC_A, SRC_B)                                                                                 \
+    {                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                           \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                       \
+                acc[i][j] = (EPI == 1) ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(SRC_B[j], SRC_A[i], acc[i][j], 0, 0, 0)     \
+                                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(SRC_A[i], SRC_B[j], acc[i][j], 0, 0, 0);   \
+    }
+#define OESS_WAIT32(N_, FA_, FB_)                                                                                \
+    {                                                                                                            \
+        if constexpr (MT == 2 && NT == 2)                                                                        \
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(FA_[0]), "+v"(FA_[1]), "+v"(FB_[0]), "+v"(FB_[1]) : "n"(N_) : "memory"); \
+        else                                                                                                     \
+            asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(FA_[0]), "+v"(FB_[0]), "+v"(FB_[1]) : "n"(N_) : "memory"); \
+    }
+
+    for (int kt = 0; kt < KT; ++kt) {
+        // retire slab kt; up to two younger slabs stay in flight across the barrier
+        if (kt + 2 < KT) {
+            if constexpr (IPS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else if (kt + 1 < KT) {
+            if constexpr (IPS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                   // slab kt visible to every wave; the stage of slab kt-1 is free
+        if (kt + NST - 1 < KT) issue(kt + NST - 1);
+        const uint32_t stage_ = lds0 + (uint32_t)((kt & (NST - 1)) * STAGE_BYTES);
+        bf16x8_t fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+        OESS_FR32(fa0, fb0, sl0)
+        OESS_FR32(fa1, fb1, sl1)
+        OESS_WAIT32(NFRAG, fa0, fb0)
+        OESS_MMA32(fa0, fb0)
+        OESS_WAIT32(0, fa1, fb1)
+        OESS_MMA32(fa1, fb1)
+    }
+#undef OESS_FR32
+#undef OESS_MMA32
+#undef OESS_WAIT32
+    __syncthreads();
+
+    if constexpr (EPI == 1) lstm_epilogue(a, acc, smem, m0, n0, wm, wn, lane, tid);
+    else conv_epilogue<BMX, BN>(a, acc, smem, m0, n0, wm, wn, lane, tid);
+}
+
+// =================================================================================================
 // v3: PERSISTENT LDS-DMA kernel.  Same tile, ring and fragment pipeline as conv_fwd_dma_kernel<128, BN, 2>,
 // but one workgroup walks a strided list of output tiles of its XCD:
 //   * the first K-slab of the NEXT tile is DMA'd under the last K-slab of the current one, so a tile's
@@ -1033,6 +1213,7 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
             else if (!strcmp(e, "dma2")) impl = 2;
             else if (!strcmp(e, "dma3")) impl = 3;
             else if (!strcmp(e, "persist")) impl = 4;
+            else if (!strcmp(e, "dma32")) impl = 5;
         }
         const void* fns[] = {(const void*)&conv_fwd_kernel<128>, (const void*)&conv_fwd_kernel<64>, (const void*)&conv_fwd_kernel<32>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<128, 64, 2, false>, (const void*)&conv_fwd_dma_kernel<128, 32, 2, false>,
@@ -1041,6 +1222,9 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
                              (const void*)&conv_fwd_dma_kernel<256, 128, 3, false>, (const void*)&conv_fwd_dma_kernel<256, 128, 3, true>,
                              (const void*)&conv_fwd_dma_kernel<256, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<256, 128, 2, true>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 2, false, 1>, (const void*)&conv_fwd_dma_kernel<128, 128, 2, true, 1>,
+                             (const void*)&conv_fwd_dma32_kernel<128, false, 0>, (const void*)&conv_fwd_dma32_kernel<128, true, 0>,
+                             (const void*)&conv_fwd_dma32_kernel<64, false, 0>, (const void*)&conv_fwd_dma32_kernel<64, true, 0>,
+                             (const void*)&conv_fwd_dma32_kernel<128, false, 1>, (const void*)&conv_fwd_dma32_kernel<128, true, 1>,
                              (const void*)&conv_fwd_persist_kernel<128, false>, (const void*)&conv_fwd_persist_kernel<64, false>, (const void*)&conv_fwd_persist_kernel<32, false>,
                              (const void*)&conv_fwd_persist_kernel<128, true>, (const void*)&conv_fwd_persist_kernel<64, true>, (const void*)&conv_fwd_persist_kernel<32, true>};
         for (const void* f : fns)      // > 64 KiB of dynamic LDS needs an explicit opt-in
@@ -1067,6 +1251,7 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
     const dim3 grid(a.tiles_m * a.tiles_n), block(CONV_THREADS);
     const size_t tab = (size_t)(a.Kpad / 8) * 8;
     const bool fastk = (Cin % 64) == 0 && !getenv("OESS_CONV_NOFASTK");
+    const bool fastk32 = (Cin % 32) == 0 && !getenv("OESS_CONV_NOFASTK");
     const size_t epi = (size_t)BM * (bn + 8) * 2 + 4096;     // output image + BatchNorm partials
 #define OESS_LAUNCH_V1(BN_)                                                                  \
     {                                                                                        \
@@ -1089,10 +1274,21 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
         if (fastk) hipLaunchKernelGGL((conv_fwd_persist_kernel<BN_, true>), pgrid, block, lds, st, a);   \
         else hipLaunchKernelGGL((conv_fwd_persist_kernel<BN_, false>), pgrid, block, lds, st, a);        \
     }
+#define OESS_LAUNCH_DMA32(BN_)                                                               \
+    {                                                                                        \
+        if (BN_ >= 64) {                                                                     \
+            constexpr int BNX = BN_ >= 64 ? BN_ : 64;                                        \
+            size_t lds = (size_t)4 * (BM + BNX) * 64;                                        \
+            if (lds < epi) lds = epi;                                                        \
+            if (fastk32) hipLaunchKernelGGL((conv_fwd_dma32_kernel<BNX, true, 0>), grid, block, lds, st, a);   \
+            else hipLaunchKernelGGL((conv_fwd_dma32_kernel<BNX, false, 0>), grid, block, lds, st, a);          \
+        } else OESS_LAUNCH_DMA(BN_, 2)                                                       \
+    }
 #define OESS_DISPATCH(BN_)                                                                   \
     switch (use) {                                                                           \
         case 2: OESS_LAUNCH_DMA(BN_, 2) break;                                               \
         case 4: OESS_LAUNCH_PERSIST(BN_) break;                                              \
+        case 5: OESS_LAUNCH_DMA32(BN_) break;                                                \
         case 3: OESS_LAUNCH_DMA(BN_, 3) break;                                               \
         default: OESS_LAUNCH_V1(BN_) break;                                                  \
     }
@@ -1109,6 +1305,10 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
     if (lstm) {     // fused ConvLSTM cell update: transposed MFMA + lane-local gate algebra (needs the LDS-DMA kernel)
         if (use < 2) return OESS_EINVAL;
         const size_t lds = (size_t)2 * (BM + 128) * 8 * 16;
+        if (use == 5) {
+            if (fastk32) hipLaunchKernelGGL((conv_fwd_dma32_kernel<128, true, 1>), grid, block, lds, st, a);
+            else hipLaunchKernelGGL((conv_fwd_dma32_kernel<128, false, 1>), grid, block, lds, st, a);
+        } else
         if (fastk) hipLaunchKernelGGL((conv_fwd_dma_kernel<128, 128, 2, true, 1>), grid, block, lds, st, a);
         else hipLaunchKernelGGL((conv_fwd_dma_kernel<128, 128, 2, false, 1>), grid, block, lds, st, a);
         OESS_HIP(hipGetLastError());
@@ -1142,6 +1342,7 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
 #undef OESS_DISPATCH
 #undef OESS_LAUNCH_DMA
 #undef OESS_LAUNCH_PERSIST
+#undef OESS_LAUNCH_DMA32
 #undef OESS_LAUNCH_V1
     OESS_HIP(hipGetLastError());
     return OESS_OK;
