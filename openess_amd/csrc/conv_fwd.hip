@@ -65,6 +65,9 @@ struct ConvArgs {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
+// threads per workgroup of the LDS-DMA kernel by tile height: 64- and 128-row tiles 4 waves, 256-row tiles 8 waves
+constexpr int conv_tile_threads(int bmx) { return bmx == 256 ? 512 : 256; }
+
 // epilogue activation: 0 none, 1 ReLU, 2 GELU (exact erf form = nn.GELU(), the ViT FFN of models/maskclip_model.py)
 __device__ __forceinline__ float conv_act(float v, int mode) {
     if (mode == 1) return fmaxf(v, 0.0f);
@@ -77,10 +80,10 @@ __device__ __forceinline__ float conv_act(float v, int mode) {
 // free: the 16-lane groups of ds_read_b128 cover 16 distinct 16-byte chunks of a 256-byte row pair.
 template <int BMX, int BN, int PITCH = BN + 8>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
-                                              f32x16_t (&acc)[BMX / ((BMX * 2 / 64) / ((BN == 128) ? 2 : 1)) / 32][(BN / ((BN == 128) ? 2 : 1)) / 32],
+                                              f32x16_t (&acc)[BMX / ((conv_tile_threads(BMX) / 64) / ((BN == 128) ? 2 : 1)) / 32][(BN / ((BN == 128) ? 2 : 1)) / 32],
                                               unsigned char* smem, int m0, int n0, int wm, int wn, int lane, int tid,
                                               float* red_override = nullptr) {
-    constexpr int NTHREADS = BMX * 2;
+    constexpr int NTHREADS = conv_tile_threads(BMX);
     constexpr int WAVES_N = (BN == 128) ? 2 : 1;
     constexpr int WAVES_M = (NTHREADS / 64) / WAVES_N;
     constexpr int WM = BMX / WAVES_M;
@@ -413,8 +416,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_fwd_kernel(ConvArgs a) {
 // FASTK: Cin % 64 == 0, i.e. every 64-wide K-slab lies inside ONE filter tap -> the tap decode is wave-uniform
 // (scalar) and the per-lane part of a gather address is a constant.
 template <int BMX, int BN, int NSTAGE, bool FASTK, int EPI = 0>
-__global__ __launch_bounds__(BMX * 2) void conv_fwd_dma_kernel(ConvArgs a) {
-    constexpr int NTHREADS = BMX * 2;                // 128-row tile: 4 waves, 256-row tile: 8 waves
+__global__ __launch_bounds__(conv_tile_threads(BMX)) void conv_fwd_dma_kernel(ConvArgs a) {
+    constexpr int NTHREADS = conv_tile_threads(BMX); // 64 / 128-row tile: 4 waves, 256-row tile: 8 waves
     constexpr int NWAVES = NTHREADS / 64;
     constexpr int WAVES_N = (BN == 128) ? 2 : 1;
     constexpr int WAVES_M = NWAVES / WAVES_N;
@@ -1313,6 +1316,27 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
         else hipLaunchKernelGGL((conv_fwd_dma_kernel<128, 128, 2, false, 1>), grid, block, lds, st, a);
         OESS_HIP(hipGetLastError());
         return OESS_OK;
+    }
+    // 64 x 128 tiles (48 KB of LDS: 3 workgroups per CU) when the 128-row tiling leaves most of its last round of
+    // workgroups empty: e.g. 550 tiles over 512 slots run as two rounds at 54 % - 1100 half tiles over 768 slots do not.
+    static int small_m = -1;
+    if (small_m < 0) { const char* e = getenv("OESS_CONV_BM64"); small_m = e ? atoi(e) : 1; }
+    if (use == 2 && small_m && bn == 128 && !tile_stats) {
+        const long long t128 = (long long)a.tiles_m * a.tiles_n;
+        const long long t64 = (long long)((a.M + 63) / 64) * a.tiles_n;
+        const double e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
+        const double e64 = 0.88 * (double)t64 / (double)(((t64 + 767) / 768) * 768);      // 0.88: measured per-tile efficiency
+        if (small_m == 2 || e64 > e128 * 1.04) {
+            a.tiles_m = (a.M + 63) / 64;
+            const dim3 grid64(a.tiles_m * a.tiles_n);
+            size_t lds = (size_t)2 * (64 + 128) * 8 * 16;
+            const size_t epi64 = (size_t)64 * (128 + 8) * 2 + 4096;
+            if (lds < epi64) lds = epi64;
+            if (fastk) hipLaunchKernelGGL((conv_fwd_dma_kernel<64, 128, 2, true>), grid64, block, lds, st, a);
+            else hipLaunchKernelGGL((conv_fwd_dma_kernel<64, 128, 2, false>), grid64, block, lds, st, a);
+            OESS_HIP(hipGetLastError());
+            return OESS_OK;
+        }
     }
     // 256 x 128 tile, 8 waves, 1 workgroup per CU: 25 % fewer L2->LDS bytes per FLOP.  Measured neutral against the
     // 128-row kernel (tools/conv_ablate.py: +-3 % per layer) because the wave tile, hence the LDS fragment traffic,

@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openess_amd import hip
 SHAPES = {"gates": (8, 110, 160, 256, 512, 3, 1, 1, 1), "l3": (8, 55, 80, 256, 256, 3, 1, 4, 4),
           "pw": (8, 55, 80, 256, 1024, 1, 1, 0, 1), "l4": (8, 55, 80, 512, 512, 3, 1, 8, 8),
-          "head": (8, 440, 640, 8, 32, 5, 1, 2, 1), "gk4": (8, 110, 160, 1024, 512, 3, 1, 1, 1), "gk1": (8, 110, 160, 64, 512, 3, 1, 1, 1)}
+          "head": (8, 440, 640, 8, 32, 5, 1, 2, 1), "enc3": (8, 110, 160, 128, 256, 5, 2, 2, 1), "enc2": (8, 220, 320, 64, 128, 5, 2, 2, 1),
+          "res": (8, 55, 80, 256, 256, 3, 1, 1, 1), "aspp": (8, 28, 40, 2048, 256, 3, 1, 6, 6), "dl4": (8, 28, 40, 512, 512, 3, 1, 2, 2), "gk4": (8, 110, 160, 1024, 512, 3, 1, 1, 1), "gk1": (8, 110, 160, 64, 512, 3, 1, 1, 1)}
 for name in sys.argv[1:]:
     B, H, W, Cin, Cout, R, st, pad, dil = SHAPES[name]
     mode = os.environ.get("ABL_DATA", "randn")
@@ -13,7 +14,8 @@ for name in sys.argv[1:]:
     if mode == "zeros": x.zero_(); w.zero_()
     if mode == "ones": x.fill_(1.0); w.fill_(1.0)
     pk = hip.pack_conv_weight(w)
-    out = torch.empty(B, H, W, Cout, device="cuda", dtype=torch.bfloat16)
+    Ho, Wo = (H + 2 * pad - dil * (R - 1) - 1) // st + 1, (W + 2 * pad - dil * (R - 1) - 1) // st + 1
+    out = torch.empty(B, Ho, Wo, Cout, device="cuda", dtype=torch.bfloat16)
     for _ in range(5):
         hip.conv2d_nhwc(x, pk, None, Cout, R, R, st, pad, dil, out=out)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -22,5 +24,5 @@ for name in sys.argv[1:]:
         hip.conv2d_nhwc(x, pk, None, Cout, R, R, st, pad, dil, out=out)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / int(os.environ.get('ABL_N', '20'))
-    fl = 2.0 * B * H * W * Cout * Cin * R * R
+    fl = 2.0 * B * Ho * Wo * Cout * Cin * R * R
     print(f"{name}: {ms:.4f} ms  {fl / ms / 1e9:.0f} TF/s", flush=True)
