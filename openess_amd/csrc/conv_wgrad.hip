@@ -14,6 +14,7 @@
 // (no per-pixel div/mod), split-K over output rows, fp32 atomics into the OIHW gradient (pre-zeroed).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "oess.h"
 #include "oess_common.h"
 
@@ -209,7 +210,9 @@ int oess_conv2d_wgrad_bf16(const void* x, long long x_pix_stride, int B, int H, 
     a.tiles_n = (a.Kdim + TN - 1) / TN;
     a.rows_total = B * a.Ho;
     const int tiles = a.tiles_m * a.tiles_n;
-    int splits = (1024 + tiles - 1) / tiles;                 // ~4 workgroups per CU in flight
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("OESS_WGRAD_TARGET"); target = e ? atoi(e) : 512; if (target < 1) target = 512; }
+    int splits = (target + tiles - 1) / tiles;               // ~2 workgroups per CU: measured best (1024: +3 % step time on frame2recon from the larger partial-sum traffic)
     const size_t per_split = (size_t)a.tiles_m * TM * a.tiles_n * TN * sizeof(float);
     if (per_split > workspace_bytes) return OESS_ENOMEM;
     if ((size_t)splits * per_split > workspace_bytes) splits = (int)(workspace_bytes / per_split);
