@@ -220,25 +220,26 @@ __global__ __launch_bounds__(THREADS) void segmean_fwd_kernel(const void* __rest
 // contiguous pixel run with a register run-accumulator and only touches the LDS table [VLOCAL ids][C] when the id
 // changes.  One workgroup per CU (the table is up to 128 KB); 8 groups x 8 loads x 512 B = 32 KB in flight per CU.
 constexpr int SEGV_PIX_PER_WG = 2048;
+constexpr int SEGV_THREADS = 512;        // 8 waves on the one workgroup a CU can hold (the LDS table is up to 128 KB)
 template <bool BF16, int LPP>
-__global__ __launch_bounds__(THREADS) void segmean_fwd_vec_kernel(const void* __restrict__ feat, const int64_t* __restrict__ ids,
+__global__ __launch_bounds__(SEGV_THREADS) void segmean_fwd_vec_kernel(const void* __restrict__ feat, const int64_t* __restrict__ ids,
                                                                   int64_t P, int64_t pps, int sps, int S, int vlocal,
-                                                                  float* __restrict__ k, float* __restrict__ count) {
+                                                                  float* __restrict__ k, float* __restrict__ count, int pix_per_wg) {
     constexpr int CPL = BF16 ? 8 : 4;
     constexpr int Cf = LPP * CPL;
-    constexpr int GROUPS = THREADS / LPP;
+    constexpr int GROUPS = SEGV_THREADS / LPP;
     extern __shared__ __attribute__((aligned(16))) unsigned char seg_smem[];
     float* acc = reinterpret_cast<float*>(seg_smem);                    // [vlocal][Cf]
     int* cnt = reinterpret_cast<int*>(acc + (size_t)vlocal * Cf);       // [vlocal]
     const int sub = threadIdx.x % LPP, grp = threadIdx.x / LPP;
-    const int64_t chunks_per_sample = (pps + SEGV_PIX_PER_WG - 1) / SEGV_PIX_PER_WG;
+    const int64_t chunks_per_sample = (pps + pix_per_wg - 1) / pix_per_wg;
     const int64_t b = blockIdx.x / chunks_per_sample, ch = blockIdx.x - b * chunks_per_sample;
-    const int64_t p_beg = b * pps + ch * SEGV_PIX_PER_WG;
-    int64_t p_end = p_beg + SEGV_PIX_PER_WG;
+    const int64_t p_beg = b * pps + ch * pix_per_wg;
+    int64_t p_end = p_beg + pix_per_wg;
     if (p_end > (b + 1) * pps) p_end = (b + 1) * pps;
     if (p_end > P) p_end = P;
-    for (int i = threadIdx.x; i < vlocal * Cf; i += THREADS) acc[i] = 0.0f;
-    for (int i = threadIdx.x; i < vlocal; i += THREADS) cnt[i] = 0;
+    for (int i = threadIdx.x; i < vlocal * Cf; i += SEGV_THREADS) acc[i] = 0.0f;
+    for (int i = threadIdx.x; i < vlocal; i += SEGV_THREADS) cnt[i] = 0;
     __syncthreads();
     const int64_t id_off = b * (int64_t)sps;
     const int64_t len = p_end - p_beg;
@@ -567,13 +568,27 @@ int oess_segment_mean_fwd(const void* feat, int is_bf16, const int64_t* ids, int
             int vlocal = (int)((128 * 1024) / ((size_t)Cf * 4 + 4));      // ids held in the LDS table (<= 128 KB)
             if (vlocal > 256) vlocal = 256;
             const size_t lds = (size_t)vlocal * ((size_t)Cf * 4 + 4);
-            const int64_t vchunks = (pixels_per_sample + SEGV_PIX_PER_WG - 1) / SEGV_PIX_PER_WG;
+            // pixels per workgroup: aim at three full rounds of one workgroup per CU (measured at 8 x 440 x 640: 2048 px ->
+            // 0.436 ms, 3072 px -> 0.382 / 0.399 ms bf16 / fp32 = 38 % / 73 % of 8 TB/s); OESS_SEGMEAN_PIX overrides
+            static int ppw_env = -1;
+            if (ppw_env < 0) { const char* e = getenv("OESS_SEGMEAN_PIX"); ppw_env = e ? atoi(e) : 0; }
+            int ppw = ppw_env;
+            if (ppw < 64) {
+                long long chunks = (3 * 256 + B / 2) / B;
+                if (chunks < 1) chunks = 1;
+                long long q = (pixels_per_sample + chunks - 1) / chunks;
+                q = (q + 63) / 64 * 64;
+                if (q < 512) q = 512;
+                if (q > 16384) q = 16384;
+                ppw = (int)q;
+            }
+            const int64_t vchunks = (pixels_per_sample + ppw - 1) / ppw;
             const dim3 vgrid((unsigned)(B * vchunks));
 #define OESS_SEGV(BF, L)                                                                                                     \
             {                                                                                                                \
                 (void)hipFuncSetAttribute((const void*)&segmean_fwd_vec_kernel<BF, L>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                hipLaunchKernelGGL((segmean_fwd_vec_kernel<BF, L>), vgrid, dim3(THREADS), lds, st, feat, ids, P, pixels_per_sample, \
-                                   superpixel_size, S, vlocal, k, count);                                                   \
+                hipLaunchKernelGGL((segmean_fwd_vec_kernel<BF, L>), vgrid, dim3(SEGV_THREADS), lds, st, feat, ids, P, pixels_per_sample, \
+                                   superpixel_size, S, vlocal, k, count, ppw);                                              \
             }
             if (is_bf16) { if (lpp == 8) OESS_SEGV(true, 8) else if (lpp == 16) OESS_SEGV(true, 16) else if (lpp == 32) OESS_SEGV(true, 32) else OESS_SEGV(true, 64) }
             else { if (lpp == 8) OESS_SEGV(false, 8) else if (lpp == 16) OESS_SEGV(false, 16) else if (lpp == 32) OESS_SEGV(false, 32) else OESS_SEGV(false, 64) }
