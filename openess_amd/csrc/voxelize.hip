@@ -57,7 +57,9 @@ struct Geom {
 __host__ Geom make_geom(int C, int H, int W, int crop_rows, int64_t max_seg_len) {
     Geom g;
     g.C = C; g.H = H; g.W = W; g.Hout = H - crop_rows;
-    int th = MAX_LDS_TILE_BYTES / (C * TW * 8);
+    static int lds_budget = -1;
+    if (lds_budget < 0) { const char* e = getenv("OESS_VOX_LDS_KB"); lds_budget = e ? atoi(e) * 1024 : MAX_LDS_TILE_BYTES; if (lds_budget < 4096) lds_budget = MAX_LDS_TILE_BYTES; }
+    int th = lds_budget / (C * TW * 8);
     if (th > 32) th = 32;
     int lg = 0;
     while ((2 << lg) <= th) ++lg;          // round down to a power of two: tile math is shifts, not divides
@@ -814,6 +816,7 @@ int run_tri(Src src, const int64_t* seg_off, int n_seg, int64_t max_seg_len, int
     OESS_HIP(hipFuncSetAttribute((const void*)&tri_sort_kernel<Src>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
     hipLaunchKernelGGL((tri_sort_kernel<Src>), dim3(nSl, n_seg), dim3(SORT_THREADS), sort_lds, st, src_c, seg_off, g, nSl, table, alloc,
                        recs, cap);
+    OESS_HIP(hipFuncSetAttribute((const void*)&tri_splat2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)g.C * g.TH * TW * sizeof(long long))));
     hipLaunchKernelGGL(tri_splat2_kernel, dim3(g.nTiles, n_seg), dim3(THREADS), (size_t)g.C * g.TH * TW * sizeof(long long), st,
                        (const float4*)recs, (const int*)table, g, nSl, count_mode, cap, out);
     OESS_HIP(hipGetLastError());
