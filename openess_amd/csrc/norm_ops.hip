@@ -109,23 +109,27 @@ __global__ void finalize_kernel(const float* __restrict__ sum, const float* __re
     }
 }
 
+// Thread layout of both apply kernels: lane_c = channel chunk (8 channels) is FIXED per thread, rows = THREADS / (C/8)
+// pixels per block iteration, grid = (pixel chunks, G): no per-element 64-bit divisions, per-channel constants stay in
+// registers for the whole loop.  Needs C/8 <= THREADS (C <= 2048).
 __global__ __launch_bounds__(THREADS) void apply_kernel(const uint16_t* __restrict__ x, int64_t xps,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const uint16_t* __restrict__ res, int64_t rps, int relu,
                                                         int64_t ppg, int G, int C, uint16_t* __restrict__ out, int64_t ops) {
     const int cl = C >> 3;
-    const int64_t total = (int64_t)G * ppg * cl;
-    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * THREADS) {
-        const int64_t pix = i / cl;
-        const int c0 = (int)(i - pix * cl) * 8;
-        const int64_t g = pix / ppg;
+    const int rows = THREADS / cl;
+    const int lane_c = threadIdx.x % cl, row = threadIdx.x / cl;
+    if (row >= rows) return;
+    const int g = blockIdx.y, c0 = lane_c * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = scale[(int64_t)g * C + c0 + k]; sh[k] = shift[(int64_t)g * C + c0 + k]; }
+    const int64_t base = (int64_t)g * ppg;
+    for (int64_t p = (int64_t)blockIdx.x * rows + row; p < ppg; p += (int64_t)gridDim.x * rows) {
+        const int64_t pix = base + p;
         Pack8 v, r, o;
         v.q = *reinterpret_cast<const uint4*>(x + pix * xps + c0);
         if (res) r.q = *reinterpret_cast<const uint4*>(res + pix * rps + c0);
-        const float4 s0 = *reinterpret_cast<const float4*>(scale + g * C + c0), s1 = *reinterpret_cast<const float4*>(scale + g * C + c0 + 4);
-        const float4 h0 = *reinterpret_cast<const float4*>(shift + g * C + c0), h1 = *reinterpret_cast<const float4*>(shift + g * C + c0 + 4);
-        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float f = bf16_to_f32(v.h[k]) * sc[k] + sh[k];
@@ -149,25 +153,31 @@ __global__ __launch_bounds__(THREADS) void in_bwd_apply_kernel(const uint16_t* _
                                                                const float* __restrict__ gamma = nullptr,
                                                                uint16_t* __restrict__ dres = nullptr, int64_t drps = 0) {
     const int cl = C >> 3;
+    const int rows = THREADS / cl;
+    const int lane_c = threadIdx.x % cl, row = threadIdx.x / cl;
+    if (row >= rows) return;
+    const int g = blockIdx.y, c0 = lane_c * 8;
     const float invn = 1.0f / (float)ppg;
-    const int64_t total = (int64_t)G * ppg * cl;
-    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * THREADS) {
-        const int64_t pix = i / cl;
-        const int c0 = (int)(i - pix * cl) * 8;
-        const int64_t g = pix / ppg;
+    float mu[8], rs[8], a1[8], a2[8], gr[8];               // per channel: mean, rstd, s1/N, s2/N, gamma*rstd
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int64_t gc = (int64_t)g * C + c0 + k;
+        mu[k] = mean[gc]; rs[k] = rstd[gc]; a1[k] = s1[gc] * invn; a2[k] = s2[gc] * invn;
+        gr[k] = (gamma ? gamma[c0 + k] : 1.0f) * rs[k];
+    }
+    const int64_t base = (int64_t)g * ppg;
+    for (int64_t p = (int64_t)blockIdx.x * rows + row; p < ppg; p += (int64_t)gridDim.x * rows) {
+        const int64_t pix = base + p;
         Pack8 v, d, o, yo, ro;
         v.q = *reinterpret_cast<const uint4*>(x + pix * xps + c0);
         d.q = *reinterpret_cast<const uint4*>(dy + pix * dps + c0);
         if (relu && yout) yo.q = *reinterpret_cast<const uint4*>(yout + pix * yps + c0);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int64_t gc = g * C + c0 + k;
-            const float r = rstd[gc];
-            const float xh = (bf16_to_f32(v.h[k]) - mean[gc]) * r;
+            const float xh = (bf16_to_f32(v.h[k]) - mu[k]) * rs[k];
             float gg = bf16_to_f32(d.h[k]);
             if (relu && !(yout ? bf16_to_f32(yo.h[k]) > 0.f : xh > 0.f)) gg = 0.f;
-            const float ga = gamma ? gamma[c0 + k] : 1.0f;
-            o.h[k] = f32_to_bf16(ga * r * (gg - s1[gc] * invn - xh * s2[gc] * invn));
+            o.h[k] = f32_to_bf16(gr[k] * (gg - a1[k] - xh * a2[k]));
             ro.h[k] = f32_to_bf16(gg);
         }
         *reinterpret_cast<uint4*>(dx + pix * gps + c0) = o.q;
@@ -365,6 +375,17 @@ unsigned stats_chunks(int64_t ppg, int G) {
     return (unsigned)want;
 }
 
+// grid of the apply kernels: x = pixel chunks (enough workgroups to fill the chip a few times over, each thread keeping
+// >= 4 pixels in its loop), y = groups
+dim3 apply_grid(int64_t ppg, int G, int C) {
+    const int rows = THREADS / (C >> 3);
+    int64_t gx = (ppg + (int64_t)rows * 4 - 1) / ((int64_t)rows * 4);
+    const int64_t cap = (8192 + G - 1) / G;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    return dim3((unsigned)gx, (unsigned)G);
+}
+
 int grid_for(int64_t work) {
     int64_t g = (work + THREADS - 1) / THREADS;
     if (g < 1) g = 1;
@@ -429,7 +450,8 @@ int oess_norm_apply_nhwc_bf16(const void* x, long long x_pix_stride, const float
     if (!x || !scale || !shift || !out || G <= 0 || pixels_per_group <= 0 || C <= 0 || (C & 7) || (x_pix_stride & 7) ||
         (out_pix_stride & 7) || (residual && (res_pix_stride & 7)))
         return OESS_EINVAL;
-    hipLaunchKernelGGL(apply_kernel, dim3(grid_for((int64_t)G * pixels_per_group * (C >> 3))), dim3(THREADS), 0,
+    if ((C >> 3) > THREADS) return OESS_EINVAL;
+    hipLaunchKernelGGL(apply_kernel, apply_grid(pixels_per_group, G, C), dim3(THREADS), 0,
                        (hipStream_t)stream, (const uint16_t*)x, (int64_t)x_pix_stride, scale, shift, (const uint16_t*)residual,
                        (int64_t)res_pix_stride, relu, (int64_t)pixels_per_group, G, C, (uint16_t*)out, (int64_t)out_pix_stride);
     OESS_HIP(hipGetLastError());
@@ -451,7 +473,7 @@ int oess_instnorm_bwd_nhwc_bf16(const void* x, long long x_pix_stride, const voi
     dim3 grid(stats_chunks(pixels_per_group, G), (unsigned)G);
     hipLaunchKernelGGL(stats_kernel<1>, grid, dim3(THREADS), lds, st, (const uint16_t*)x, (int64_t)x_pix_stride,
                        (const uint16_t*)dy, (int64_t)dy_pix_stride, mean, rstd, relu, (int64_t)pixels_per_group, C, s1, s2);
-    hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(grid_for((int64_t)G * pixels_per_group * cl)), dim3(THREADS), 0, st,
+    hipLaunchKernelGGL(in_bwd_apply_kernel, apply_grid(pixels_per_group, G, C), dim3(THREADS), 0, st,
                        (const uint16_t*)x, (int64_t)x_pix_stride, (const uint16_t*)dy, (int64_t)dy_pix_stride, mean, rstd, s1,
                        s2, relu, (int64_t)pixels_per_group, G, C, (uint16_t*)dx, (int64_t)dx_pix_stride);
     OESS_HIP(hipGetLastError());
@@ -477,7 +499,7 @@ int oess_batchnorm_bwd_nhwc_bf16(const void* x, long long x_pix_stride, const vo
     hipLaunchKernelGGL(stats_kernel<1>, grid, dim3(THREADS), lds, st, (const uint16_t*)x, (int64_t)x_pix_stride,
                        (const uint16_t*)dy, (int64_t)dy_pix_stride, mean, rstd, relu, (int64_t)pixels, C, dbeta, dgamma,
                        (const uint16_t*)y_out, (int64_t)y_pix_stride);
-    hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(grid_for((int64_t)pixels * cl)), dim3(THREADS), 0, st, (const uint16_t*)x,
+    hipLaunchKernelGGL(in_bwd_apply_kernel, apply_grid(pixels, 1, C), dim3(THREADS), 0, st, (const uint16_t*)x,
                        (int64_t)x_pix_stride, (const uint16_t*)dy, (int64_t)dy_pix_stride, mean, rstd, dbeta, dgamma, relu,
                        (int64_t)pixels, 1, C, (uint16_t*)dx, (int64_t)dx_pix_stride, (const uint16_t*)y_out, (int64_t)y_pix_stride,
                        gamma, (uint16_t*)dresidual, (int64_t)dres_pix_stride);
