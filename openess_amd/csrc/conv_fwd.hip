@@ -142,7 +142,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int ml = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                lC[ml * PITCH + nl] = f32_to_bf16(acc[i][j][e] + bv);      // activation applied after the residual
+                lC[ml * PITCH + nl] = (uint16_t)pack_bf16x2(acc[i][j][e] + bv, 0.0f);      // activation applied after the residual
             }
         }
     __syncthreads();
@@ -181,13 +181,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
             }
         }
         if (a.residual || a.relu) {
+            float f[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                float f = bf16_to_f32(u.h[q]);
-                if (a.residual) f += bf16_to_f32(rs.h[q]);
-                f = conv_act(f, a.relu);
-                u.h[q] = f32_to_bf16(f);
+                f[q] = bf16_to_f32(u.h[q]);
+                if (a.residual) f[q] += bf16_to_f32(rs.h[q]);
+                f[q] = conv_act(f[q], a.relu);
             }
+            u.q4 = pack_bf16x8(f);
         }
         if (full) {
             *reinterpret_cast<uint4*>(dst) = u.q4;      // (nontemporal stores measured 5-8 % slower here)
@@ -233,7 +234,7 @@ __device__ __forceinline__ void lstm_epilogue(const ConvArgs& a, f32x16_t (&acc)
                 const float nc = fast_sigmoid(gr) * pc + fast_sigmoid(gi) * fast_tanh(gc);     // submodules.py:211
                 const float hv = fast_sigmoid(go) * fast_tanh(nc);                              // submodules.py:212
                 lc[ml * CP + hcl] = nc;
-                lh[ml * HP + hcl] = f32_to_bf16(hv);
+                lh[ml * HP + hcl] = (uint16_t)pack_bf16x2(hv, 0.0f);
             }
     }
     __syncthreads();

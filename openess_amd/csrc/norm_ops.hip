@@ -127,17 +127,17 @@ __global__ __launch_bounds__(THREADS) void apply_kernel(const uint16_t* __restri
     const int64_t base = (int64_t)g * ppg;
     for (int64_t p = (int64_t)blockIdx.x * rows + row; p < ppg; p += (int64_t)gridDim.x * rows) {
         const int64_t pix = base + p;
-        Pack8 v, r, o;
+        Pack8 v, r;
+        float f[8];
         v.q = *reinterpret_cast<const uint4*>(x + pix * xps + c0);
         if (res) r.q = *reinterpret_cast<const uint4*>(res + pix * rps + c0);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            float f = bf16_to_f32(v.h[k]) * sc[k] + sh[k];
-            if (res) f += bf16_to_f32(r.h[k]);
-            if (relu) f = fmaxf(f, 0.f);
-            o.h[k] = f32_to_bf16(f);
+            f[k] = bf16_to_f32(v.h[k]) * sc[k] + sh[k];
+            if (res) f[k] += bf16_to_f32(r.h[k]);
+            if (relu) f[k] = fmaxf(f[k], 0.f);
         }
-        *reinterpret_cast<uint4*>(out + pix * ops + c0) = o.q;
+        *reinterpret_cast<uint4*>(out + pix * ops + c0) = pack_bf16x8(f);
     }
 }
 
@@ -168,7 +168,8 @@ __global__ __launch_bounds__(THREADS) void in_bwd_apply_kernel(const uint16_t* _
     const int64_t base = (int64_t)g * ppg;
     for (int64_t p = (int64_t)blockIdx.x * rows + row; p < ppg; p += (int64_t)gridDim.x * rows) {
         const int64_t pix = base + p;
-        Pack8 v, d, o, yo, ro;
+        Pack8 v, d, yo;
+        float od[8], og[8];
         v.q = *reinterpret_cast<const uint4*>(x + pix * xps + c0);
         d.q = *reinterpret_cast<const uint4*>(dy + pix * dps + c0);
         if (relu && yout) yo.q = *reinterpret_cast<const uint4*>(yout + pix * yps + c0);
@@ -177,11 +178,11 @@ __global__ __launch_bounds__(THREADS) void in_bwd_apply_kernel(const uint16_t* _
             const float xh = (bf16_to_f32(v.h[k]) - mu[k]) * rs[k];
             float gg = bf16_to_f32(d.h[k]);
             if (relu && !(yout ? bf16_to_f32(yo.h[k]) > 0.f : xh > 0.f)) gg = 0.f;
-            o.h[k] = f32_to_bf16(gr[k] * (gg - a1[k] - xh * a2[k]));
-            ro.h[k] = f32_to_bf16(gg);
+            od[k] = gr[k] * (gg - a1[k] - xh * a2[k]);
+            og[k] = gg;
         }
-        *reinterpret_cast<uint4*>(dx + pix * gps + c0) = o.q;
-        if (dres) *reinterpret_cast<uint4*>(dres + pix * drps + c0) = ro.q;
+        *reinterpret_cast<uint4*>(dx + pix * gps + c0) = pack_bf16x8(od);
+        if (dres) *reinterpret_cast<uint4*>(dres + pix * drps + c0) = pack_bf16x8(og);
     }
 }
 
@@ -306,21 +307,24 @@ __global__ __launch_bounds__(THREADS) void bilinear_l2_vec_kernel(const uint16_t
     const float rx = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
     constexpr int PPB = THREADS / LPP;             // output pixels per block iteration
     const int sub = threadIdx.x % LPP, pl = threadIdx.x / LPP;
-    const int64_t total = (int64_t)B * Ho * Wo;
-    for (int64_t opix = (int64_t)blockIdx.x * PPB + pl; opix < total; opix += (int64_t)gridDim.x * PPB) {
-        const int ox = (int)(opix % Wo);
-        const int64_t t = opix / Wo;
-        const int oy = (int)(t % Ho);
-        const int64_t b = t / Ho;
-        const float fy = ry * oy, fx = rx * ox;
-        const int y0 = (int)fy, x0 = (int)fx;
-        const int y1 = (y0 < H - 1) ? y0 + 1 : y0, x1 = (x0 < W - 1) ? x0 + 1 : x0;
-        const float wy = fy - y0, wx = fx - x0;
-        union U { uint4 q; uint16_t h[8]; } a, bb, c, d, o;
-        a.q = *reinterpret_cast<const uint4*>(in + ((b * H + y0) * W + x0) * ips + sub * 8);
-        bb.q = *reinterpret_cast<const uint4*>(in + ((b * H + y0) * W + x1) * ips + sub * 8);
-        c.q = *reinterpret_cast<const uint4*>(in + ((b * H + y1) * W + x0) * ips + sub * 8);
-        d.q = *reinterpret_cast<const uint4*>(in + ((b * H + y1) * W + x1) * ips + sub * 8);
+    // one workgroup per output row (blockIdx.x = b * Ho + oy): row-level index math is scalar
+    const int oy = blockIdx.x % Ho;
+    const int64_t b = blockIdx.x / Ho;
+    const float fy = ry * oy;
+    const int y0 = (int)fy;
+    const int y1 = (y0 < H - 1) ? y0 + 1 : y0;
+    const float wy = fy - y0;
+    const int64_t row0 = (b * H + y0) * W, row1 = (b * H + y1) * W, orow = (b * Ho + oy) * (int64_t)Wo;
+    for (int ox = pl; ox < Wo; ox += PPB) {
+        const float fx = rx * ox;
+        const int x0 = (int)fx;
+        const int x1 = (x0 < W - 1) ? x0 + 1 : x0;
+        const float wx = fx - x0;
+        union U { uint4 q; uint16_t h[8]; } a, bb, c, d;
+        a.q = *reinterpret_cast<const uint4*>(in + (row0 + x0) * ips + sub * 8);
+        bb.q = *reinterpret_cast<const uint4*>(in + (row0 + x1) * ips + sub * 8);
+        c.q = *reinterpret_cast<const uint4*>(in + (row1 + x0) * ips + sub * 8);
+        d.q = *reinterpret_cast<const uint4*>(in + (row1 + x1) * ips + sub * 8);
         float v[8];
         float ss = 0.f;
 #pragma unroll
@@ -337,8 +341,8 @@ __global__ __launch_bounds__(THREADS) void bilinear_l2_vec_kernel(const uint16_t
             inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) o.h[k] = f32_to_bf16(v[k] * inv);
-        *reinterpret_cast<uint4*>(out + opix * ops + sub * 8) = o.q;
+        for (int k = 0; k < 8; ++k) v[k] *= inv;
+        *reinterpret_cast<uint4*>(out + (orow + ox) * ops + sub * 8) = pack_bf16x8(v);
     }
 }
 
@@ -545,8 +549,7 @@ int oess_bilinear_l2norm_nhwc_bf16(const void* in, long long in_pix_stride, int 
     const int lpp = C / 8;
     if ((lpp == 8 || lpp == 16 || lpp == 32 || lpp == 64) && (in_pix_stride & 7) == 0 && (out_pix_stride & 7) == 0 &&
         ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0) {
-        int64_t gv = (total + THREADS / lpp - 1) / (THREADS / lpp);
-        if (gv > 65536) gv = 65536;
+        const int64_t gv = (int64_t)B * H * scale;            // one workgroup per output row
 #define OESS_BL(LPP_)                                                                                                  \
         hipLaunchKernelGGL(bilinear_l2_vec_kernel<LPP_>, dim3((unsigned)gv), dim3(THREADS), 0, (hipStream_t)stream,    \
                            (const uint16_t*)in, (int64_t)in_pix_stride, B, H, W, scale, normalize, (uint16_t*)out,      \

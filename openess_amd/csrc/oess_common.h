@@ -24,6 +24,18 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
     return (uint16_t)(u >> 16);
 }
 
+// two floats -> packed bf16x2 (low half = a) with the gfx950 hardware conversion (round-to-nearest-even, identical to
+// f32_to_bf16 for every non-NaN input; NaNs come out as a quiet NaN).  One VALU instruction instead of ~10.
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// eight floats -> one 16-byte vector of bf16
+__device__ __forceinline__ uint4 pack_bf16x8(const float (&v)[8]) {
+    return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
