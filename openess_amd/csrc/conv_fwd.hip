@@ -1084,8 +1084,8 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvArgs a) {
                 v[k] = conv_act(v[k], a.relu);
             }
             uint2 o;
-            o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-            o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
             *reinterpret_cast<uint2*>(img + pl * OP + ch) = o;
         }
     }

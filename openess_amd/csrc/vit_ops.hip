@@ -228,9 +228,9 @@ __global__ __launch_bounds__(THREADS) void attention_d64_mfma_kernel(const uint1
         // O^T += V^T P^T
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            union { abf16x8_t v; uint16_t hh[8]; } pf;
+            union { abf16x8_t v; uint32_t w[4]; } pf;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pf.hh[j] = f32_to_bf16(p[8 * kk + j]);
+            for (int j = 0; j < 4; ++j) pf.w[j] = pack_bf16x2(p[8 * kk + 2 * j], p[8 * kk + 2 * j + 1]);
             const abf16x8_t v0 = *reinterpret_cast<const abf16x8_t*>(&lvt[qcol * VP + 16 * kk + 8 * hi]);          // d = lane & 31
             const abf16x8_t v1 = *reinterpret_cast<const abf16x8_t*>(&lvt[(32 + qcol) * VP + 16 * kk + 8 * hi]);   // d = 32 + (lane & 31)
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf.v, o0, 0, 0, 0);
@@ -244,10 +244,10 @@ __global__ __launch_bounds__(THREADS) void attention_d64_mfma_kernel(const uint1
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint2 a, c;
-            a.x = (uint32_t)f32_to_bf16(o0[4 * g] * inv) | ((uint32_t)f32_to_bf16(o0[4 * g + 1] * inv) << 16);
-            a.y = (uint32_t)f32_to_bf16(o0[4 * g + 2] * inv) | ((uint32_t)f32_to_bf16(o0[4 * g + 3] * inv) << 16);
-            c.x = (uint32_t)f32_to_bf16(o1[4 * g] * inv) | ((uint32_t)f32_to_bf16(o1[4 * g + 1] * inv) << 16);
-            c.y = (uint32_t)f32_to_bf16(o1[4 * g + 2] * inv) | ((uint32_t)f32_to_bf16(o1[4 * g + 3] * inv) << 16);
+            a.x = pack_bf16x2(o0[4 * g] * inv, o0[4 * g + 1] * inv);
+            a.y = pack_bf16x2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            c.x = pack_bf16x2(o1[4 * g] * inv, o1[4 * g + 1] * inv);
+            c.y = pack_bf16x2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
             *reinterpret_cast<uint2*>(op + 8 * g + 4 * hi) = a;            // d = 8 g + 4 hi + (0..3)
             *reinterpret_cast<uint2*>(op + 32 + 8 * g + 4 * hi) = c;       // d = 32 + ...
         }
