@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--raw", type=int, default=1)
     ap.add_argument("--B", type=int, default=8)
+    ap.add_argument("--h2d", type=int, default=0, help="1: time the pinned-host -> device copy of the raw columns with every batch")
     a = ap.parse_args()
     C, H, W, crop, nwin, n_per, B = 5, 480, 640, 40, 20, 100000, a.B
     xs, ys, ts, ps = [], [], [], []
@@ -41,8 +42,14 @@ def main():
             tt = (t[s * n_per:(s + 1) * n_per] - t[s * n_per]).double().float()
             tf[s * n_per:(s + 1) * n_per] = tt / tt[-1]
 
+    if a.h2d:       # the loader's pinned buffers (DataLoader(pin_memory=True)) -> non_blocking copies -> voxelizer
+        hx, hy, ht, hp = (v.cpu().pin_memory() for v in (x, y, t, p))
+
     def run():
-        if a.raw:
+        if a.raw and a.h2d:
+            dx, dy, dt, dp = (v.to("cuda", non_blocking=True) for v in (hx, hy, ht, hp))
+            hip.voxelize_dsec_raw(dx, dy, dt, dp, maps, seg_map, so, C, H, W, crop_rows=crop, out=out)
+        elif a.raw:
             hip.voxelize_dsec_raw(x, y, t, p, maps, seg_map, so, C, H, W, crop_rows=crop, out=out)
         else:
             hip.voxelize_trilinear(xf, yf, pf, tf, so, C, H, W, crop_rows=crop, out=out)
@@ -58,7 +65,7 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
     alg = B * (16 * nwin * n_per + 4 * nwin * C * H * W)
-    print(f"voxelize B={B} raw={a.raw}: {ms:.3f} ms/batch  algorithmic {alg / 1e9:.3f} GB -> {alg / ms / 1e6:.1f} GB/s "
+    print(f"voxelize B={B} raw={a.raw} h2d={a.h2d}: {ms:.3f} ms/batch  algorithmic {alg / 1e9:.3f} GB -> {alg / ms / 1e6:.1f} GB/s "
           f"({alg / ms / 1e6 / 8000 * 100:.1f}% of 8 TB/s)  {B / ms * 1000:.0f} event-frames/s")
 
 
