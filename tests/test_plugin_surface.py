@@ -111,7 +111,8 @@ def test_ddd17_batch_voxelization_matches_oracle(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg,loop", [("pretrain_dsec_synthetic.yaml", "pretraining"), ("finetune_dsec_synthetic.yaml", "training")])
+@pytest.mark.parametrize("cfg,loop", [("pretrain_dsec_synthetic.yaml", "pretraining"), ("finetune_dsec_synthetic.yaml", "training"),
+                                      ("openess_dsec_synthetic.yaml", "training")])
 def test_train_py_dispatch_and_one_epoch(cfg, loop, tmp_path, monkeypatch):
     """train.py's dispatch + one synthetic epoch end to end (voxelizer -> step -> checkpoint in the reference format)."""
     import train
@@ -121,6 +122,8 @@ def test_train_py_dispatch_and_one_epoch(cfg, loop, tmp_path, monkeypatch):
     s.ckpt_dir = str(tmp_path)
     trainer, which = train.build_trainer(s)
     assert which == loop
+    if cfg.startswith("openess"):
+        assert type(trainer).__name__ == "OpenESSModel"
     getattr(trainer, which)()
     assert trainer.epoch_count == 1 and trainer.step_count == len(trainer.train_loader_sensor_b)
     saved = os.listdir(str(tmp_path))
