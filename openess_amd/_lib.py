@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboess.so")
+LIB_PATH = os.environ.get("OESS_LIB_PATH") or os.path.join(_HERE, "liboess.so")      # override: A/B builds of the same ABI
 
 c_i64 = ctypes.c_int64
 c_ll = ctypes.c_longlong
