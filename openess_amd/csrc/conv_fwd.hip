@@ -587,6 +587,7 @@ __global__ __launch_bounds__(conv_tile_threads(BMX)) void conv_fwd_dma_kernel(Co
         const uint32_t stage_ = lds0 + (uint32_t)((kt % NSTAGE) * STAGE_BYTES);
         bf16x8_t fa0[MT], fb0[NT], fa1[MT], fb1[NT];
         // register double-buffered fragments: reads of k-step ks+1 are in flight under the MFMAs of k-step ks
+        __builtin_amdgcn_s_setprio(3);
         OESS_FRAG_READ(fa0, fb0, 0)
         OESS_FRAG_READ(fa1, fb1, 1)
         OESS_WAIT_FRAGS(NFRAG, fa0, fb0)
@@ -599,6 +600,7 @@ __global__ __launch_bounds__(conv_tile_threads(BMX)) void conv_fwd_dma_kernel(Co
         OESS_FRAG_MMA(fa0, fb0)
         OESS_WAIT_FRAGS(0, fa1, fb1)
         OESS_FRAG_MMA(fa1, fb1)
+        __builtin_amdgcn_s_setprio(0);
     }
 #undef OESS_FRAG_READ
 #undef OESS_FRAG_MMA
