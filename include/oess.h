@@ -155,6 +155,17 @@ int oess_cosine_mean_bwd(const void* a, long long a_pix_stride, const void* b, l
                          long long gb_pix_stride, oess_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * a14 PointInfoNCE, NCELoss.forward (utils/loss_functions.py:147-154): loss = CrossEntropy(k q^T / T, arange(S)).
+ * k, q: fp32 [S x C] (superpixel means).  The forward leaves dL/d(k q^T) = (softmax - I) / (S T) in grad_logits
+ * [S x S] fp32, which the backward multiplies out: grad_k = g * G q, grad_q = g * G^T k (either may be null).
+ * partials: scratch of >= S doubles; loss / grad_out: device scalars.
+ * ------------------------------------------------------------------------------------------ */
+int oess_nce_loss_fwd(const float* k, const float* q, int S, int C, float temperature, float* grad_logits, void* partials,
+                      size_t partials_bytes, float* loss, oess_stream_t stream);
+int oess_nce_loss_bwd(const float* grad_logits, const float* k, const float* q, int S, int C, const float* grad_out, float* grad_k,
+                      float* grad_q, oess_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * K11 Confusion matrix (evaluation/metrics.py:4-23): conf[gt*K + pred] += 1 over gt != ignore.
  * conf: K*K int64, ACCUMULATED into (caller zeroes once per validation epoch).
  * ------------------------------------------------------------------------------------------ */

@@ -60,6 +60,8 @@ SIGNATURES = {
                                              c_vp, c_ll, c_vp, c_ll, c_vp]),
     "oess_layernorm_bf16": (c_int, [c_vp, c_ll, c_i64, c_int, c_vp, c_vp, c_f, c_vp, c_ll, c_vp]),
     "oess_attention_d64_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_f, c_vp, c_ll, c_vp]),
+    "oess_nce_loss_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_f, c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "oess_nce_loss_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "oess_masked_stats_slice_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp]),
     "oess_event_slice_to_nhwc8_bf16": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_ll, c_vp, c_int, c_vp, c_vp]),
     "oess_norm_stats_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_ll, c_int, c_vp, c_vp, c_vp]),

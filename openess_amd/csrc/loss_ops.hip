@@ -119,6 +119,75 @@ __global__ __launch_bounds__(THREADS) void cos_bwd_kernel(const void* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// a14 PointInfoNCE (utils/loss_functions.py:147-154): loss = CE(k q^T / T, arange(S)), mean over the S rows.
+// S <= ~100 * B superpixel rows, C = 256: everything is L2 resident; plain fp32 FMA kernels (the logits are divided
+// by T = 0.07, so bf16 operands would cost 14x their rounding error).
+//   nce_logits_kernel : G[i][j] = k_i . q_j / T                     (tile 16 x 16 outputs per workgroup, LDS staged)
+//   nce_rows_kernel   : row log-sum-exp -> loss partials; G[i][j] <- (softmax_ij - [i == j]) / (S T)   (= dL/d(k q^T))
+//   nce_grad_kernel   : dk = g * G q ,  dq = g * G^T k
+// ---------------------------------------------------------------------------------------------
+constexpr int NT = 16;
+__global__ __launch_bounds__(NT * NT) void nce_logits_kernel(const float* __restrict__ k, const float* __restrict__ q, int S, int C,
+                                                             float inv_t, float* __restrict__ G) {
+    __shared__ float lk[NT][NT + 1], lq[NT][NT + 1];
+    const int tx = threadIdx.x % NT, ty = threadIdx.x / NT;
+    const int i = blockIdx.y * NT + ty, j = blockIdx.x * NT + tx;
+    float acc = 0.f;
+    for (int c0 = 0; c0 < C; c0 += NT) {
+        const int ik = blockIdx.y * NT + ty, jq = blockIdx.x * NT + ty;
+        lk[ty][tx] = (ik < S && c0 + tx < C) ? k[(int64_t)ik * C + c0 + tx] : 0.f;
+        lq[ty][tx] = (jq < S && c0 + tx < C) ? q[(int64_t)jq * C + c0 + tx] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc += lk[ty][c] * lq[tx][c];
+        __syncthreads();
+    }
+    if (i < S && j < S) G[(int64_t)i * S + j] = acc * inv_t;
+}
+
+__global__ __launch_bounds__(THREADS) void nce_rows_kernel(float* __restrict__ G, int S, float inv_st, double* __restrict__ partials) {
+    __shared__ float red[THREADS / 64];
+    const int i = blockIdx.x;
+    float* row = G + (int64_t)i * S;
+    float m = -INFINITY;
+    for (int j = threadIdx.x; j < S; j += THREADS) m = fmaxf(m, row[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = red[0];
+    for (int w = 1; w < THREADS / 64; ++w) m = fmaxf(m, red[w]);
+    __syncthreads();
+    float s = 0.f;
+    for (int j = threadIdx.x; j < S; j += THREADS) s += expf(row[j] - m);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    s = 0.f;
+    for (int w = 0; w < THREADS / 64; ++w) s += red[w];
+    const float lse = m + logf(s);
+    if (threadIdx.x == 0) partials[i] = (double)(lse - row[i]);          // -log softmax_ii
+    __syncthreads();
+    for (int j = threadIdx.x; j < S; j += THREADS) {
+        const float p = expf(row[j] - lse);
+        row[j] = (p - (j == i ? 1.0f : 0.0f)) * inv_st;
+    }
+}
+
+// out[i][c] = g * sum_j G[i][j] * v[j][c]     (TRANS: sum_j G[j][i] * v[j][c])
+template <bool TRANS>
+__global__ __launch_bounds__(THREADS) void nce_grad_kernel(const float* __restrict__ G, const float* __restrict__ v, int S, int C,
+                                                           const float* __restrict__ gout, float* __restrict__ out) {
+    const int i = blockIdx.x;
+    const float g = gout[0];
+    for (int c = threadIdx.x; c < C; c += THREADS) {
+        float acc = 0.f;
+        for (int j = 0; j < S; ++j) acc += (TRANS ? G[(int64_t)j * S + i] : G[(int64_t)i * S + j]) * v[(int64_t)j * C + c];
+        out[(int64_t)i * C + c] = g * acc;
+    }
+}
+
 int grid_of(int64_t work_items, int per_block) {
     int64_t g = (work_items + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -177,6 +246,29 @@ int oess_cosine_mean_bwd(const void* a, long long a_pix_stride, const void* b, l
     const float inv_p = (float)(1.0 / (double)P);
     if (is_bf16) hipLaunchKernelGGL(cos_bwd_kernel<true>, dim3((unsigned)g), dim3(THREADS), 0, st, a, (int64_t)a_pix_stride, b, (int64_t)b_pix_stride, P, C, eps, grad_out, inv_p, grad_a, (int64_t)ga_pix_stride, grad_b, (int64_t)gb_pix_stride);
     else hipLaunchKernelGGL(cos_bwd_kernel<false>, dim3((unsigned)g), dim3(THREADS), 0, st, a, (int64_t)a_pix_stride, b, (int64_t)b_pix_stride, P, C, eps, grad_out, inv_p, grad_a, (int64_t)ga_pix_stride, grad_b, (int64_t)gb_pix_stride);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_nce_loss_fwd(const float* k, const float* q, int S, int C, float temperature, float* grad_logits /*[S x S]*/, void* partials,
+                      size_t partials_bytes, float* loss, oess_stream_t stream) {
+    if (!k || !q || !grad_logits || !partials || !loss || S <= 0 || C <= 0 || temperature <= 0.f || partials_bytes < (size_t)S * sizeof(double))
+        return OESS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g2((S + NT - 1) / NT, (S + NT - 1) / NT);
+    hipLaunchKernelGGL(nce_logits_kernel, g2, dim3(NT * NT), 0, st, k, q, S, C, 1.0f / temperature, grad_logits);
+    hipLaunchKernelGGL(nce_rows_kernel, dim3(S), dim3(THREADS), 0, st, grad_logits, S, 1.0f / ((float)S * temperature), (double*)partials);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(THREADS), 0, st, (const double*)partials, S, 0.0, 1.0 / (double)S, loss);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_nce_loss_bwd(const float* grad_logits, const float* k, const float* q, int S, int C, const float* grad_out, float* grad_k,
+                      float* grad_q, oess_stream_t stream) {
+    if (!grad_logits || !k || !q || !grad_out || (!grad_k && !grad_q) || S <= 0 || C <= 0) return OESS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (grad_k) hipLaunchKernelGGL(nce_grad_kernel<false>, dim3(S), dim3(THREADS), 0, st, grad_logits, q, S, C, grad_out, grad_k);
+    if (grad_q) hipLaunchKernelGGL(nce_grad_kernel<true>, dim3(S), dim3(THREADS), 0, st, grad_logits, k, S, C, grad_out, grad_q);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }

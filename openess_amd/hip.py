@@ -369,6 +369,40 @@ def _uniform_pix_stride(x):
     return (H == 1 or W == 1 or x.stride(1) == W * ps) and (B == 1 or x.stride(0) == H * W * ps) and ps >= C
 
 
+class _NCELoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, k, q, temperature):
+        lib = _lib.load()
+        S, C = k.shape
+        G = torch.empty((S, S), dtype=torch.float32, device=k.device)
+        part = torch.empty(S, dtype=torch.float64, device=k.device)
+        loss = torch.empty(1, dtype=torch.float32, device=k.device)
+        _lib.check(lib.oess_nce_loss_fwd(_ptr(k), _ptr(q), S, C, temperature, _ptr(G), _ptr(part), part.numel() * 8, _ptr(loss),
+                                         _stream()), "oess_nce_loss_fwd")
+        ctx.save_for_backward(G, k, q)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        G, k, q = ctx.saved_tensors
+        S, C = k.shape
+        gk = torch.empty_like(k) if ctx.needs_input_grad[0] else None
+        gq = torch.empty_like(q) if ctx.needs_input_grad[1] else None
+        gdev = g.reshape(1).float().contiguous()
+        _lib.check(lib.oess_nce_loss_bwd(_ptr(G), _ptr(k), _ptr(q), S, C, _ptr(gdev), None if gk is None else _ptr(gk),
+                                         None if gq is None else _ptr(gq), _stream()), "oess_nce_loss_bwd")
+        return gk, gq, None
+
+
+def nce_loss(k, q, temperature=0.07):
+    """NCELoss.forward (utils/loss_functions.py:147-154) on fp32 [S x C] superpixel means."""
+    _need_gpu(k, q)
+    if k.shape != q.shape or k.ndim != 2:
+        raise ValueError("nce_loss: k and q must both be [S, C]")
+    return _NCELoss.apply(k.float().contiguous(), q.float().contiguous(), float(temperature))
+
+
 # ------------------------------------------------------------------------------------------ K11
 def confusion_accumulate(pred, label, num_classes, ignore_label, conf):
     lib = _lib.load()

@@ -35,13 +35,11 @@ class DiceLoss(torch.nn.Module):
 
 
 class NCELoss(torch.nn.Module):
-    """PointInfoNCE: CE(k q^T / T, arange).  S <= 100*B rows: a tiny GEMM (library call) + log-softmax."""
+    """PointInfoNCE: CE(k q^T / T, arange) over the S <= 100*B superpixel rows (utils/loss_functions.py:140-154)."""
 
     def __init__(self, temperature):
         super().__init__()
         self.temperature = temperature
 
     def forward(self, k, q):
-        logits = torch.mm(k.float(), q.float().transpose(1, 0)) / self.temperature
-        target = torch.arange(k.shape[0], device=k.device)
-        return torch.nn.functional.cross_entropy(logits, target)
+        return hip.nce_loss(k, q, self.temperature)                # oess_nce_loss_fwd / _bwd

@@ -173,3 +173,34 @@ def test_consistency_losses_golden(tag, layout):
     assert ga.dtype == torch.bfloat16
     np.testing.assert_allclose(ga.float().cpu().numpy(), rga.cpu().numpy(), rtol=1e-2, atol=1e-6)
     np.testing.assert_allclose(gb.float().cpu().numpy(), rgb.cpu().numpy(), rtol=1e-2, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_nce_loss_golden(golden_losses):
+    """a14 NCELoss (utils/loss_functions.py:140-154) on the HIP kernels vs the reference's golden loss and both input
+    gradients (fp32 throughout: 2e-6 relative on the loss, gradients to summation order), plus a full-size S = 800 case
+    against the oracle."""
+    from openess_amd.utils.loss_functions import NCELoss
+    g = golden_losses
+    k = torch.from_numpy(g["nce_k"]).cuda().requires_grad_(True)
+    q = torch.from_numpy(g["nce_q"]).cuda().requires_grad_(True)
+    loss = NCELoss(temperature=0.07)(k, q)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g["nce_loss"], rtol=2e-6)
+    # gradients are O(1) sums of ~S terms of mixed sign: fp32 summation order shows up at 1e-5 absolute
+    np.testing.assert_allclose(k.grad.cpu().numpy(), g["nce_gk"], rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(q.grad.cpu().numpy(), g["nce_gq"], rtol=2e-5, atol=1e-5)
+    torch.manual_seed(2)
+    S, C = 800, 256
+    kk = torch.nn.functional.normalize(torch.randn(S, C), dim=1)
+    qq = torch.nn.functional.normalize(torch.randn(S, C), dim=1)
+    kk[5] = 0; qq[7] = 0                                     # empty superpixels: zero rows still enter the loss
+    kr, qr = kk.clone().requires_grad_(True), qq.clone().requires_grad_(True)
+    ref = ol.nce_loss(kr, qr, 0.07)
+    ref.backward()
+    kd, qd = kk.cuda().requires_grad_(True), qq.cuda().requires_grad_(True)
+    out = NCELoss(temperature=0.07)(kd, qd)
+    (out * 3.0).backward()
+    np.testing.assert_allclose(out.item(), ref.item(), rtol=1e-5)
+    np.testing.assert_allclose(kd.grad.cpu().numpy(), 3.0 * kr.grad.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(qd.grad.cpu().numpy(), 3.0 * qr.grad.numpy(), rtol=1e-4, atol=1e-6)
