@@ -141,6 +141,35 @@ def conv2d_train(x, weight, bias, pw, k, stride=1, pad=0, dil=1, out_f32=False, 
     return _ConvTrainFn.apply(x, weight, bias, pw, k, stride, pad, dil, out_f32)
 
 
+# ---- BatchNorm2d.num_batches_tracked: one tiny kernel per `+= 1`.  Inside `defer_bn_counters()` (a whole backbone forward)
+# the bumps are collected and applied with ONE multi-tensor add on exit (53 launches -> 1 for the ResNet-50 teacher).
+_BN_COUNTER_STACK = []
+
+
+class defer_bn_counters:
+    def __enter__(self):
+        _BN_COUNTER_STACK.append([])
+        return self
+
+    def __exit__(self, *exc):
+        pending = _BN_COUNTER_STACK.pop()
+        if pending:
+            if _BN_COUNTER_STACK:                    # nested: hand over to the outer scope
+                _BN_COUNTER_STACK[-1].extend(pending)
+            else:
+                torch._foreach_add_(pending, 1)
+        return False
+
+
+def bump_bn_counter(bn):
+    if bn.num_batches_tracked is None:
+        return
+    if _BN_COUNTER_STACK:
+        _BN_COUNTER_STACK[-1].append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked += 1
+
+
 def batch_norm_act(x, bn, relu=False, residual=None):
     """BatchNorm2d (+ residual add + ReLU) on a channels_last bf16 tensor, honouring bn.training exactly like
     nn.BatchNorm2d (batch statistics + running-stat update in train mode).  Train mode runs on the HIP norm kernels
@@ -155,8 +184,8 @@ def batch_norm_act(x, bn, relu=False, residual=None):
         return from_nhwc(hip.batch_norm_train_nhwc(nhwc(x), bn, relu=relu, residual=None if r is None else nhwc(r)))
     y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training,
                      0.0 if bn.momentum is None else bn.momentum, bn.eps)
-    if bn.training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+    if bn.training:
+        bump_bn_counter(bn)
     if residual is not None:
         y = y + residual
     return F.relu(y) if relu else y

@@ -661,8 +661,8 @@ def batch_norm_train_nhwc(x_nhwc, bn, relu=False, residual=None):
     out, _, _ = _norm_forward(x_nhwc, 1, bn.weight.detach(), bn.bias.detach(), bn.eps, relu, residual,
                               running=(bn.running_mean, bn.running_var),
                               momentum=0.0 if bn.momentum is None else bn.momentum)
-    if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+    from . import engine as _engine
+    _engine.bump_bn_counter(bn)
     return out
 
 
@@ -714,8 +714,8 @@ def batch_norm_train(x, bn, relu=False, residual=None):
         residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     y = _BatchNormTrainFn.apply(x, bn.weight, bn.bias, residual, bool(relu), float(bn.eps),
                                 0.0 if bn.momentum is None else float(bn.momentum), bn.running_mean, bn.running_var)
-    if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+    from . import engine as _engine
+    _engine.bump_bn_counter(bn)
     return y
 
 
@@ -955,6 +955,6 @@ def conv_bn_train_nhwc(x, packed, Cout, R, S, stride, pad, dil, bn, relu=False, 
         _, _, _, _, rps = _nhwc_geom(residual)
     _lib.check(lib.oess_norm_apply_nhwc_bf16(_ptr(y), Cout, _ptr(st[4]), _ptr(st[5]), _ptr(residual), rps, int(relu), 1, M, Cout,
                                              _ptr(y), Cout, _stream()), "oess_norm_apply_nhwc_bf16")
-    if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+    from . import engine as _engine
+    _engine.bump_bn_counter(bn)
     return y

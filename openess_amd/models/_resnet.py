@@ -144,11 +144,12 @@ class ResNet(nn.Module):
         return self.maxpool(x)
 
     def features(self, x):
-        x = self.stem(x)
-        x = self.layer1(x)
-        x = self.layer2(x)
-        x = self.layer3(x)
-        return self.layer4(x)
+        with engine.defer_bn_counters():             # 53 num_batches_tracked bumps -> one multi-tensor add
+            x = self.stem(x)
+            x = self.layer1(x)
+            x = self.layer2(x)
+            x = self.layer3(x)
+            return self.layer4(x)
 
     def forward(self, x):
         x = self.features(x)

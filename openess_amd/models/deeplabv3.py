@@ -151,8 +151,9 @@ class deeplabv3_resnet50(nn.Module):
 
     def forward(self, x):
         input_shape = x.shape[-2:]
-        features = self.backbone(x)
-        logist, feats = self.classifier(features)
+        with engine.defer_bn_counters():              # one multi-tensor add for all BatchNorm step counters
+            features = self.backbone(x)
+            logist, feats = self.classifier(features)
         logist = hip.bilinear_resize(logist.float(), size=input_shape, align_corners=False)      # deeplabv3.py:183
         feats = hip.bilinear_resize(feats, size=input_shape, align_corners=False)                # deeplabv3.py:184
         if self.if_linear_probing:
