@@ -196,7 +196,8 @@ int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, 
 /* tile_stats (nullable): [ceil(M/128)][2][Cout] fp32, per-128-row-tile column sums and sums of squares of the fp32
  * result (BatchNorm batch statistics straight from the accumulators; bias-free, no activation/residual).
  * oess_norm_reduce_tile_stats folds them into sum[C] / sumsq[C] for oess_norm_finalize. */
-int oess_norm_reduce_tile_stats(const float* tile_stats, int tiles, int C, float* sum, float* sumsq, oess_stream_t stream);
+int oess_norm_reduce_tile_stats(const float* tile_stats, int tiles, int C, float* sum, float* sumsq, int pre_zeroed,
+                                oess_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * ConvLSTM gate fusion.  Replaces the chunk/sigmoid/tanh/mul/add tail of ConvLSTM.forward
@@ -235,9 +236,11 @@ int oess_event_slice_to_nhwc8_bf16(const float* in, int B, int Ctot, int c0, int
  * (image_model.py:121-143).  G groups of pixels_per_group pixels: G = 1 BatchNorm, G = B InstanceNorm.
  * ------------------------------------------------------------------------------------------ */
 int oess_norm_stats_nhwc_bf16(const void* x, long long x_pix_stride, int G, long long pixels_per_group, int C,
-                              float* sum, float* sumsq, oess_stream_t stream);
-/* mean/rstd/scale/shift are [G x C]; gamma/beta/running_* nullable; running stats updated when G == 1 */
-int oess_norm_finalize(const float* sum, const float* sumsq, int G, int C, float count, float eps, const float* gamma,
+                              float* sum, float* sumsq, int pre_zeroed, oess_stream_t stream);
+/* sum / sumsq are ACCUMULATED into; pre_zeroed = 0 makes the call zero them first.  With pre_zeroed = 1 and
+ * oess_norm_finalize(..., rezero = 1) a caller keeps one persistent zero scratch and never issues a memset
+ * (the finalize kernel clears what it has read). */
+int oess_norm_finalize(float* sum, float* sumsq, int rezero, int G, int C, float count, float eps, const float* gamma,
                        const float* beta, float* running_mean, float* running_var, float momentum, float* mean,
                        float* rstd, float* scale, float* shift, oess_stream_t stream);
 /* out = act(x*scale + shift [+ residual]) */

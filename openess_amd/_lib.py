@@ -64,8 +64,8 @@ SIGNATURES = {
     "oess_nce_loss_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "oess_masked_stats_slice_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp]),
     "oess_event_slice_to_nhwc8_bf16": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_ll, c_vp, c_int, c_vp, c_vp]),
-    "oess_norm_stats_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_ll, c_int, c_vp, c_vp, c_vp]),
-    "oess_norm_finalize": (c_int, [c_vp, c_vp, c_int, c_int, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_vp,
+    "oess_norm_stats_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_ll, c_int, c_vp, c_vp, c_int, c_vp]),
+    "oess_norm_finalize": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_vp,
                                    c_vp]),
     "oess_norm_apply_nhwc_bf16": (c_int, [c_vp, c_ll, c_vp, c_vp, c_vp, c_ll, c_int, c_int, c_ll, c_int, c_vp, c_ll, c_vp]),
     "oess_instnorm_bwd_nhwc_bf16": (c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_int, c_int, c_ll, c_int, c_vp, c_vp, c_vp,
@@ -79,7 +79,7 @@ SIGNATURES = {
     "oess_conv2d_pack_weight": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
     "oess_conv2d_fwd_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                      c_int, c_int, c_int, c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp]),
-    "oess_norm_reduce_tile_stats": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "oess_norm_reduce_tile_stats": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
 }
 
 _lib = None

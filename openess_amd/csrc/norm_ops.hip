@@ -86,7 +86,7 @@ __global__ __launch_bounds__(THREADS) void stats_kernel(const uint16_t* __restri
 }
 
 // mean / rstd / (scale, shift) per (group, channel); optional BatchNorm running-stat update (G == 1).
-__global__ void finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, int G, int C, float count,
+__global__ void finalize_kernel(float* __restrict__ sum, float* __restrict__ sumsq, int rezero, int G, int C, float count,
                                 float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
                                 float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
                                 float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ scale,
@@ -96,6 +96,7 @@ __global__ void finalize_kernel(const float* __restrict__ sum, const float* __re
     const int c = i % C;
     const float m = sum[i] / count;
     float var = sumsq[i] / count - m * m;        // biased variance (normalisation uses it in BN and IN)
+    if (rezero) { sum[i] = 0.f; sumsq[i] = 0.f; }  // self-cleaning accumulators: the caller keeps them zero between uses
     if (var < 0.f) var = 0.f;
     const float r = rsqrtf(var + eps);
     mean_out[i] = m; rstd_out[i] = r;
@@ -410,11 +411,11 @@ static hipError_t zero_pair(float* a, float* b, size_t n, hipStream_t st) {
 extern "C" {
 
 int oess_norm_stats_nhwc_bf16(const void* x, long long x_pix_stride, int G, long long pixels_per_group, int C,
-                              float* sum, float* sumsq, oess_stream_t stream) {
+                              float* sum, float* sumsq, int pre_zeroed, oess_stream_t stream) {
     if (!x || !sum || !sumsq || G <= 0 || pixels_per_group <= 0 || C <= 0 || (C & 7) || C > 2048 || (x_pix_stride & 7))
         return OESS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    OESS_HIP(zero_pair(sum, sumsq, (size_t)G * C, st));
+    if (!pre_zeroed) OESS_HIP(zero_pair(sum, sumsq, (size_t)G * C, st));
     const int cl = C >> 3;
     if (cl > THREADS) return OESS_EINVAL;
     const int rows = THREADS / cl;
@@ -426,10 +427,11 @@ int oess_norm_stats_nhwc_bf16(const void* x, long long x_pix_stride, int G, long
     return OESS_OK;
 }
 
-int oess_norm_reduce_tile_stats(const float* tile_stats, int tiles, int C, float* sum, float* sumsq, oess_stream_t stream) {
+int oess_norm_reduce_tile_stats(const float* tile_stats, int tiles, int C, float* sum, float* sumsq, int pre_zeroed,
+                                oess_stream_t stream) {
     if (!tile_stats || !sum || !sumsq || tiles <= 0 || C <= 0) return OESS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    OESS_HIP(zero_pair(sum, sumsq, (size_t)C, st));
+    if (!pre_zeroed) OESS_HIP(zero_pair(sum, sumsq, (size_t)C, st));
     int gy = (tiles + 63) / 64;                    // >= 8 tiles per tile lane
     if (gy > 32) gy = 32;
     if (gy < 1) gy = 1;
@@ -438,11 +440,11 @@ int oess_norm_reduce_tile_stats(const float* tile_stats, int tiles, int C, float
     return OESS_OK;
 }
 
-int oess_norm_finalize(const float* sum, const float* sumsq, int G, int C, float count, float eps, const float* gamma,
+int oess_norm_finalize(float* sum, float* sumsq, int rezero, int G, int C, float count, float eps, const float* gamma,
                        const float* beta, float* running_mean, float* running_var, float momentum, float* mean,
                        float* rstd, float* scale, float* shift, oess_stream_t stream) {
     if (!sum || !sumsq || !mean || !rstd || !scale || !shift || G <= 0 || C <= 0 || count <= 0.f) return OESS_EINVAL;
-    hipLaunchKernelGGL(finalize_kernel, dim3((G * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sum, sumsq, G, C, count,
+    hipLaunchKernelGGL(finalize_kernel, dim3((G * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sum, sumsq, rezero, G, C, count,
                        eps, gamma, beta, running_mean, running_var, momentum, mean, rstd, scale, shift);
     OESS_HIP(hipGetLastError());
     return OESS_OK;

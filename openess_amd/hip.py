@@ -628,6 +628,35 @@ def attention_d64(qkv, B, L, heads, out=None):
     return out
 
 
+# persistent zero accumulators for the norm statistics (self-cleaning: oess_norm_finalize(rezero=1) clears what it read),
+# so a BatchNorm / InstanceNorm forward issues no memset.  `busy` guards against an exception between stats and finalize.
+_STATS_SCRATCH = {}
+
+
+class _StatsScratch:
+    def __init__(self, n, device):
+        self.buf = torch.zeros((2, n), dtype=torch.float32, device=device)
+        self.busy = False
+
+    def acquire(self):
+        if self.busy:                      # a previous use never reached its finalize: clean up the slow way
+            self.buf.zero_()
+        self.busy = True
+        return self.buf
+
+    def release(self):
+        self.busy = False
+
+
+def _stats_scratch(n, device):
+    # stream-ordered reuse is only safe on one stream: key by the current stream as well
+    key = (device.index, n, torch.cuda.current_stream(device).cuda_stream)
+    sc = _STATS_SCRATCH.get(key)
+    if sc is None:
+        sc = _STATS_SCRATCH[key] = _StatsScratch(n, device)
+    return sc
+
+
 # ------------------------------------------------------------------------------------------ norms / resampling
 def _norm_forward(x_nhwc, G, gamma, beta, eps, relu, residual, running=None, momentum=0.1, out=None):
     """Shared BatchNorm(train)/InstanceNorm forward on an NHWC bf16 view.  Returns (out, mean, rstd)."""
@@ -635,15 +664,18 @@ def _norm_forward(x_nhwc, G, gamma, beta, eps, relu, residual, running=None, mom
     B, H, W, C, ps = _nhwc_geom(x_nhwc)
     ppg = (B * H * W) // G
     dev = x_nhwc.device
-    stats = torch.empty((6, G, C), dtype=torch.float32, device=dev)        # sum, sumsq, mean, rstd, scale, shift
-    _lib.check(lib.oess_norm_stats_nhwc_bf16(_ptr(x_nhwc), ps, G, ppg, C, _ptr(stats[0]), _ptr(stats[1]), _stream()),
+    stats = torch.empty((6, G, C), dtype=torch.float32, device=dev)        # (unused, unused), mean, rstd, scale, shift
+    sc = _stats_scratch(G * C, dev)
+    acc = sc.acquire()                                                      # sum, sumsq: persistent, kept zero
+    _lib.check(lib.oess_norm_stats_nhwc_bf16(_ptr(x_nhwc), ps, G, ppg, C, _ptr(acc[0]), _ptr(acc[1]), 1, _stream()),
                "oess_norm_stats_nhwc_bf16")
     rm = rv = None
     if running is not None:
         rm, rv = running
-    _lib.check(lib.oess_norm_finalize(_ptr(stats[0]), _ptr(stats[1]), G, C, float(ppg), float(eps), _ptr(gamma), _ptr(beta),
+    _lib.check(lib.oess_norm_finalize(_ptr(acc[0]), _ptr(acc[1]), 1, G, C, float(ppg), float(eps), _ptr(gamma), _ptr(beta),
                                       _ptr(rm), _ptr(rv), float(momentum), _ptr(stats[2]), _ptr(stats[3]), _ptr(stats[4]),
                                       _ptr(stats[5]), _stream()), "oess_norm_finalize")
+    sc.release()
     if out is None:
         out = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=dev)
     _, _, _, _, ops = _nhwc_geom(out)
@@ -927,7 +959,7 @@ def channel_sum(x_nhwc):
     lib = _lib.load()
     B, H, W, C, ps = _nhwc_geom(x_nhwc)
     st = torch.empty((2, C), dtype=torch.float32, device=x_nhwc.device)
-    _lib.check(lib.oess_norm_stats_nhwc_bf16(_ptr(x_nhwc), ps, 1, B * H * W, C, _ptr(st[0]), _ptr(st[1]), _stream()),
+    _lib.check(lib.oess_norm_stats_nhwc_bf16(_ptr(x_nhwc), ps, 1, B * H * W, C, _ptr(st[0]), _ptr(st[1]), 0, _stream()),
                "oess_norm_stats_nhwc_bf16")
     return st[0]
 
@@ -944,12 +976,15 @@ def conv_bn_train_nhwc(x, packed, Cout, R, S, stride, pad, dil, bn, relu=False, 
     part = torch.empty((tiles, 2, Cout), dtype=torch.float32, device=x.device)
     y = conv2d_nhwc(x, packed, None, Cout, R, S, stride, pad, dil, tile_stats=part)
     st = torch.empty((6, 1, Cout), dtype=torch.float32, device=x.device)
-    _lib.check(lib.oess_norm_reduce_tile_stats(_ptr(part), tiles, Cout, _ptr(st[0]), _ptr(st[1]), _stream()),
+    sc = _stats_scratch(Cout, x.device)
+    acc = sc.acquire()
+    _lib.check(lib.oess_norm_reduce_tile_stats(_ptr(part), tiles, Cout, _ptr(acc[0]), _ptr(acc[1]), 1, _stream()),
                "oess_norm_reduce_tile_stats")
     mom = 0.0 if bn.momentum is None else bn.momentum
-    _lib.check(lib.oess_norm_finalize(_ptr(st[0]), _ptr(st[1]), 1, Cout, float(M), float(bn.eps), _ptr(bn.weight.detach()),
+    _lib.check(lib.oess_norm_finalize(_ptr(acc[0]), _ptr(acc[1]), 1, 1, Cout, float(M), float(bn.eps), _ptr(bn.weight.detach()),
                                       _ptr(bn.bias.detach()), _ptr(bn.running_mean), _ptr(bn.running_var), float(mom),
                                       _ptr(st[2]), _ptr(st[3]), _ptr(st[4]), _ptr(st[5]), _stream()), "oess_norm_finalize")
+    sc.release()
     rps = 0
     if residual is not None:
         _, _, _, _, rps = _nhwc_geom(residual)
