@@ -166,6 +166,18 @@ int oess_nce_loss_bwd(const float* grad_logits, const float* k, const float* q, 
                       float* grad_q, oess_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * a18 AdamW step for a whole parameter list in one launch (torch.optim.AdamW as built in
+ * training/pretrain_trainer.py:231-243: decoupled weight decay, amsgrad off), ATen's operation order.
+ * table: device int64 [n_tensors][5] = {param, grad, exp_avg, exp_avg_sq pointers (fp32), numel};
+ * chunk_map: device int32 [n_chunks][2] = {tensor index, chunk index}, chunks of chunk_elems elements.
+ * bias_correction1 = 1 - beta1^step, bias_correction2_sqrt = sqrt(1 - beta2^step); all scalars are doubles (the Python
+ * optimiser's own values) and are rounded to fp32 once, so 1 - beta2 etc. match the library bit for bit.
+ * ------------------------------------------------------------------------------------------ */
+int oess_adamw_multi_f32(const int64_t* table, int n_tensors, const int32_t* chunk_map, int n_chunks, int chunk_elems, double lr,
+                         double beta1, double beta2, double eps, double weight_decay, double bias_correction1,
+                         double bias_correction2_sqrt, oess_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * K11 Confusion matrix (evaluation/metrics.py:4-23): conf[gt*K + pred] += 1 over gt != ignore.
  * conf: K*K int64, ACCUMULATED into (caller zeroes once per validation epoch).
  * ------------------------------------------------------------------------------------------ */

@@ -14,6 +14,7 @@ c_i64 = ctypes.c_int64
 c_ll = ctypes.c_longlong
 c_int = ctypes.c_int
 c_f = ctypes.c_float
+c_d = ctypes.c_double
 c_vp = ctypes.c_void_p
 c_sz = ctypes.c_size_t
 
@@ -62,6 +63,7 @@ SIGNATURES = {
     "oess_attention_d64_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_f, c_vp, c_ll, c_vp]),
     "oess_nce_loss_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_f, c_vp, c_vp, c_sz, c_vp, c_vp]),
     "oess_nce_loss_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "oess_adamw_multi_f32": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_d, c_d, c_d, c_d, c_d, c_d, c_d, c_vp]),
     "oess_masked_stats_slice_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp]),
     "oess_event_slice_to_nhwc8_bf16": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_ll, c_vp, c_int, c_vp, c_vp]),
     "oess_norm_stats_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_ll, c_int, c_vp, c_vp, c_int, c_vp]),

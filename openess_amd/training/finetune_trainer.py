@@ -12,6 +12,7 @@ from ..e2vid.model.model import E2VID_LIGHTWEIGHT_CONFIG, E2VIDRecurrent
 from ..models.deeplabv3 import deeplabv3_resnet50
 from ..models.style_networks import SemSegE2VID
 from ..utils.loss_functions import TaskLoss
+from ..utils.optim import AdamW          # torch.optim.AdamW with its step on the multi-tensor HIP kernel
 from .base_trainer_ov import BaseTrainer
 
 
@@ -41,7 +42,7 @@ class _SupervisedTrainer(BaseTrainer):
                                             if_linear_probing=self.linear_probing, materialize_ch256=False)
             self.models_dict['back_end'] = self.task_backend
             trainable = [p for p in self.task_backend.parameters() if p.requires_grad]
-            self.optimizers_dict = {'optimizer_voxel': torch.optim.AdamW(trainable, lr=s.lr_voxel)}
+            self.optimizers_dict = {'optimizer_voxel': AdamW(trainable, lr=s.lr_voxel)}
         elif s.config_option == 'frame2recon':
             self.model_recon = deeplabv3_resnet50(num_classes=s.semseg_num_classes, text_embeddings_path=text_path,
                                                   output_stride=s.output_stride, pretrained_backbone=s.pretrained_backbone,
@@ -50,7 +51,7 @@ class _SupervisedTrainer(BaseTrainer):
                                                   frozen_backbone=s.frozen_backbone)
             self.models_dict['model_recon'] = self.model_recon
             trainable = [p for p in self.model_recon.parameters() if p.requires_grad]
-            self.optimizers_dict = {'optimizer_recon': torch.optim.AdamW(trainable, lr=s.lr_recon)}
+            self.optimizers_dict = {'optimizer_recon': AdamW(trainable, lr=s.lr_recon)}
         else:
             raise NotImplementedError(s.config_option)
         for m in self.models_dict.values():

@@ -17,6 +17,7 @@ import torch.nn.functional as f
 from .. import hip
 from ..models.deeplabv3 import deeplabv3_resnet50
 from ..utils.loss_functions import NCELoss, TaskLoss
+from ..utils.optim import AdamW          # torch.optim.AdamW with its step on the multi-tensor HIP kernel
 from .base_trainer_ov import BaseTrainer
 
 
@@ -42,8 +43,8 @@ class OpenESSModel(BaseTrainer):
         self.nce_loss = NCELoss(temperature=0.07)
         self.l1_loss = torch.nn.L1Loss()
         self.optimizers_dict = {
-            'optimizer_recon': torch.optim.AdamW([p for p in self.model_recon.parameters() if p.requires_grad], lr=s.lr_recon),
-            'optimizer_frame': torch.optim.AdamW([p for p in self.model_frame.parameters() if p.requires_grad], lr=s.lr_frame)}
+            'optimizer_recon': AdamW([p for p in self.model_recon.parameters() if p.requires_grad], lr=s.lr_recon),
+            'optimizer_frame': AdamW([p for p in self.model_frame.parameters() if p.requires_grad], lr=s.lr_frame)}
 
     def task_train_step(self, batch):
         s = self.settings

@@ -15,6 +15,7 @@ from ..models.deeplabv3 import deeplabv3_resnet50
 from ..models.image_model import DilationFeatureExtractor
 from ..models.style_networks import SemSegE2VID
 from ..utils.loss_functions import NCELoss, TaskLoss
+from ..utils.optim import AdamW          # torch.optim.AdamW with its step on the multi-tensor HIP kernel
 
 
 class PretrainStep:
@@ -66,12 +67,12 @@ class PretrainStep:
         if config_option == 'frame2voxel':
             params_voxel = [p for p in self.task_backend.parameters() if p.requires_grad]
             params_voxel = [p for p in self.front_end_sensor_b.parameters() if p.requires_grad] + params_voxel
-            self.optimizers_dict = {'optimizer_voxel': torch.optim.AdamW(params_voxel, lr=lr),
-                                    'optimizer_frame': torch.optim.AdamW(params_frame, lr=lr)}
+            self.optimizers_dict = {'optimizer_voxel': AdamW(params_voxel, lr=lr),
+                                    'optimizer_frame': AdamW(params_frame, lr=lr)}
         else:
             params_recon = [p for p in self.model_recon.parameters() if p.requires_grad]
-            self.optimizers_dict = {'optimizer_recon': torch.optim.AdamW(params_recon, lr=lr),
-                                    'optimizer_frame': torch.optim.AdamW(params_frame, lr=lr)}
+            self.optimizers_dict = {'optimizer_recon': AdamW(params_recon, lr=lr),
+                                    'optimizer_frame': AdamW(params_frame, lr=lr)}
 
     # ------------------------------------------------------------------ pretrain_trainer.py:364-534
     def _set_modes(self):

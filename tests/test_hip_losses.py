@@ -204,3 +204,33 @@ def test_nce_loss_golden(golden_losses):
     np.testing.assert_allclose(out.item(), ref.item(), rtol=1e-5)
     np.testing.assert_allclose(kd.grad.cpu().numpy(), 3.0 * kr.grad.numpy(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(qd.grad.cpu().numpy(), 3.0 * qr.grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_adamw_multi_tensor_matches_torch():
+    """a18: openess_amd.utils.optim.AdamW (one multi-tensor HIP launch) vs torch.optim.AdamW over 4 steps on a ragged
+    parameter list (a parameter whose grad is None at first joins later; two groups with different lr / weight decay),
+    and state_dict interchange in both directions."""
+    from openess_amd.utils.optim import AdamW
+    torch.manual_seed(0)
+    shapes = [(64, 32, 3, 3), (64,), (7,), (300, 300), (1,), (70000,)]
+    ref_p = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    my_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    mk = lambda cls, ps: cls([{'params': ps[:3], 'lr': 5e-4}, {'params': ps[3:], 'lr': 5e-6, 'weight_decay': 0.05}])
+    ref, mine = mk(torch.optim.AdamW, ref_p), mk(AdamW, my_p)
+    for step in range(4):
+        for i, (a, b) in enumerate(zip(ref_p, my_p)):
+            if i == 2 and step < 2:
+                a.grad = b.grad = None                                   # joins at step 2
+                continue
+            g = torch.randn_like(a)
+            a.grad, b.grad = g.clone(), g.clone()
+        ref.step(); mine.step()
+        for a, b in zip(ref_p, my_p):
+            np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)   # 1 ulp of the update
+    sd_ref, sd_mine = ref.state_dict(), mine.state_dict()
+    assert sd_ref['state'].keys() == sd_mine['state'].keys()
+    for k in sd_ref['state']:
+        assert float(sd_ref['state'][k]['step']) == float(sd_mine['state'][k]['step'])
+        np.testing.assert_allclose(sd_mine['state'][k]['exp_avg_sq'].cpu().numpy(), sd_ref['state'][k]['exp_avg_sq'].cpu().numpy(), rtol=2e-6, atol=1e-12)
+    mine.load_state_dict(sd_ref); ref.load_state_dict(sd_mine)         # interchangeable
