@@ -78,13 +78,11 @@ __device__ __forceinline__ float conv_act(float v, int mode) {
 // PITCH: row pitch (elements) of the bf16 LDS image.  BN + 8 pads the image; BN (no padding) makes it exactly one
 // ring stage (the persistent kernel parks it in the stage it has just finished reading) and still reads conflict
 // free: the 16-lane groups of ds_read_b128 cover 16 distinct 16-byte chunks of a 256-byte row pair.
-template <int BMX, int BN, int PITCH = BN + 8>
+template <int BMX, int BN, int PITCH = BN + 8, int NTHREADS = conv_tile_threads(BMX), int WAVES_N = (BN == 128) ? 2 : 1>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
-                                              f32x16_t (&acc)[BMX / ((conv_tile_threads(BMX) / 64) / ((BN == 128) ? 2 : 1)) / 32][(BN / ((BN == 128) ? 2 : 1)) / 32],
+                                              f32x16_t (&acc)[BMX / ((NTHREADS / 64) / WAVES_N) / 32][(BN / WAVES_N) / 32],
                                               unsigned char* smem, int m0, int n0, int wm, int wn, int lane, int tid,
                                               float* red_override = nullptr) {
-    constexpr int NTHREADS = conv_tile_threads(BMX);
-    constexpr int WAVES_N = (BN == 128) ? 2 : 1;
     constexpr int WAVES_M = (NTHREADS / 64) / WAVES_N;
     constexpr int WM = BMX / WAVES_M;
     constexpr int WN = BN / WAVES_N;
@@ -209,28 +207,58 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
-__device__ __forceinline__ void lstm_epilogue(const ConvArgs& a, f32x16_t (&acc)[2][2], unsigned char* smem, int m0, int n0,
-                                              int wm, int wn, int lane, int tid) {
-    constexpr int CP = 33, HP = 34;                        // LDS pitches: fp32 cell image, bf16 hidden image
-    float* lc = reinterpret_cast<float*>(smem);            // [128][33]
-    uint16_t* lh = reinterpret_cast<uint16_t*>(smem + 128 * CP * 4);    // [128][34]
-    const int C = a.lstm_C;
-    const int hc0 = n0 >> 2;                               // first hidden channel of this tile (32 per 128-row n tile)
-    const int p = lane & 31, hi = lane >> 5;
+// Previous cell state of a 128-row x 32-hidden-channel tile, fetched COALESCED (whole 128-byte rows, float4 per lane)
+// at kernel start so the loads retire under the K loop; the epilogue redistributes it through LDS.  (Read in place by
+// the lanes that own the gates it would be 16 loads per lane touching 32 different lines each, issued after the K loop.)
+struct LstmPrefetch { float4 v[4]; };
+__device__ __forceinline__ void lstm_prefetch(const ConvArgs& a, LstmPrefetch& p, int m0, int n0, int tid) {
+    const int hc0 = n0 >> 2;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ml = wm * 64 + i * 32 + p;
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + 256 * k, row = idx >> 3, c4 = idx & 7;
+        const int m = m0 + row;
+        p.v[k] = (a.lstm_prev && m < a.M) ? *reinterpret_cast<const float4*>(a.lstm_prev + (long long)m * a.lstm_C + hc0 + c4 * 4)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+template <int MT = 2, int NT = 2, bool PREF = false>
+__device__ __forceinline__ void lstm_epilogue(const ConvArgs& a, f32x16_t (&acc)[MT][NT], unsigned char* smem, int m0, int n0,
+                                              int wm, int wn, int lane, int tid, const LstmPrefetch* pref = nullptr) {
+    // 2 x 2 waves; workgroup tile = 64*MT rows x 64*NT gate columns = 16*NT hidden channels
+    constexpr int ROWS = 64 * MT, HC = 16 * NT;
+    constexpr int CP = HC + 1, HP = HC + 2;                // LDS pitches: fp32 cell image, bf16 hidden image
+    static_assert(!PREF || (MT == 2 && NT == 2), "prefetch layout is the 128 x 128 tile's");
+    float* lc = reinterpret_cast<float*>(smem);            // [ROWS][CP]
+    uint16_t* lh = reinterpret_cast<uint16_t*>(smem + ROWS * CP * 4);    // [ROWS][HP]
+    const int C = a.lstm_C;
+    const int hc0 = n0 >> 2;                               // first hidden channel of this tile
+    const int p = lane & 31, hi = lane >> 5;
+    if constexpr (PREF) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + 256 * k, row = idx >> 3, c4 = idx & 7;
+            float* d = lc + row * CP + c4 * 4;
+            d[0] = pref->v[k].x; d[1] = pref->v[k].y; d[2] = pref->v[k].z; d[3] = pref->v[k].w;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int ml = wm * 32 * MT + i * 32 + p;
         const int m = m0 + ml;
         const bool valid = m < a.M;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int hcl = wn * 16 + j * 8 + 2 * q + hi;
+                const int hcl = wn * 8 * NT + j * 8 + 2 * q + hi;
                 const int hc = hc0 + hcl;
                 float gi = acc[i][j][q * 4 + 0], gr = acc[i][j][q * 4 + 1], go = acc[i][j][q * 4 + 2], gc = acc[i][j][q * 4 + 3];
                 if (a.bias) { gi += a.bias[hc]; gr += a.bias[C + hc]; go += a.bias[2 * C + hc]; gc += a.bias[3 * C + hc]; }
-                const float pc = (a.lstm_prev && valid) ? a.lstm_prev[(long long)m * C + hc] : 0.0f;
+                float pc;
+                if constexpr (PREF) pc = lc[ml * CP + hcl];              // this lane is the slot's only reader and writer
+                else pc = (a.lstm_prev && valid) ? a.lstm_prev[(long long)m * C + hc] : 0.0f;
                 const float nc = fast_sigmoid(gr) * pc + fast_sigmoid(gi) * fast_tanh(gc);     // submodules.py:211
                 const float hv = fast_sigmoid(go) * fast_tanh(nc);                              // submodules.py:212
                 lc[ml * CP + hcl] = nc;
@@ -238,16 +266,16 @@ __device__ __forceinline__ void lstm_epilogue(const ConvArgs& a, f32x16_t (&acc)
             }
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {                         // cell: 128 rows x 32 fp32, one 128-byte row per 32 lanes
-        const int idx = tid + 256 * k, row = idx >> 5, col = idx & 31;
+#pragma unroll 4
+    for (int idx = tid; idx < ROWS * HC; idx += 256) {     // cell: ROWS x HC fp32, whole rows per lane group
+        const int row = idx / HC, col = idx - row * HC;
         const int m = m0 + row;
         if (m < a.M) a.lstm_cell[(long long)m * C + hc0 + col] = lc[row * CP + col];
     }
     const uint32_t* lh32 = reinterpret_cast<const uint32_t*>(lh);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {                          // hidden: 128 rows x 16 dwords (2 bf16 each)
-        const int idx = tid + 256 * k, row = idx >> 4, col = idx & 15;
+#pragma unroll 4
+    for (int idx = tid; idx < ROWS * (HC / 2); idx += 256) {   // hidden: ROWS x HC/2 dwords (2 bf16 each)
+        const int row = idx / (HC / 2), col = idx - row * (HC / 2);
         const int m = m0 + row;
         if (m < a.M) *reinterpret_cast<uint32_t*>(a.lstm_h + (long long)m * a.lstm_h_stride + hc0 + col * 2) = lh32[row * (HP / 2) + col];
     }
@@ -416,11 +444,12 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_fwd_kernel(ConvArgs a) {
 // =================================================================================================
 // FASTK: Cin % 64 == 0, i.e. every 64-wide K-slab lies inside ONE filter tap -> the tap decode is wave-uniform
 // (scalar) and the per-lane part of a gather address is a constant.
-template <int BMX, int BN, int NSTAGE, bool FASTK, int EPI = 0>
-__global__ __launch_bounds__(conv_tile_threads(BMX)) void conv_fwd_dma_kernel(ConvArgs a) {
-    constexpr int NTHREADS = conv_tile_threads(BMX); // 64 / 128-row tile: 4 waves, 256-row tile: 8 waves
-    constexpr int NWAVES = NTHREADS / 64;
-    constexpr int WAVES_N = (BN == 128) ? 2 : 1;
+// NTHREADS = 256 with a 256 x 256 tile gives the vendor-GEMM shape: 4 waves, each a 128 x 128 wave tile (16 MFMAs per
+// 8 fragment reads instead of 4 per 4 -> half the LDS read bytes per FLOP), 2 x 64 KB ring, 1 workgroup per CU.
+template <int BMX, int BN, int NSTAGE, bool FASTK, int EPI = 0, int NTHREADS = conv_tile_threads(BMX)>
+__global__ __launch_bounds__(NTHREADS) void conv_fwd_dma_kernel(ConvArgs a) {
+    constexpr int NWAVES = NTHREADS / 64;            // 64 / 128-row tile: 4 waves, 256 x 128 tile: 8 waves
+    constexpr int WAVES_N = (BN >= 128) ? 2 : 1;
     constexpr int WAVES_M = NWAVES / WAVES_N;
     constexpr int WM = BMX / WAVES_M;
     constexpr int WN = BN / WAVES_N;
@@ -541,6 +570,9 @@ __global__ __launch_bounds__(conv_tile_threads(BMX)) void conv_fwd_dma_kernel(Co
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
         if (s < KT) issue(s);
+    constexpr bool LSTM_PREF = (EPI == 1 && MT == 2 && NT == 2);
+    LstmPrefetch pref;
+    if constexpr (LSTM_PREF) lstm_prefetch(a, pref, m0, n0, tid);
 
 #define OESS_FRAG_READ(DST_A, DST_B, KS)                                                                         \
     {                                                                                                            \
@@ -560,7 +592,10 @@ __global__ __launch_bounds__(conv_tile_threads(BMX)) void conv_fwd_dma_kernel(Co
     // wait until only N_ LDS reads remain outstanding; the "+v" operands tie later uses of the fragments to the wait
 #define OESS_WAIT_FRAGS(N_, FA_, FB_)                                                                            \
     {                                                                                                            \
-        if constexpr (MT == 2 && NT == 2)                                                                        \
+        if constexpr (MT == 4 && NT == 4)                                                                        \
+            asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(FA_[0]), "+v"(FA_[1]), "+v"(FA_[2]), "+v"(FA_[3]),       \
+                         "+v"(FB_[0]), "+v"(FB_[1]), "+v"(FB_[2]), "+v"(FB_[3]) : "n"(N_) : "memory");           \
+        else if constexpr (MT == 2 && NT == 2)                                                                   \
             asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(FA_[0]), "+v"(FA_[1]), "+v"(FB_[0]), "+v"(FB_[1]) : "n"(N_) : "memory"); \
         else if constexpr (MT == 1 && NT == 2)                                                                   \
             asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(FA_[0]), "+v"(FB_[0]), "+v"(FB_[1]) : "n"(N_) : "memory"); \
@@ -607,8 +642,9 @@ __global__ __launch_bounds__(conv_tile_threads(BMX)) void conv_fwd_dma_kernel(Co
 #undef OESS_WAIT_FRAGS
     __syncthreads();
 
-    if constexpr (EPI == 1) lstm_epilogue(a, acc, smem, m0, n0, wm, wn, lane, tid);
-    else conv_epilogue<BMX, BN>(a, acc, smem, m0, n0, wm, wn, lane, tid);
+    if constexpr (LSTM_PREF) lstm_epilogue<MT, NT, true>(a, acc, smem, m0, n0, wm, wn, lane, tid, &pref);
+    else if constexpr (EPI == 1) lstm_epilogue<MT, NT>(a, acc, smem, m0, n0, wm, wn, lane, tid);
+    else conv_epilogue<BMX, BN, BN + 8, NTHREADS, WAVES_N>(a, acc, smem, m0, n0, wm, wn, lane, tid);
 }
 
 // =================================================================================================
@@ -789,6 +825,176 @@ __global__ __launch_bounds__(256) void conv_fwd_dma32_kernel(ConvArgs a) {
 
     if constexpr (EPI == 1) lstm_epilogue(a, acc, smem, m0, n0, wm, wn, lane, tid);
     else conv_epilogue<BMX, BN>(a, acc, smem, m0, n0, wm, wn, lane, tid);
+}
+
+// =================================================================================================
+// v5: 256 x 256 tile, 4 waves, 128 x 128 WAVE tile (the vendor GEMM's shape: 16 MFMAs per 8 fragment reads, half the
+// LDS read bytes per FLOP of the 64 x 64 wave tile), BK = 32 slabs in a 4-deep ring (128 KB), one workgroup per CU.
+// With ONE wave per SIMD nothing hides a stall, so the loop is software pipelined by hand:
+//   * a slab is DMA-issued three slabs before it is consumed (3 x 1024 MFMA cycles > the L2 -> LDS round trip),
+//     and the 8 DMA instructions of a thread are spread between the MFMAs of k-step 0;
+//   * fragments of the next k-step (also across the slab boundary) are read under the current k-step's MFMAs;
+//   * the only barrier per slab sits between the two k-steps, when the MFMA pipe still holds k-step 0's tail.
+// Needs Cin % 32 == 0 (one filter tap per slab -> scalar tap decode).
+// =================================================================================================
+template <int EPI>
+__global__ __launch_bounds__(256) void conv_fwd_t256_kernel(ConvArgs a) {
+    constexpr int BMX = 256, BN = 256, BKS = 32, NST = 4;
+    constexpr int WM = 128, WN = 128, MT = 4, NT = 4;
+    constexpr int A_INSTR = 4, B_INSTR = 4;             // 16 rows x 64 B per wave instruction, 4 waves
+    constexpr int A_BYTES = BMX * 64;
+    constexpr int STAGE_BYTES = (BMX + BN) * 64;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nwg = a.tiles_m * a.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
+    const int m0 = tile_m * BMX, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int KT = a.Kpad / BKS;
+    const int cpt = a.Cin >> 3, ntaps = a.R * a.S;
+
+    const long long in_bytes = (((long long)a.B * a.H * a.W - 1) * a.in_pix_stride + a.Cin) * 2;
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7ffffff0, 0x00020000);
+
+    const int lrow = lane >> 2, slot = lane & 3;       // 16 rows x 4 chunk slots per wave instruction
+    int iy0[A_INSTR], ix0[A_INSTR], rowoff[A_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int r = (wave * A_INSTR + i) * 16 + lrow;
+        const int m = m0 + r;
+        const bool valid = m < a.M;
+        const int mm = valid ? m : 0;
+        const int hw = a.Ho * a.Wo;
+        const int b = mm / hw, rem = mm - b * hw;
+        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        iy0[i] = valid ? oy * a.stride - a.pad : -0x4000;
+        ix0[i] = ox * a.stride - a.pad;
+        rowoff[i] = (int)((((long long)b * a.H + (oy * a.stride - a.pad)) * a.W + ix0[i]) * a.in_pix_stride * 2) +
+                    (slot ^ ((r >> 2) & 3)) * 16;
+    }
+    int boff[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int r = (wave * B_INSTR + i) * 16 + lrow;
+        boff[i] = ((n0 + r) * a.Kpad + (slot ^ ((r >> 2) & 3)) * 8) * 2;
+    }
+
+    // wave-uniform decode of slab kt (one filter tap, 32 channels of it)
+    int s_dy = 0, s_dx = 0, s_tapoff = 0;
+    unsigned s_boff = 0;
+    bool s_ok = false;
+    unsigned char* s_st = smem;
+    auto decode = [&](int kt) {
+        const unsigned kc0 = (unsigned)(kt * 4);
+        const unsigned tap = (kc0 * a.inv_cpt) >> 20;
+        const int cc0 = (int)(kc0 - tap * cpt);
+        const unsigned r = (tap * a.inv_s) >> 16;
+        const int sx = (int)(tap - r * a.S);
+        s_dy = (int)r * a.dil; s_dx = sx * a.dil;
+        s_tapoff = ((s_dy * a.W + s_dx) * (int)a.in_pix_stride + cc0 * 8) * 2;
+        s_ok = (int)tap < ntaps && kt < KT;
+        s_st = smem + (kt & (NST - 1)) * STAGE_BYTES;
+        s_boff = kt < KT ? (unsigned)(kt * BKS * 2) : 0x80000000u;     // dummy slab: out of range -> zeros
+    };
+    auto issue_a = [&](int i) {
+        const bool ok = s_ok && (unsigned)(iy0[i] + s_dy) < (unsigned)a.H && (unsigned)(ix0[i] + s_dx) < (unsigned)a.W;
+        const unsigned voff = ok ? (unsigned)(rowoff[i] + s_tapoff) : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(s_st + (wave * A_INSTR + i) * 1024),
+                                                 16, voff, 0, 0, 0);
+    };
+    auto issue_b = [&](int i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(s_st + A_BYTES + (wave * B_INSTR + i) * 1024),
+                                                 16, (unsigned)boff[i] + s_boff, 0, 0, 0);
+    };
+
+    f32x16_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    uint32_t fa_off[MT], fb_off[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa_off[i] = (uint32_t)(wm * WM + i * 32 + (lane & 31)) * 64;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb_off[j] = (uint32_t)(A_BYTES + (wn * WN + j * 32 + (lane & 31)) * 64);
+    const int half = lane >> 5;
+    const int rsw = ((lane & 31) >> 2) & 3;
+    const uint32_t sl0 = (uint32_t)(((0 + half) ^ rsw) * 16), sl1 = (uint32_t)(((2 + half) ^ rsw) * 16);
+
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) {
+        decode(s);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { issue_a(i); issue_b(i); }
+    }
+
+#define OESS_FR(DST_A, DST_B, SL)                                                                                \
+    {                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                           \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(DST_A[i]) : "v"(stage_ + fa_off[i] + SL) : "memory");     \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                           \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(DST_B[j]) : "v"(stage_ + fb_off[j] + SL) : "memory");     \
+    }
+#define OESS_MFMA(I_, J_, SA_, SB_)                                                                              \
+    acc[I_][J_] = (EPI == 1) ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(SB_[J_], SA_[I_], acc[I_][J_], 0, 0, 0)   \
+                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(SA_[I_], SB_[J_], acc[I_][J_], 0, 0, 0);
+#define OESS_WAITF(N_, FA_, FB_)                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(FA_[0]), "+v"(FA_[1]), "+v"(FA_[2]), "+v"(FA_[3]),               \
+                 "+v"(FB_[0]), "+v"(FB_[1]), "+v"(FB_[2]), "+v"(FB_[3]) : "n"(N_) : "memory");
+
+    // Branch-free loop: slabs beyond KT are issued as dummies (out-of-range offsets: the DMA writes zeros into a stage
+    // nobody reads again), so every iteration issues exactly 8 DMA instructions per thread and the retire wait is
+    // always vmcnt(16) = "the two younger slabs may stay in flight".  (A branchy version made hipcc shuffle the 256
+    // accumulators between AGPRs and VGPRs on every iteration.)
+    bf16x8_t fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    uint32_t stage_ = lds0;
+    OESS_FR(fa0, fb0, sl0)
+
+    for (int kt = 0; kt < KT; ++kt) {
+        OESS_FR(fa1, fb1, sl1)                           // k-step 1 of slab kt, in flight under k-step 0's MFMAs
+        OESS_WAITF(8, fa0, fb0)
+        __builtin_amdgcn_sched_barrier(0);
+        decode(kt + NST - 1);                            // its stage held slab kt-1, free since the last barrier
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { OESS_MFMA(i, j, fa0, fb0) }
+            issue_a(i);
+            issue_b(i);
+        }
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // slab kt+1: this thread's parts (the barrier makes it everyone's)
+        OESS_WAITF(0, fa1, fb1)                          // every read of slab kt has landed in registers
+        __builtin_amdgcn_s_barrier();
+        stage_ = lds0 + (uint32_t)(((kt + 1) & (NST - 1)) * STAGE_BYTES);
+        OESS_FR(fa0, fb0, sl0)                           // k-step 0 of slab kt+1 under k-step 1's MFMAs
+        __builtin_amdgcn_sched_barrier(0);               // keep all 8 reads in front of the 16 MFMAs that hide them
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { OESS_MFMA(i, j, fa1, fb1) }
+    }
+#undef OESS_FR
+#undef OESS_MFMA
+#undef OESS_WAITF
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // dummy slabs must land before the epilogue reuses the LDS
+    __syncthreads();
+
+    if constexpr (EPI == 1) lstm_epilogue<MT, NT>(a, acc, smem, m0, n0, wm, wn, lane, tid);
+    else conv_epilogue<BMX, BN, BN + 8, 256, 2>(a, acc, smem, m0, n0, wm, wn, lane, tid);
 }
 
 // =================================================================================================
@@ -1228,6 +1434,7 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
                              (const void*)&conv_fwd_dma_kernel<256, 128, 3, false>, (const void*)&conv_fwd_dma_kernel<256, 128, 3, true>,
                              (const void*)&conv_fwd_dma_kernel<256, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<256, 128, 2, true>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 2, false, 1>, (const void*)&conv_fwd_dma_kernel<128, 128, 2, true, 1>,
+                             (const void*)&conv_fwd_t256_kernel<0>, (const void*)&conv_fwd_t256_kernel<1>,
                              (const void*)&conv_fwd_dma32_kernel<128, false, 0>, (const void*)&conv_fwd_dma32_kernel<128, true, 0>,
                              (const void*)&conv_fwd_dma32_kernel<64, false, 0>, (const void*)&conv_fwd_dma32_kernel<64, true, 0>,
                              (const void*)&conv_fwd_dma32_kernel<128, false, 1>, (const void*)&conv_fwd_dma32_kernel<128, true, 1>,
@@ -1307,6 +1514,28 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
         hipLaunchKernelGGL((conv_smallcin_kernel<5, 5>), dim3(tiles), dim3(256), 0, st, a);
         OESS_HIP(hipGetLastError());
         return OESS_OK;
+    }
+    // 256 x 256 tile, 4 waves x (128 x 128), software-pipelined BK = 32 ring (conv_fwd_t256_kernel).  Measured
+    // (tools/conv_ablate.py, same box): while all 256 CUs hold a tile it runs 1150 TF/s against 1030 TF/s for the
+    // 128 x 128 kernel (+11 %), but one workgroup per CU means 256 slots, and on the model's shapes the coarser tile
+    // quantisation gives all of it back (gates / gk4: 1100 tiles = 4.3 rounds -> 5; 989 vs 986 TF/s end to end), and
+    // small layers lose outright.  Opt-in until the remainder is balanced stream-K style:
+    // OESS_CONV_T256 = 0 off (default), 1 when the round model predicts a gain, 2 always (when legal).
+    static int t256 = -1;
+    if (t256 < 0) { const char* e = getenv("OESS_CONV_T256"); t256 = e ? atoi(e) : 0; }
+    if (use == 2 && t256 && (Cout % 256) == 0 && fastk32) {
+        const long long tm = (a.M + 255) / 256, tn = Cout / 256, t = tm * tn;
+        const long long t128 = (long long)a.tiles_m * a.tiles_n;
+        const double e256 = 1.11 * (double)t / (double)(((t + 255) / 256) * 256);
+        const double e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
+        if (t256 == 2 || (t >= 512 && e256 > e128 * 1.03)) {
+            a.tiles_m = (int)tm; a.tiles_n = (int)tn;
+            const size_t lds = lstm ? (size_t)4 * 512 * 64 : (size_t)256 * (256 + 8) * 2 + 4096;   // ring 128 KB; output image 132 KB + partials
+            if (lstm) hipLaunchKernelGGL((conv_fwd_t256_kernel<1>), dim3((unsigned)t), dim3(256), lds, st, a);
+            else hipLaunchKernelGGL((conv_fwd_t256_kernel<0>), dim3((unsigned)t), dim3(256), lds, st, a);
+            OESS_HIP(hipGetLastError());
+            return OESS_OK;
+        }
     }
     if (lstm) {     // fused ConvLSTM cell update: transposed MFMA + lane-local gate algebra (needs the LDS-DMA kernel)
         if (use < 2) return OESS_EINVAL;
