@@ -118,8 +118,18 @@ class ConvLSTM(nn.Module):
                     pw['bias'] = g.bias.detach().float().contiguous()
                 pw['key'] = key
             h_view = state['xh'][1 - cur][:, self.input_size:]
-            hip.convlstm_fused(engine.nhwc(xh), pw['packed'], pw['bias'], state['cell'], engine.nhwc(h_view), k, pad,
-                               prev_cell_is_zero=state['fresh'])
+            if state['fresh'] and os.environ.get('OESS_LSTM_NO_FRESH_SKIP') is None:
+                # first sub-window: h_prev = 0 and c_prev = 0 (submodules.py:190-198), so the h half of the Gates
+                # reduction contributes nothing -> convolve the x half only (half the K loop), same cell update
+                if pw.get('packed_x') is None or pw.get('key_x') != key:
+                    with torch.no_grad():
+                        pw['packed_x'] = hip.pack_conv_weight(g.weight[:, :self.input_size], flip=2)
+                    pw['key_x'] = key
+                hip.convlstm_fused(engine.nhwc(xh[:, :self.input_size]), pw['packed_x'], pw['bias'], state['cell'],
+                                   engine.nhwc(h_view), k, pad, prev_cell_is_zero=True)
+            else:
+                hip.convlstm_fused(engine.nhwc(xh), pw['packed'], pw['bias'], state['cell'], engine.nhwc(h_view), k, pad,
+                                   prev_cell_is_zero=state['fresh'])
             state['cur'] = 1 - cur
         else:
             pw = self._pw.get(g.weight, g.bias, None, cin_pad=xh.shape[1])
