@@ -655,9 +655,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_dma_kernel(ConvArgs a) {
 // is issued three compute phases before it is needed.  64-byte LDS rows: chunk c of row r lives at
 // c ^ ((r >> 2) & 3) (conflict free for the ds_read_b128 lane groups), one wave DMA instruction covers 16 rows.
 // =================================================================================================
-template <int BN, bool FASTK, int EPI = 0>
+template <int BN, bool FASTK, int EPI = 0, int NST = 4>
 __global__ __launch_bounds__(256) void conv_fwd_dma32_kernel(ConvArgs a) {
-    constexpr int BMX = 128, BKS = 32, NST = 4, NWAVES = 4;
+    constexpr int BMX = 128, BKS = 32, NWAVES = 4;
     constexpr int WAVES_N = (BN == 128) ? 2 : 1;
     constexpr int WAVES_M = NWAVES / WAVES_N;
     constexpr int WM = BMX / WAVES_M;
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256) void conv_fwd_dma32_kernel(ConvArgs a) {
     }
 
     auto issue = [&](int kt) {
-        unsigned char* st = smem + (kt & (NST - 1)) * STAGE_BYTES;
+        unsigned char* st = smem + (kt % NST) * STAGE_BYTES;
         if constexpr (FASTK) {
             const unsigned kc0 = (unsigned)(kt * 4);
             const unsigned tap = (kc0 * a.inv_cpt) >> 20;
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(256) void conv_fwd_dma32_kernel(ConvArgs a) {
 
     for (int kt = 0; kt < KT; ++kt) {
         // retire slab kt; up to two younger slabs stay in flight across the barrier
-        if (kt + 2 < KT) {
+        if (NST == 4 && kt + 2 < KT) {
             if constexpr (IPS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else if (kt + 1 < KT) {
@@ -809,7 +809,7 @@ __global__ __launch_bounds__(256) void conv_fwd_dma32_kernel(ConvArgs a) {
         }
         __builtin_amdgcn_s_barrier();                   // slab kt visible to every wave; the stage of slab kt-1 is free
         if (kt + NST - 1 < KT) issue(kt + NST - 1);
-        const uint32_t stage_ = lds0 + (uint32_t)((kt & (NST - 1)) * STAGE_BYTES);
+        const uint32_t stage_ = lds0 + (uint32_t)((kt % NST) * STAGE_BYTES);
         bf16x8_t fa0[MT], fb0[NT], fa1[MT], fb1[NT];
         OESS_FR32(fa0, fb0, sl0)
         OESS_FR32(fa1, fb1, sl1)
@@ -1493,6 +1493,13 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
             constexpr int BNX = BN_ >= 64 ? BN_ : 64;                                        \
             size_t lds = (size_t)4 * (BM + BNX) * 64;                                        \
             if (lds < epi) lds = epi;                                                        \
+            static int nst3 = -1;                                                            \
+            if (nst3 < 0) { const char* e_ = getenv("OESS_CONV_DMA32_NST"); nst3 = (e_ && atoi(e_) == 3) ? 1 : 0; }   \
+            if (nst3 && fastk32) {                                                           \
+                size_t lds3 = (size_t)3 * (BM + BNX) * 64;                                   \
+                if (lds3 < epi) lds3 = epi;                                                  \
+                hipLaunchKernelGGL((conv_fwd_dma32_kernel<BNX, true, 0, 3>), grid, block, lds3, st, a);   \
+            } else                                                                           \
             if (fastk32) hipLaunchKernelGGL((conv_fwd_dma32_kernel<BNX, true, 0>), grid, block, lds, st, a);   \
             else hipLaunchKernelGGL((conv_fwd_dma32_kernel<BNX, false, 0>), grid, block, lds, st, a);          \
         } else OESS_LAUNCH_DMA(BN_, 2)                                                       \
@@ -1546,6 +1553,19 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
         } else
         if (fastk) hipLaunchKernelGGL((conv_fwd_dma_kernel<128, 128, 2, true, 1>), grid, block, lds, st, a);
         else hipLaunchKernelGGL((conv_fwd_dma_kernel<128, 128, 2, false, 1>), grid, block, lds, st, a);
+        OESS_HIP(hipGetLastError());
+        return OESS_OK;
+    }
+    // Short reductions (K <= 256, i.e. the 1x1 bottleneck convs): a workgroup lives ~6 us of which the K loop is a
+    // fraction (launch, first DMA round trip, store acknowledgements), so residency matters more than the main loop:
+    // BK = 32 slabs in a 3-deep ring = 48 KB -> 3 workgroups per CU.  tools/conv_ablate.py: K=64 0.121 -> 0.096 ms,
+    // K=256 (pw) 0.0414 -> 0.0369 ms; from K = 512 up the BK = 64 kernel wins again (half the barriers per FLOP).
+    static int shortk = -1;
+    if (shortk < 0) { const char* e = getenv("OESS_CONV_SHORTK"); shortk = e ? atoi(e) : 1; }
+    if (use == 2 && shortk && bn == 128 && fastk32 && a.Kpad <= 256) {
+        size_t lds3 = (size_t)3 * (BM + 128) * 64;
+        if (lds3 < epi) lds3 = epi;
+        hipLaunchKernelGGL((conv_fwd_dma32_kernel<128, true, 0, 3>), grid, block, lds3, st, a);
         OESS_HIP(hipGetLastError());
         return OESS_OK;
     }

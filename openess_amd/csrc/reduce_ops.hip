@@ -42,16 +42,17 @@ __device__ __forceinline__ void block_atomic_add(double (&v)[NV], double* dst) {
 // ------------------------------------------------------------------------------------------ K2
 // Tensor viewed as `nchunk` contiguous chunks of L floats; chunk j starts at in + in_off + j*in_stride,
 // out is dense.  (Dense tensor: nchunk = 1.)
+// grid = (blocks per chunk, nchunk): no per-element index division (a 64-bit divide per float4 made this ALU-bound).
 __global__ __launch_bounds__(THREADS) void norm_stats_kernel(const float* __restrict__ in, int64_t L, int64_t nchunk,
                                                              int64_t in_stride, int64_t in_off, int vec,
                                                              double* __restrict__ stats) {
     double acc[3] = {0.0, 0.0, 0.0};
+    const float* src = in + in_off + (int64_t)blockIdx.y * in_stride;
     const int64_t tid = (int64_t)blockIdx.x * THREADS + threadIdx.x, nthr = (int64_t)gridDim.x * THREADS;
     if (vec) {
-        const int64_t L4 = L >> 2, total = L4 * nchunk;
-        for (int64_t i = tid; i < total; i += nthr) {
-            const int64_t j = i / L4, r = i - j * L4;
-            const float4 v = *reinterpret_cast<const float4*>(in + in_off + j * in_stride + r * 4);
+        const int64_t L4 = L >> 2;
+        for (int64_t r = tid; r < L4; r += nthr) {
+            const float4 v = *reinterpret_cast<const float4*>(src + r * 4);
             const float a[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -60,10 +61,8 @@ __global__ __launch_bounds__(THREADS) void norm_stats_kernel(const float* __rest
             }
         }
     } else {
-        const int64_t total = L * nchunk;
-        for (int64_t i = tid; i < total; i += nthr) {
-            const int64_t j = i / L, r = i - j * L;
-            const float a = in[in_off + j * in_stride + r];
+        for (int64_t r = tid; r < L; r += nthr) {
+            const float a = src[r];
             const double d = (double)a;
             acc[0] += d; acc[1] += d * d; acc[2] += (a != 0.0f) ? 1.0 : 0.0;
         }
@@ -81,12 +80,13 @@ __global__ __launch_bounds__(THREADS) void norm_apply_kernel(const float* __rest
     const float mean = (float)stats[0] / nf;
     const float var = __fsub_rn((float)stats[1] / nf, __fmul_rn(mean, mean));
     const float stdv = sqrtf(var);
+    const float* src = in + in_off + (int64_t)blockIdx.y * in_stride;
+    float* dst = out + (int64_t)blockIdx.y * L;
     const int64_t tid = (int64_t)blockIdx.x * THREADS + threadIdx.x, nthr = (int64_t)gridDim.x * THREADS;
     if (vec) {
-        const int64_t L4 = L >> 2, total = L4 * nchunk;
-        for (int64_t i = tid; i < total; i += nthr) {
-            const int64_t j = i / L4, r = i - j * L4;
-            float4 v = *reinterpret_cast<const float4*>(in + in_off + j * in_stride + r * 4);
+        const int64_t L4 = L >> 2;
+        for (int64_t r = tid; r < L4; r += nthr) {
+            float4 v = *reinterpret_cast<const float4*>(src + r * 4);
             if (active) {
                 float a[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -94,17 +94,25 @@ __global__ __launch_bounds__(THREADS) void norm_apply_kernel(const float* __rest
                     a[k] = __fmul_rn((a[k] != 0.0f) ? 1.0f : 0.0f, __fsub_rn(a[k], mean)) / stdv;
                 v = make_float4(a[0], a[1], a[2], a[3]);
             }
-            *reinterpret_cast<float4*>(out + j * L + r * 4) = v;
+            *reinterpret_cast<float4*>(dst + r * 4) = v;
         }
     } else {
-        const int64_t total = L * nchunk;
-        for (int64_t i = tid; i < total; i += nthr) {
-            const int64_t j = i / L, r = i - j * L;
-            float a = in[in_off + j * in_stride + r];
+        for (int64_t r = tid; r < L; r += nthr) {
+            float a = src[r];
             if (active) a = __fmul_rn((a != 0.0f) ? 1.0f : 0.0f, __fsub_rn(a, mean)) / stdv;
-            out[j * L + r] = a;
+            dst[r] = a;
         }
     }
+}
+
+// blocks per chunk so that the whole launch is <= 4096 workgroups
+__host__ dim3 norm_grid(int64_t L, int64_t nchunk, int vec) {
+    int64_t gx = (L / (vec ? 4 : 1) + THREADS * 4 - 1) / (THREADS * 4);
+    int64_t cap = 4096 / (nchunk < 1 ? 1 : nchunk);
+    if (cap < 1) cap = 1;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    return dim3((unsigned)gx, (unsigned)nchunk);
 }
 
 int run_normalize(const float* in, float* out, int64_t L, int64_t nchunk, int64_t in_stride, int64_t in_off,
@@ -114,9 +122,10 @@ int run_normalize(const float* in, float* out, int64_t L, int64_t nchunk, int64_
     if (L * nchunk == 0) return OESS_OK;
     const int vec = ((L & 3) == 0) && ((in_stride & 3) == 0) && ((in_off & 3) == 0) &&
                     (((uintptr_t)in & 15) == 0) && (((uintptr_t)out & 15) == 0);
-    const int grid = stream_grid(L * nchunk / (vec ? 4 : 1), THREADS * 4);
-    hipLaunchKernelGGL(norm_stats_kernel, dim3(grid), dim3(THREADS), 0, st, in, L, nchunk, in_stride, in_off, vec, stats);
-    hipLaunchKernelGGL(norm_apply_kernel, dim3(grid), dim3(THREADS), 0, st, in, out, L, nchunk, in_stride, in_off, vec,
+    if (nchunk > 65535) return OESS_EINVAL;
+    const dim3 grid = norm_grid(L, nchunk, vec);
+    hipLaunchKernelGGL(norm_stats_kernel, grid, dim3(THREADS), 0, st, in, L, nchunk, in_stride, in_off, vec, stats);
+    hipLaunchKernelGGL(norm_apply_kernel, grid, dim3(THREADS), 0, st, in, out, L, nchunk, in_stride, in_off, vec,
                        stats);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
@@ -548,8 +557,8 @@ int oess_masked_stats_slice_f32(const float* in, int B, int Ctot, int c0, int Cs
     OESS_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(double), st));
     const int64_t L = (int64_t)Cs * HW, in_stride = (int64_t)Ctot * HW, in_off = (int64_t)c0 * HW;
     const int vec = ((L & 3) == 0) && ((in_stride & 3) == 0) && ((in_off & 3) == 0) && (((uintptr_t)in & 15) == 0);
-    const int grid = stream_grid(L * B / (vec ? 4 : 1), THREADS * 4);
-    hipLaunchKernelGGL(norm_stats_kernel, dim3(grid), dim3(THREADS), 0, st, in, L, (int64_t)B, in_stride, in_off, vec, stats);
+    if (B > 65535) return OESS_EINVAL;
+    hipLaunchKernelGGL(norm_stats_kernel, norm_grid(L, B, vec), dim3(THREADS), 0, st, in, L, (int64_t)B, in_stride, in_off, vec, stats);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }

@@ -25,6 +25,8 @@ CASES = [
     (1, 28, 40, 128, 128, 3, 1, 6, 6),     # ASPP rate 6
     (3, 9, 11, 256, 512, 3, 1, 1, 1),      # ConvLSTM gates class
     (1, 64, 96, 8, 64, 7, 2, 3, 1),        # ResNet conv1 (3->8 padded)
+    (2, 21, 26, 96, 128, 3, 1, 1, 1),      # Cin % 32 == 0 only: half-slab tap decode, slab halves in different taps
+    (1, 19, 23, 32, 72, 5, 1, 2, 2),       # same path, ragged K (25 taps x 32 = 800 -> Kpad 832), dilated
 ]
 
 
