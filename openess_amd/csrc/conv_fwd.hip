@@ -222,7 +222,26 @@ __device__ __forceinline__ void lstm_prefetch(const ConvArgs& a, LstmPrefetch& p
     }
 }
 
-template <int MT = 2, int NT = 2, bool PREF = false>
+// accumulator start values = the gate biases (EPI == 1 kernels that pass ADD_BIAS = false to the epilogue): the 64 bias
+// loads per lane leave the epilogue and hide under the first operand fetch
+template <int MT, int NT>
+__device__ __forceinline__ void lstm_bias_init(const ConvArgs& a, f32x16_t (&acc)[MT][NT], int n0, int wn, int lane) {
+    const int hi = lane >> 5, hc0 = n0 >> 2, C = a.lstm_C;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int hc = hc0 + wn * 8 * NT + j * 8 + 2 * q + hi;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float b = a.bias ? a.bias[g * C + hc] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i][j][q * 4 + g] = b;
+            }
+        }
+}
+
+template <int MT = 2, int NT = 2, bool PREF = false, bool ADD_BIAS = true>
 __device__ __forceinline__ void lstm_epilogue(const ConvArgs& a, f32x16_t (&acc)[MT][NT], unsigned char* smem, int m0, int n0,
                                               int wm, int wn, int lane, int tid, const LstmPrefetch* pref = nullptr) {
     // 2 x 2 waves; workgroup tile = 64*MT rows x 64*NT gate columns = 16*NT hidden channels
@@ -255,7 +274,7 @@ __device__ __forceinline__ void lstm_epilogue(const ConvArgs& a, f32x16_t (&acc)
                 const int hcl = wn * 8 * NT + j * 8 + 2 * q + hi;
                 const int hc = hc0 + hcl;
                 float gi = acc[i][j][q * 4 + 0], gr = acc[i][j][q * 4 + 1], go = acc[i][j][q * 4 + 2], gc = acc[i][j][q * 4 + 3];
-                if (a.bias) { gi += a.bias[hc]; gr += a.bias[C + hc]; go += a.bias[2 * C + hc]; gc += a.bias[3 * C + hc]; }
+                if (ADD_BIAS && a.bias) { gi += a.bias[hc]; gr += a.bias[C + hc]; go += a.bias[2 * C + hc]; gc += a.bias[3 * C + hc]; }
                 float pc;
                 if constexpr (PREF) pc = lc[ml * CP + hcl];              // this lane is the slot's only reader and writer
                 else pc = (a.lstm_prev && valid) ? a.lstm_prev[(long long)m * C + hc] : 0.0f;
@@ -266,6 +285,26 @@ __device__ __forceinline__ void lstm_epilogue(const ConvArgs& a, f32x16_t (&acc)
             }
     }
     __syncthreads();
+    // 16-byte stores when rows are 16-byte aligned (always for the E2VID state buffers); LDS pitches are odd -> dword reads
+    const bool vec_ok = (C & 3) == 0 && (a.lstm_h_stride & 7) == 0 && (((uintptr_t)a.lstm_h | (uintptr_t)a.lstm_cell) & 15) == 0;
+    if (vec_ok) {
+#pragma unroll
+        for (int idx = tid; idx < ROWS * (HC / 4); idx += 256) {       // cell: float4 per lane, HC/4 lanes per row
+            const int row = idx / (HC / 4), c4 = idx - row * (HC / 4);
+            const int m = m0 + row;
+            const float* sp = lc + row * CP + c4 * 4;
+            if (m < a.M) *reinterpret_cast<float4*>(a.lstm_cell + (long long)m * C + hc0 + c4 * 4) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+        }
+        const uint32_t* lhv = reinterpret_cast<const uint32_t*>(lh);
+#pragma unroll
+        for (int idx = tid; idx < ROWS * (HC / 8); idx += 256) {       // hidden: 8 bf16 per lane
+            const int row = idx / (HC / 8), c8 = idx - row * (HC / 8);
+            const int m = m0 + row;
+            const uint32_t* sp = lhv + row * (HP / 2) + c8 * 4;
+            if (m < a.M) *reinterpret_cast<uint4*>(a.lstm_h + (long long)m * a.lstm_h_stride + hc0 + c8 * 8) = make_uint4(sp[0], sp[1], sp[2], sp[3]);
+        }
+        return;
+    }
 #pragma unroll 4
     for (int idx = tid; idx < ROWS * HC; idx += 256) {     // cell: ROWS x HC fp32, whole rows per lane group
         const int row = idx / HC, col = idx - row * HC;
@@ -549,12 +588,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_dma_kernel(ConvArgs a) {
     };
 
     f32x16_t acc[MT][NT];
+    if constexpr (EPI == 1) {
+        lstm_bias_init<MT, NT>(a, acc, n0, wn, lane);
+    } else {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    }
 
     // fragment addresses (bytes from the stage base), fixed over the K loop: row r, chunk slot swz(r, ks*2 + half)
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
@@ -642,8 +685,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_dma_kernel(ConvArgs a) {
 #undef OESS_WAIT_FRAGS
     __syncthreads();
 
-    if constexpr (LSTM_PREF) lstm_epilogue<MT, NT, true>(a, acc, smem, m0, n0, wm, wn, lane, tid, &pref);
-    else if constexpr (EPI == 1) lstm_epilogue<MT, NT>(a, acc, smem, m0, n0, wm, wn, lane, tid);
+    if constexpr (LSTM_PREF) lstm_epilogue<MT, NT, true, false>(a, acc, smem, m0, n0, wm, wn, lane, tid, &pref);
+    else if constexpr (EPI == 1) lstm_epilogue<MT, NT, false, false>(a, acc, smem, m0, n0, wm, wn, lane, tid);
     else conv_epilogue<BMX, BN, BN + 8, NTHREADS, WAVES_N>(a, acc, smem, m0, n0, wm, wn, lane, tid);
 }
 
