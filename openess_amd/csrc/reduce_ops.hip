@@ -50,8 +50,25 @@ __global__ __launch_bounds__(THREADS) void norm_stats_kernel(const float* __rest
     const float* src = in + in_off + (int64_t)blockIdx.y * in_stride;
     const int64_t tid = (int64_t)blockIdx.x * THREADS + threadIdx.x, nthr = (int64_t)gridDim.x * THREADS;
     if (vec) {
+        // four 16-byte loads in flight per lane; accumulation stays in double (the reference sums in float64-exact order
+        // only up to its final float32 rounding, tests pin 2e-5 / 2e-6)
         const int64_t L4 = L >> 2;
-        for (int64_t r = tid; r < L4; r += nthr) {
+        int64_t r = tid;
+        for (; r + 3 * nthr < L4; r += 4 * nthr) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(src + (r + u * nthr) * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float a[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double d = (double)a[k];
+                    acc[0] += d; acc[1] += d * d; acc[2] += (a[k] != 0.0f) ? 1.0 : 0.0;
+                }
+            }
+        }
+        for (; r < L4; r += nthr) {
             const float4 v = *reinterpret_cast<const float4*>(src + r * 4);
             const float a[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -105,10 +122,10 @@ __global__ __launch_bounds__(THREADS) void norm_apply_kernel(const float* __rest
     }
 }
 
-// blocks per chunk so that the whole launch is <= 4096 workgroups
+// blocks per chunk: >= 8 items per thread, the whole launch <= 256 workgroups (one block reduction + 3 same-address atomics each)
 __host__ dim3 norm_grid(int64_t L, int64_t nchunk, int vec) {
-    int64_t gx = (L / (vec ? 4 : 1) + THREADS * 4 - 1) / (THREADS * 4);
-    int64_t cap = 4096 / (nchunk < 1 ? 1 : nchunk);
+    int64_t gx = (L / (vec ? 4 : 1) + THREADS * 8 - 1) / (THREADS * 8);
+    int64_t cap = 256 / (nchunk < 1 ? 1 : nchunk);      // measured: 2048 workgroups 23.9 us, 256 14.5 us (same-address atomics serialise in L2)
     if (cap < 1) cap = 1;
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
