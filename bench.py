@@ -190,7 +190,7 @@ def main():
         roof = None
         if conv_stats and conv_stats["ms"] > 0:
             ach = conv_stats["flops"] / (conv_stats["ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "conv_fwd_dma_kernel<{128|64},128,2> (implicit-GEMM bf16 MFMA, LDS-DMA; all fwd + dgrad launches with Cout > 64, incl. the fused ConvLSTM-epilogue variant: conv FLOPs only)",
+            roof = {"bound": "mfma", "kernel": "conv_fwd_dma_kernel<{128|64},128,2> + short-K conv_fwd_dma32_kernel<128,..,3> (implicit-GEMM bf16 MFMA, LDS-DMA; all fwd + dgrad launches with Cout > 64, incl. the fused ConvLSTM-epilogue variant: conv FLOPs only)",
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": _pmc_traffic(a.workload),
                     "launches_per_step": conv_stats["launches"] // a.steps,
