@@ -194,7 +194,8 @@ def test_convlstm_fused_rejects_aliasing_and_bad_shapes():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,H,W,Cout,relu", [(2, 70, 130, 32, True), (1, 9, 65, 12, False), (3, 8, 64, 32, True)])
+@pytest.mark.parametrize("B,H,W,Cout,relu", [(2, 70, 130, 32, True), (1, 9, 65, 12, False), (3, 8, 64, 32, True),
+                                               (4, 130, 650, 32, True)])     # 748 tiles > 512 persistent workgroups: 1 or 2 tiles each
 def test_conv_small_cin_halo_kernel(B, H, W, Cout, relu):
     """Cin = 8, 5x5, stride 1 (E2VID head): the LDS halo-tile kernel (conv_smallcin_kernel), several tiles with ragged
     edges, bias + ReLU in bf16, output written into a channel slice of a wider buffer."""
