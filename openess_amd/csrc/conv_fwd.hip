@@ -1532,6 +1532,7 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
     }
     const long long in_extent = (((long long)B * H * W - 1) * in_pix_stride + Cin) * 2;
     int use = (in_extent >= 0x7ffffff0ll) ? 0 : impl;              // 32-bit buffer offsets in the DMA kernels
+    bool dma_ok = in_extent < 0x7ffffff0ll;
     {   // exact reciprocals for the in-kernel tap arithmetic (checked over the whole range; else fall back)
         const unsigned cpt = (unsigned)(Cin >> 3), nkc = (unsigned)(a.Kpad / 8);
         a.inv_cpt = ((1u << 20) + cpt - 1) / cpt;
@@ -1540,7 +1541,7 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
         for (unsigned kc = 0; exact && kc < nkc; ++kc) exact = ((kc * a.inv_cpt) >> 20) == kc / cpt;
         const unsigned maxtap = nkc / cpt + 1;
         for (unsigned t = 0; exact && t <= maxtap; ++t) exact = ((t * a.inv_s) >> 16) == t / (unsigned)S;
-        if (!exact) use = 0;
+        if (!exact) { use = 0; dma_ok = false; }
         a.rcp_hw = 1.0f / (float)(a.Ho * a.Wo);
         a.rcp_wo = 1.0f / (float)a.Wo;
         if (use == 4 && M >= (1ll << 22)) use = 2;     // float-reciprocal row decode is exact below 2^22 rows
@@ -1634,7 +1635,10 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
         }
     }
     if (lstm) {     // fused ConvLSTM cell update: transposed MFMA + lane-local gate algebra (needs the LDS-DMA kernel)
-        if (use < 2) return OESS_EINVAL;
+        if (use < 2) {      // the fused epilogue exists only in the LDS-DMA kernels (32-bit offsets, exact tap reciprocals)
+            if (!dma_ok) return OESS_EINVAL;
+            use = 2;        // OESS_CONV_IMPL=v1 (debug knob) does not apply to this entry point
+        }
         const size_t lds = (size_t)2 * (BM + 128) * 8 * 16;
         if (use == 5) {
             if (fastk32) hipLaunchKernelGGL((conv_fwd_dma32_kernel<128, true, 1>), grid, block, lds, st, a);
