@@ -7,7 +7,8 @@ SHAPES = {"gates": (8, 110, 160, 256, 512, 3, 1, 1, 1), "l3": (8, 55, 80, 256, 2
           "head": (8, 440, 640, 8, 32, 5, 1, 2, 1), "enc3": (8, 110, 160, 128, 256, 5, 2, 2, 1), "enc2": (8, 220, 320, 64, 128, 5, 2, 2, 1),
           "res": (8, 55, 80, 256, 256, 3, 1, 1, 1), "aspp": (8, 28, 40, 2048, 256, 3, 1, 6, 6), "dl4": (8, 28, 40, 512, 512, 3, 1, 2, 2), "gk4": (8, 110, 160, 1024, 512, 3, 1, 1, 1), "gk1": (8, 110, 160, 64, 512, 3, 1, 1, 1),
           "g1": (8, 220, 320, 128, 256, 3, 1, 1, 1), "g3": (8, 55, 80, 512, 1024, 3, 1, 1, 1),
-          "enc1": (8, 440, 640, 32, 64, 5, 2, 2, 1), "k64": (8, 220, 320, 64, 256, 1, 1, 0, 1), "k64c128": (8, 220, 320, 64, 128, 1, 1, 0, 1), "k64c64": (8, 220, 320, 64, 64, 1, 1, 0, 1), "k64c512": (8, 220, 320, 64, 512, 1, 1, 0, 1), "k128": (8, 220, 320, 128, 256, 1, 1, 0, 1), "k256": (8, 220, 320, 256, 256, 1, 1, 0, 1), "k512": (8, 220, 320, 512, 256, 1, 1, 0, 1)}
+          "enc1": (8, 440, 640, 32, 64, 5, 2, 2, 1),
+          "t1": (8, 110, 160, 512, 2048, 1, 1, 0, 1), "t2": (8, 110, 160, 256, 1024, 1, 1, 0, 1), "t3": (8, 110, 160, 1024, 256, 1, 1, 0, 1), "t4": (8, 110, 160, 128, 512, 1, 1, 0, 1), "t5": (8, 110, 160, 2048, 512, 1, 1, 0, 1), "t6": (8, 110, 160, 1024, 2048, 1, 1, 0, 1), "k64": (8, 220, 320, 64, 256, 1, 1, 0, 1), "k64c128": (8, 220, 320, 64, 128, 1, 1, 0, 1), "k64c64": (8, 220, 320, 64, 64, 1, 1, 0, 1), "k64c512": (8, 220, 320, 64, 512, 1, 1, 0, 1), "k128": (8, 220, 320, 128, 256, 1, 1, 0, 1), "k256": (8, 220, 320, 256, 256, 1, 1, 0, 1), "k512": (8, 220, 320, 512, 256, 1, 1, 0, 1)}
 for name in sys.argv[1:]:
     B, H, W, Cin, Cout, R, st, pad, dil = SHAPES[name]
     mode = os.environ.get("ABL_DATA", "randn")
