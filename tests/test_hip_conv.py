@@ -27,6 +27,9 @@ CASES = [
     (1, 64, 96, 8, 64, 7, 2, 3, 1),        # ResNet conv1 (3->8 padded)
     (2, 21, 26, 96, 128, 3, 1, 1, 1),      # Cin % 32 == 0 only: half-slab tap decode, slab halves in different taps
     (1, 19, 23, 32, 72, 5, 1, 2, 2),       # same path, ragged K (25 taps x 32 = 800 -> Kpad 832), dilated
+    (1, 110, 160, 256, 512, 3, 1, 1, 1),   # full-width gate-conv class: 138 x 4 = 552 tiles, more than one round of workgroups
+    (2, 220, 320, 64, 256, 1, 1, 0, 1),    # short-K 1x1 at scale: BK = 32 x 3 ring kernel, 1100 x 2 tiles
+    (1, 55, 80, 512, 1024, 3, 1, 1, 1),    # 35 m-tiles (ragged) x 8 n-tiles through the 64 x 128 tile heuristic
 ]
 
 
@@ -127,7 +130,8 @@ def test_conv_wgrad_matches_autograd(case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,H,W,Cx,C", [(2, 9, 11, 32, 32), (1, 13, 10, 64, 64), (3, 8, 8, 96, 32)])
+@pytest.mark.parametrize("B,H,W,Cx,C", [(2, 9, 11, 32, 32), (1, 13, 10, 64, 64), (3, 8, 8, 96, 32),
+                                          (1, 110, 160, 128, 128)])     # one DSEC level at full width: 552 tiles > 512 slots (second round, ragged last m-tile)
 def test_convlstm_fused_step_matches_torch(B, H, W, Cx, C):
     """oess_convlstm_fused_bf16 (Gates conv + cell update in one kernel, gate-interleaved weights, transposed MFMA)
     against a plain fp32 restatement of ConvLSTM.forward (e2vid/model/submodules.py:199-214), three recurrent steps
@@ -195,7 +199,8 @@ def test_convlstm_fused_rejects_aliasing_and_bad_shapes():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W,Cout,relu", [(2, 70, 130, 32, True), (1, 9, 65, 12, False), (3, 8, 64, 32, True),
-                                               (4, 130, 650, 32, True)])     # 748 tiles > 512 persistent workgroups: 1 or 2 tiles each
+                                               (4, 130, 650, 32, True),      # 748 tiles > 512 persistent workgroups: 1 or 2 tiles each
+                                               (3, 440, 640, 32, True)])     # the E2VID head at full DSEC size: 1650 tiles, 3 or 4 each
 def test_conv_small_cin_halo_kernel(B, H, W, Cout, relu):
     """Cin = 8, 5x5, stride 1 (E2VID head): the LDS halo-tile kernel (conv_smallcin_kernel), several tiles with ragged
     edges, bias + ReLU in bf16, output written into a channel slice of a wider buffer."""
