@@ -108,6 +108,8 @@ def test_conv_dgrad_operator():
     (2, 16, 24, 64, 64, 3, 2, 1, 1),       # stride 2
     (1, 14, 18, 48, 136, 3, 1, 2, 2),      # dilation, ragged tiles
     (2, 8, 130, 8, 16, 5, 1, 2, 1),
+    (1, 220, 320, 64, 32, 3, 1, 1, 1),     # decoder layer at scale: 70 400 pixels reduced by the full split-K fan-out
+    (1, 110, 160, 128, 256, 3, 1, 1, 1),   # several (Cout, taps*Cin) tiles x split-K
 ])
 def test_conv_wgrad_matches_autograd(case):
     from openess_amd import hip
