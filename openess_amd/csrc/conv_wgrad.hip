@@ -47,26 +47,33 @@ __device__ __forceinline__ bf16x4_t tr_read(uint32_t lds_addr) {
     return v;
 }
 
+// TMV = output channels per tile: 128 (2 x 2 waves of 64 x 64), 64 (2 x 2 waves of 32 x 64) or 32 (1 x 4 waves of
+// 32 x 32).  The narrow tiles are for the decoder's 32 / 64-channel layers at 440 x 640 and 220 x 320, where a 128-row
+// tile spends 75 % / 50 % of its MFMAs on zero rows and the kernel was MFMA bound on padding (370 us for 41 GFLOP).
+template <int TMV>
 __global__ __launch_bounds__(WG) void conv_wgrad_kernel(WgradArgs a) {
+    constexpr int WAVES_M = (TMV == 32) ? 1 : 2, WAVES_N = 4 / WAVES_M;
+    constexpr int WMV = TMV / WAVES_M, WNV = TN / WAVES_N;       // wave tile
+    constexpr int MT = WMV / 32, NT = WNV / 32;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KP * PITCH];
-    unsigned char* lA = smem;                      // dY tile  [KP pixels][128 co]
+    unsigned char* lA = smem;                      // dY tile  [KP pixels][TMV co]
     unsigned char* lB = smem + KP * PITCH;         // X  tile  [KP pixels][128 kk]
     const int tile = blockIdx.x;
     const int tile_n = tile % a.tiles_n, tile_m = tile / a.tiles_n;
-    const int co0 = tile_m * TM, kk0 = tile_n * TN;
+    const int co0 = tile_m * TMV, kk0 = tile_n * TN;
     const int split = blockIdx.y;
     const int row_beg = split * a.rows_per_split;
     int row_end = row_beg + a.rows_per_split;
     if (row_end > a.rows_total) row_end = a.rows_total;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
     // ---- global->LDS staging roles: 16 chunk columns x 16 pixel rows per pass, 4 passes
     const int ccol = tid & 15, prow = tid >> 4;
     // A (dY): channel chunk
     const int a_co = co0 + ccol * 8;
-    const bool a_ok = a_co < a.Cout;               // Cout % 8 == 0 is required by the host wrapper
+    const bool a_ok = a_co < a.Cout && ccol * 8 < TMV;            // Cout % 8 == 0 is required by the host wrapper
     // B (X): fixed (tap, channel chunk) of this thread
     const int kk = kk0 + ccol * 8;
     const int cpt = a.Cin_x;                        // kk = tap * Cin_x + ci
@@ -75,11 +82,11 @@ __global__ __launch_bounds__(WG) void conv_wgrad_kernel(WgradArgs a) {
     const int r = tap / a.S, s = tap - r * a.S;
     const int dyo = r * a.dil - a.pad, dxo = s * a.dil - a.pad;
 
-    f32x16_t acc[2][2];
+    f32x16_t acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(WG) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int pr = prow + 16 * i;
-            *reinterpret_cast<u32x4_t*>(lA + pr * PITCH + ccol * 16) = ra[i];
+            if (ccol * 8 < TMV) *reinterpret_cast<u32x4_t*>(lA + pr * PITCH + ccol * 16) = ra[i];
             *reinterpret_cast<u32x4_t*>(lB + pr * PITCH + ccol * 16) = rb[i];
         }
         __syncthreads();
@@ -126,33 +133,38 @@ __global__ __launch_bounds__(WG) void conv_wgrad_kernel(WgradArgs a) {
         {
 #pragma unroll
             for (int ks = 0; ks < KP / 16; ++ks) {
-                bf16x4_t al[2], ah[2], bl[2], bh[2];
+                bf16x4_t al[MT], ah[MT], bl[NT], bh[NT];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const uint32_t base = ldsA + (uint32_t)(ks * 16 + tr_row) * PITCH + (uint32_t)(wm * 64 + i * 32 + tr_col) * 2;
+                for (int i = 0; i < MT; ++i) {
+                    const uint32_t base = ldsA + (uint32_t)(ks * 16 + tr_row) * PITCH + (uint32_t)(wm * WMV + i * 32 + tr_col) * 2;
                     al[i] = tr_read(base);
                     ah[i] = tr_read(base + 4 * PITCH);
                 }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const uint32_t base = ldsB + (uint32_t)(ks * 16 + tr_row) * PITCH + (uint32_t)(wn * 64 + j * 32 + tr_col) * 2;
+                for (int j = 0; j < NT; ++j) {
+                    const uint32_t base = ldsB + (uint32_t)(ks * 16 + tr_row) * PITCH + (uint32_t)(wn * WNV + j * 32 + tr_col) * 2;
                     bl[j] = tr_read(base);
                     bh[j] = tr_read(base + 4 * PITCH);
                 }
-                // the "+v" operands tie every later use of the eight results to this wait (hipcc does not track
+                // the "+v" operands tie every later use of the results to this wait (hipcc does not track
                 // inline-asm LDS reads: cdna_hip_programming.md 5.4 rule 18)
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1])
-                             :: "memory");
-                bf16x8_t fa[2], fb[2];
+                if constexpr (MT == 2 && NT == 2)
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1])
+                                 :: "memory");
+                else if constexpr (MT == 1 && NT == 2)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(al[0]), "+v"(ah[0]), "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1]) :: "memory");
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(al[0]), "+v"(ah[0]), "+v"(bl[0]), "+v"(bh[0]) :: "memory");
+                bf16x8_t fa[MT], fb[NT];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[i] = __builtin_shufflevector(al[i], ah[i], 0, 1, 2, 3, 4, 5, 6, 7);
+                for (int i = 0; i < MT; ++i) fa[i] = __builtin_shufflevector(al[i], ah[i], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) fb[j] = __builtin_shufflevector(bl[j], bh[j], 0, 1, 2, 3, 4, 5, 6, 7);
+                for (int j = 0; j < NT; ++j) fb[j] = __builtin_shufflevector(bl[j], bh[j], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
         }
@@ -160,15 +172,15 @@ __global__ __launch_bounds__(WG) void conv_wgrad_kernel(WgradArgs a) {
 #undef OESS_WG_LOAD
     // ---- epilogue: plain coalesced stores of the partial tile (no atomics); reduced by wgrad_reduce_kernel
     const int ldn = a.tiles_n * TN;
-    float* P = a.part + (size_t)split * a.tiles_m * TM * ldn;
+    float* P = a.part + (size_t)split * a.tiles_m * TMV * ldn;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int kq = kk0 + wn * 64 + j * 32 + (lane & 31);
+        for (int j = 0; j < NT; ++j) {
+            const int kq = kk0 + wn * WNV + j * 32 + (lane & 31);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int co = co0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int co = co0 + wm * WMV + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 P[(size_t)co * ldn + kq] = acc[i][j][e];
             }
         }
@@ -206,26 +218,31 @@ int oess_conv2d_wgrad_bf16(const void* x, long long x_pix_stride, int B, int H, 
     a.Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
     if (a.Ho <= 0 || a.Wo <= 0) return OESS_EINVAL;
     a.Kdim = R * S * Cin_x;
-    a.tiles_m = (Cout + TM - 1) / TM;
+    static int narrow = -1;
+    if (narrow < 0) { const char* e = getenv("OESS_WGRAD_NARROW"); narrow = e ? atoi(e) : 1; }
+    const int tmv = (narrow && Cout <= 32) ? 32 : ((narrow && Cout <= 64) ? 64 : TM);
+    a.tiles_m = (Cout + tmv - 1) / tmv;
     a.tiles_n = (a.Kdim + TN - 1) / TN;
     a.rows_total = B * a.Ho;
     const int tiles = a.tiles_m * a.tiles_n;
     static int target = -1;
     if (target < 0) { const char* e = getenv("OESS_WGRAD_TARGET"); target = e ? atoi(e) : 512; if (target < 1) target = 512; }
     int splits = (target + tiles - 1) / tiles;               // ~2 workgroups per CU: measured best (1024: +3 % step time on frame2recon from the larger partial-sum traffic)
-    const size_t per_split = (size_t)a.tiles_m * TM * a.tiles_n * TN * sizeof(float);
+    const size_t per_split = (size_t)a.tiles_m * tmv * a.tiles_n * TN * sizeof(float);
     if (per_split > workspace_bytes) return OESS_ENOMEM;
     if ((size_t)splits * per_split > workspace_bytes) splits = (int)(workspace_bytes / per_split);
     if (splits > a.rows_total) splits = a.rows_total;
     if (splits < 1) splits = 1;
     a.rows_per_split = (a.rows_total + splits - 1) / splits;
     splits = (a.rows_total + a.rows_per_split - 1) / a.rows_per_split;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, splits), dim3(WG), 0, (hipStream_t)stream, a);
+    if (tmv == 32) hipLaunchKernelGGL(conv_wgrad_kernel<32>, dim3(tiles, splits), dim3(WG), 0, (hipStream_t)stream, a);
+    else if (tmv == 64) hipLaunchKernelGGL(conv_wgrad_kernel<64>, dim3(tiles, splits), dim3(WG), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<128>, dim3(tiles, splits), dim3(WG), 0, (hipStream_t)stream, a);
     const int total = Cout * Cin * R * S;
     int rg = (total + 255) / 256;
     if (rg > 4096) rg = 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, splits,
-                       a.tiles_m * TM, a.tiles_n * TN, Cout, Cin, Cin_x, R * S, dw_oihw);
+                       a.tiles_m * tmv, a.tiles_n * TN, Cout, Cin, Cin_x, R * S, dw_oihw);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }
