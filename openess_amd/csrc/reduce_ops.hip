@@ -673,7 +673,10 @@ int oess_task_loss_fwd(const void* logits, int is_bf16, const int64_t* target, i
     hipStream_t st = (hipStream_t)stream;
     OESS_HIP(hipMemsetAsync(sums, 0, (size_t)(3 * K + 2) * sizeof(double), st));
     LossGeom g{P, pixels_per_sample, stride_b, stride_p, stride_c, K, ignore_index};
-    const int grid = stream_grid(P, THREADS * 4);
+    // every workgroup ends in 3K+2 double atomics on the same few cache lines (serialised in L2: 2048 workgroups spent
+    // ~100 us there): at most 512 workgroups, the per-thread fp32 partials then cover <= ~20 pixels before the promotion
+    int grid = stream_grid(P, THREADS * 4);
+    if (grid > 512) grid = 512;
 #define LAUNCH_FWD(KM)                                                                                              \
     do {                                                                                                            \
         if (is_bf16)                                                                                                \
