@@ -13,12 +13,12 @@ E2VID_LIGHTWEIGHT_CONFIG = {'num_bins': 5, 'skip_type': 'sum', 'recurrent_block_
 
 class OracleStep:
     def __init__(self, config_option='frame2voxel', num_classes=11, nr_events_data=20, bins=5,
-                 if_spatial_contrastive=False, superpixel_size=100, lr=5e-4, output_stride=32):
+                 if_spatial_contrastive=False, superpixel_size=100, lr=5e-4, output_stride=32, e2vid_config=None):
         self.opt, self.K, self.nwin, self.bins = config_option, num_classes, nr_events_data, bins
         self.contr, self.sps = if_spatial_contrastive, superpixel_size
         self.model_frame = on.DilationFeatureExtractor()
         if config_option == 'frame2voxel':
-            self.front = on.E2VIDRecurrent(E2VID_LIGHTWEIGHT_CONFIG).eval()
+            self.front = on.E2VIDRecurrent(e2vid_config or E2VID_LIGHTWEIGHT_CONFIG).eval()
             for p in self.front.parameters():
                 p.requires_grad = False
             self.back_end = on.SemSegE2VID(256, num_classes)
@@ -79,6 +79,56 @@ class OracleStep:
         self.opt_a.step()
         self.opt_b.step()
         return losses, t_loss.detach()
+
+
+class OracleSupervisedStep:
+    """Stage 2/3 step: OpenESSFineTuneModel (training/finetune_trainer.py:285-386) and OpenESSLinearProbeModel
+    (training/linear_probe_trainer.py:276-371) -- supervised Dice + CE on ground truth, ONE AdamW.  Linear probing
+    freezes everything but a K->K 1x1 conv on the logits (style_networks.py:113-133,169-170; deeplabv3.py:162-170,
+    186-187); modules stay in .train() (BatchNorm keeps using batch statistics), E2VID in .eval()."""
+
+    def __init__(self, config_option='frame2voxel', num_classes=11, nr_events_data=20, bins=5, linear_probing=False,
+                 lr=5e-4, output_stride=32, weight_task_loss=1.0):
+        self.opt, self.K, self.nwin, self.bins, self.w = config_option, num_classes, nr_events_data, bins, weight_task_loss
+        self.linear_probing = linear_probing
+        if config_option in ('frame2voxel', 'recon2voxel'):
+            self.front = on.E2VIDRecurrent(E2VID_LIGHTWEIGHT_CONFIG).eval()
+            for p in self.front.parameters():
+                p.requires_grad = False
+            self.net = on.SemSegE2VID(256, num_classes)
+        else:
+            self.net = on.DeepLabV3(num_classes, output_stride)
+        if linear_probing:
+            for p in self.net.parameters():
+                p.requires_grad = False
+            self.net.linear_probe = torch.nn.Conv2d(num_classes, num_classes, 1)
+        self.optim = torch.optim.AdamW([p for p in self.net.parameters() if p.requires_grad], lr=lr)
+
+    def modules(self):
+        if self.opt in ('frame2voxel', 'recon2voxel'):
+            return {'front_sensor_b': self.front, 'back_end': self.net}
+        return {'model_recon': self.net}
+
+    def logits(self, batch):
+        if self.opt in ('frame2voxel', 'recon2voxel'):
+            states = None
+            with torch.no_grad():
+                for i in range(self.nwin):
+                    _, states, latent = self.front(on.event_preprocess(batch[0][:, i * self.bins:(i + 1) * self.bins]), states)
+            pred, _ = self.net({k: v.detach() for k, v in latent.items()})
+            lg = pred[1]
+        else:
+            lg, _ = self.net(batch[2])
+        return self.net.linear_probe(lg) if self.linear_probing else lg
+
+    def train_step(self, batch):
+        self.net.train()
+        self.optim.zero_grad()
+        loss = ol.task_loss(self.logits(batch), batch[1], self.K) * self.w
+        loss.backward()
+        self.optim.step()
+        key = 'semseg_sensor_b_loss' if self.opt in ('frame2voxel', 'recon2voxel') else 'semseg_recon_loss'
+        return {key: loss.detach()}, loss.detach()
 
 
 def voxelize_sample(x, y, t, p, rectify_map, nwin, C, H, W, crop):

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 sys.path.insert(0, ROOT)
-from tests.synth import fill_by_name  # noqa: E402
+from tests.synth import damp_residual, fill_by_name, wc_image  # noqa: E402
 
 
 def _ref_models():
@@ -37,6 +37,7 @@ def _ref_models():
 def gen_nets():
     import importlib.util
     torch.set_num_threads(4)
+    torch.manual_seed(1205)          # every torch.randn / torch.rand input below is reproducible from this recipe
     out, keys = {}, {}
     sn, dl, rn = _ref_models()
     rng = np.random.default_rng(77)
@@ -119,11 +120,50 @@ def gen_nets():
     out["deeplab_target"], out["deeplab_train_logits"], out["deeplab_train_loss"] = tgt.numpy(), lg.detach().numpy(), loss.detach().numpy()
     out["deeplab_grad_classifier.classifier.0.weight"] = net.classifier.classifier[0].weight.grad.numpy()
     out["deeplab_grad_backbone.layer4.2.conv3.weight"] = dict(net.named_parameters())["backbone.layer4.2.conv3.weight"].grad.numpy()
+
+    # ---- G10b: the same teacher on WELL-CONDITIONED weights (residual branches damped, tests/synth.py:damp_residual)
+    enc = rn.ResNet(rn.Bottleneck, [3, 4, 6, 3], replace_stride_with_dilation=[True, True, True])
+    del enc.fc
+    fill_by_name(enc, 13)
+    damp_residual(enc)
+    enc.train()
+    img = torch.rand(2, 3, 96, 128)
+    with torch.no_grad():
+        x = enc.maxpool(enc.relu(enc.bn1(enc.conv1(img))))
+        x = enc.layer4(enc.layer3(enc.layer2(enc.layer1(x))))
+        feat = torch.nn.functional.normalize(
+            torch.nn.Upsample(scale_factor=4, mode="bilinear", align_corners=True)(dec(x)), p=2, dim=1)
+    out["teacherwc_img"], out["teacherwc_feat"], out["teacherwc_enc_out"] = img.numpy(), feat.numpy(), x.numpy()
+
+    # ---- G9b: deeplabv3_resnet50 at 4x3x224x320 (OS16 map 14x20: 1120 samples per BatchNorm channel, ASPP rates
+    #      6/12/18 all reach in-range off-centre taps), well-conditioned weights, train forward + backward
+    net = dl.deeplabv3_resnet50(num_classes=K, text_embeddings_path=None, output_stride=32, pretrained_backbone='')
+    fill_by_name(net, 15)
+    damp_residual(net)
+    net.train()
+    net.classifier.ASPP.project[3].p = 0.0
+    img = torch.from_numpy(wc_image())                 # tests/synth.py: regenerated by the consumers, not stored
+    tgt = torch.from_numpy(rng.integers(0, K, (4, 28, 40))).long().repeat_interleave(8, 1).repeat_interleave(8, 2)
+    tgt[1, :9] = 255
+    out["deeplabwc_target"] = tgt.numpy().astype(np.uint8)
+    lg, ft = net(img)
+    loss = TaskLoss(losses=['dice', 'cross_entropy'], num_classes=K, ignore_index=255)(lg, tgt)
+    loss.backward()
+    out["deeplabwc_logits"], out["deeplabwc_feats"], out["deeplabwc_loss"] = lg.detach().numpy(), ft.detach().numpy(), loss.detach().numpy()
+    out["deeplabwc_argmax"] = lg.argmax(1).numpy().astype(np.uint8)
+    named = dict(net.named_parameters())
+    for name in ("backbone.conv1.weight", "backbone.layer1.0.conv1.weight", "backbone.layer2.3.conv2.weight",
+                 "backbone.layer3.5.conv3.weight", "backbone.layer4.0.downsample.0.weight", "backbone.layer4.2.conv2.weight",
+                 "backbone.layer4.2.bn3.weight", "classifier.ASPP.convs.0.0.weight", "classifier.ASPP.convs.1.0.weight",
+                 "classifier.ASPP.convs.2.0.weight", "classifier.ASPP.convs.3.0.weight", "classifier.ASPP.convs.4.1.weight",
+                 "classifier.ASPP.project.0.weight", "classifier.ASPP.project.1.bias", "classifier.classifier.0.weight",
+                 "classifier.classifier.1.weight"):
+        out["deeplabwc_grad_" + name] = named[name].grad.numpy()
     from tests.synth import compact
     small = {}
     for k, v in out.items():
         v = np.asarray(v)
-        if v.size > 20000 and not k.endswith(("_events", "_img", "_target")) and not k.startswith("semseg_lat"):
+        if v.size > 20000 and not k.endswith(("_events", "_img", "_target", "_argmax")) and not k.startswith("semseg_lat"):
             sub, ssum, sabs = compact(v)
             small[k + "__sub"], small[k + "__sum"], small[k + "__abs"] = sub, ssum, sabs
             small[k + "__shape"] = np.array(v.shape)

@@ -30,6 +30,10 @@ CASES = [
     (1, 110, 160, 256, 512, 3, 1, 1, 1),   # full-width gate-conv class: 138 x 4 = 552 tiles, more than one round of workgroups
     (2, 220, 320, 64, 256, 1, 1, 0, 1),    # short-K 1x1 at scale: BK = 32 x 3 ring kernel, 1100 x 2 tiles
     (1, 55, 80, 512, 1024, 3, 1, 1, 1),    # 35 m-tiles (ragged) x 8 n-tiles through the 64 x 128 tile heuristic
+    (2, 28, 40, 2048, 256, 3, 1, 6, 6),    # ASPP branch, rate 6, at the frame2recon_full geometry (440x640 / 16)
+    (2, 28, 40, 2048, 256, 3, 1, 12, 12),  # ASPP rate 12: every tap lands inside the 28x40 map for interior pixels
+    (2, 28, 40, 2048, 256, 3, 1, 18, 18),  # ASPP rate 18 (models/deeplabv3.py:137-142, else-branch rates 6/12/18)
+    (1, 14, 20, 2048, 256, 3, 1, 12, 12),  # 224x320 input: rate 12 still has in-range off-centre taps
 ]
 
 
@@ -110,6 +114,8 @@ def test_conv_dgrad_operator():
     (2, 8, 130, 8, 16, 5, 1, 2, 1),
     (1, 220, 320, 64, 32, 3, 1, 1, 1),     # decoder layer at scale: 70 400 pixels reduced by the full split-K fan-out
     (1, 110, 160, 128, 256, 3, 1, 1, 1),   # several (Cout, taps*Cin) tiles x split-K
+    (2, 28, 40, 2048, 256, 3, 1, 12, 12),  # ASPP rate 12 weight gradient at the full-size 28x40 map
+    (2, 28, 40, 2048, 256, 3, 1, 18, 18),  # ASPP rate 18
 ])
 def test_conv_wgrad_matches_autograd(case):
     from openess_amd import hip

@@ -11,7 +11,7 @@ import torch
 
 from oracle import nets as on
 from oracle.step import E2VID_LIGHTWEIGHT_CONFIG, OracleStep
-from tests.synth import compact, fill_by_name
+from tests.synth import compact, damp_residual, fill_by_name
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -94,6 +94,12 @@ def test_semseg_e2vid_forward_backward(g, keys):
     assert relerr(pred[1].float().cpu().detach().numpy(), pred_ref[1].detach().numpy()) < 4e-2
     assert relerr(x256.float().cpu().detach().numpy(), x256_ref.detach().numpy()) < 4e-2
     assert loss.item() == pytest.approx(loss_ref.item(), rel=2e-2)
+    # SURVEY 8d argmax agreement: >= 99.9 % wherever the oracle's top-2 margin exceeds the measured logit error bound
+    lg, lr = pred[1].float().cpu().detach().numpy(), pred_ref[1].detach().numpy()
+    srt = np.sort(lr, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 2 * np.abs(lg - lr).max()
+    assert clear.mean() > 0.5 and (lg.argmax(1) == lr.argmax(1))[clear].mean() >= 0.999
+    assert (lg.argmax(1) == lr.argmax(1)).mean() >= 0.97
     pr = dict(ref.named_parameters())
     for name, p in net.named_parameters():
         if name.startswith("decoder_scale_5") or name == "text_embeddings":
@@ -191,6 +197,107 @@ def test_deeplab_eval_and_train(g, keys):
     assert cos(net.classifier.classifier[1].weight.grad.cpu().numpy(), pr["classifier.classifier.1.weight"].grad.numpy()) > 0.9
 
 
+def test_teacher_well_conditioned_end_to_end(g, keys):
+    """The teacher on well-conditioned weights (residual branches damped x0.25, tests/synth.py:damp_residual): here bf16
+    storage does not get amplified (the fp32 oracle with bf16 rounding points keeps cosine > 0.999 against itself,
+    tests/test_oracle_nets_golden.py), so END-TO-END parity is held tight -- a kernel bug cannot hide behind "chaos"."""
+    from openess_amd.models.image_model import DilationFeatureExtractor
+    from tests.synth import damp_residual
+    t = DilationFeatureExtractor(None)
+    fill_by_name(t.encoder, 13)
+    fill_by_name(t.decoder[0], 14)
+    damp_residual(t.encoder)
+    t.cuda().train()
+    ref = on.DilationFeatureExtractor()
+    fill_by_name(ref.encoder, 13, keys["teacher_encoder"])
+    fill_by_name(ref.decoder[0], 14)
+    damp_residual(ref.encoder)
+    ref.train()
+    img = torch.from_numpy(g["teacherwc_img"])
+    with torch.no_grad():
+        feat = t(img.cuda()).float().cpu().numpy()
+        fr = ref(img).numpy()
+    c = (feat * fr).sum(1)
+    assert float(c.mean()) >= 0.999, float(c.mean())
+    assert float(c.min()) >= 0.99, float(c.min())
+    # and against the REFERENCE module's own output (compact golden form)
+    sub, _, _ = compact(feat)
+    assert cos(sub, g["teacherwc_feat__sub"]) >= 0.999
+
+
+def test_deeplab_well_conditioned_forward_backward(g, keys):
+    """DeepLabv3-R50 train step at 4x3x224x320 (OS16 map 14x20 = 1120 samples per BatchNorm channel; ASPP rates 6/12/18 all
+    have in-range off-centre taps; models/deeplabv3.py:137-142,295-348) on well-conditioned weights: logits, loss, argmax
+    and EVERY parameter gradient against the fp32 oracle, plus 16 gradients against the reference's own golden."""
+    from openess_amd import hip
+    from openess_amd.models.deeplabv3 import deeplabv3_resnet50
+    from oracle import losses as ol
+    from tests.synth import damp_residual, wc_image
+    net = deeplabv3_resnet50(num_classes=11, text_embeddings_path=None, output_stride=32, pretrained_backbone='')
+    fill_by_name(net, 15)
+    damp_residual(net)
+    net.cuda().train()
+    net.classifier.ASPP.project[3].p = 0.0
+    img = torch.from_numpy(wc_image())
+    tgt = torch.from_numpy(g["deeplabwc_target"]).long()
+    lg, ft = net(img.cuda())
+    loss, _ = hip.task_loss(lg, tgt.cuda(), 11)
+    loss.backward()
+    ref = on.DeepLabV3(11, 32)
+    fill_by_name(ref, 15, keys["deeplab"])
+    damp_residual(ref)
+    ref.train()
+    ref.classifier.ASPP.project[3].p = 0.0
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    lr, fr = ref(img)
+    loss_ref = ol.task_loss(lr, tgt, 11)
+    loss_ref.backward()
+    lgc, lrc = lg.float().detach().cpu().numpy(), lr.detach().numpy()
+    assert relerr(lgc, lrc) < 3e-2, relerr(lgc, lrc)
+    assert relerr(ft.float().detach().cpu().numpy(), fr.detach().numpy()) < 3e-2
+    assert loss.item() == pytest.approx(loss_ref.item(), rel=1e-2)
+    assert loss.item() == pytest.approx(float(g["deeplabwc_loss"]), rel=1e-2)            # the reference's own loss
+    # SURVEY 8d: argmax agreement.  Pixels whose oracle top-2 margin is above the bf16 error bound must agree >= 99.9 %;
+    # over ALL pixels (incl. near-ties of random-weight logits) the floor is what that error bound allows.
+    am, ar = lgc.argmax(1), lrc.argmax(1)
+    srt = np.sort(lrc, axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    bound = 2 * np.abs(lgc - lrc).max()
+    clear = margin > bound
+    assert clear.mean() > 0.5
+    assert (am == ar)[clear].mean() >= 0.999
+    assert (am == ar).mean() >= 0.97, (am == ar).mean()
+    assert (am == g["deeplabwc_argmax"])[clear].mean() >= 0.999
+    # identical integer confusion matrices given identical argmax maps (evaluation/metrics.py:4-23)
+    conf = torch.zeros(11, 11, dtype=torch.int64, device="cuda")
+    hip.confusion_accumulate(torch.from_numpy(ar).cuda(), tgt.cuda(), 11, 255, conf)
+    assert np.array_equal(conf.cpu().numpy(), ol.confusion_matrix(ar, tgt.numpy(), 11))
+    pr = dict(ref.named_parameters())
+    worst = (1.0, None)
+    for name, p in net.named_parameters():
+        if "pixel_feature" in name:
+            assert p.grad is None
+            continue
+        if name == "classifier.text_embeddings":
+            continue
+        assert p.grad is not None, name
+        if name.endswith(".bias") and not name.endswith(("bn1.bias", "bn2.bias", "bn3.bias", "1.bias", "2.bias")):
+            continue
+        c = cos(p.grad.cpu().numpy(), pr[name].grad.numpy())
+        if c < worst[0]:
+            worst = (c, name)
+        assert c >= 0.98, (name, c)
+    from tests.test_oracle_nets_golden import WC_GRADS
+    named = dict(net.named_parameters())
+    for name in WC_GRADS:
+        got = named[name].grad.cpu().numpy()
+        key = "deeplabwc_grad_" + name
+        refv = g[key] if key in g else g[key + "__sub"]
+        got = got if key in g else compact(got)[0]
+        assert cos(got, refv) >= 0.98, (name, cos(got, refv))
+    print("deeplab wc: worst grad cosine", worst, "argmax agreement", float((am == ar).mean()), "clear", float(clear.mean()))
+
+
 def test_conv_train_fn_gradients():
     """conv2d_train (HIP forward, HIP dgrad incl. the zero-insert form for strided convs, HIP wgrad) vs PyTorch autograd of the same
     bf16-rounded operands: every gradient direction must agree to fp32-accumulation noise."""
@@ -202,7 +309,9 @@ def test_conv_train_fn_gradients():
                                                (32, 256, 1, 1, 0, 1, 20, 28),
                                                (64, 128, 3, 2, 1, 1, 15, 23),       # stride 2, odd sizes (output_padding 0)
                                                (128, 256, 1, 2, 0, 1, 14, 21),      # 1x1 stride-2 downsample branch
-                                               (32, 64, 5, 2, 2, 1, 18, 26)):       # 5x5 stride 2
+                                               (32, 64, 5, 2, 2, 1, 18, 26),        # 5x5 stride 2
+                                               (2048, 256, 3, 1, 12, 12, 28, 40),   # ASPP rate 12, non-degenerate (28x40 map)
+                                               (2048, 256, 3, 1, 18, 18, 28, 40)):  # ASPP rate 18
         x = torch.randn(2, Cin, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
         wgt = torch.randn(Cout, Cin, k, k, device="cuda") / (Cin * k * k) ** 0.5
         bias = torch.randn(Cout, device="cuda")
@@ -231,6 +340,7 @@ def test_pretrain_step_matches_oracle(option, contr):
     for name, m in st.models_dict.items():
         fill_by_name(m, 100 + len(name))
         fill_by_name(ref.modules()[name], 100 + len(name), sorted(m.state_dict().keys()))
+        damp_residual(m), damp_residual(ref.modules()[name])         # well-conditioned weights: bf16 storage is not amplified
     if option == "frame2recon":
         st.model_recon.classifier.ASPP.project[3].p = 0.0
         ref.model_recon.classifier.ASPP.project[3].p = 0.0
@@ -245,6 +355,6 @@ def test_pretrain_step_matches_oracle(option, contr):
         losses, _, tl = st.train_step((first.cuda(), None, frame.cuda(), pl.cuda(), sp.cuda(), S))
         lref, tref = ref.train_step((first, None, frame, pl, sp))
         for k in lref:
-            # InfoNCE at T=0.07 on UN-normalised ASPP features (frame2recon) multiplies feature error by ~14
-            rel = 0.25 if (k == 'contrastive_nce_loss' and option == 'frame2recon') else 6e-2
-            assert float(losses[k]) == pytest.approx(float(lref[k]), rel=rel, abs=2e-2), (it, k)
+            # InfoNCE at T=0.07 multiplies feature error by ~14 (un-normalised ASPP features in frame2recon): 5 %; others 2 %
+            rel = 5e-2 if k == 'contrastive_nce_loss' else 2e-2
+            assert float(losses[k]) == pytest.approx(float(lref[k]), rel=rel), (it, k, float(losses[k]), float(lref[k]))
