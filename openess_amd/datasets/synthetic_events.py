@@ -51,15 +51,26 @@ class SyntheticEvents(Dataset):
 
 
 def collate(samples):
-    """Batch the 7-tuples; raw event dicts are concatenated and get per-sub-window segment offsets."""
+    """Batch the reference-shaped tuples (6 items for DDD17, 7 for DSEC; the last one is the file path).  Raw-event dicts
+    in slot 0 are concatenated into SoA columns with per-sub-window segment offsets (pinned by DataLoader(pin_memory=True))."""
     first = [s[0] for s in samples]
-    if isinstance(first[0], dict) and 'events' in first[0]:
-        batch0 = {'events_list': [f['events'] for f in first]}
-    elif isinstance(first[0], dict):
+    if isinstance(first[0], dict) and 'events' in first[0]:                       # DDD17: int64 [N,4] rows per sample
+        batch0 = {'events_list': [f['events'] for f in first], 'flip': [bool(f.get('flip', False)) for f in first]}
+    elif isinstance(first[0], dict):                                              # DSEC / synthetic: x, y, t, p columns
         ev = {k: torch.cat([f[k] for f in first]) for k in ('x', 'y', 't', 'p')}
         ev['events_per_sample'] = torch.tensor([f['x'].numel() for f in first])
+        if 'seg_offsets' in first[0]:
+            offs, base = [torch.zeros(1, dtype=torch.int64)], 0
+            for f in first:
+                offs.append(f['seg_offsets'][1:].to(torch.int64) + base)
+                base += int(f['x'].numel())
+            ev['seg_offsets'] = torch.cat(offs)
+            ev['flip'] = [bool(f.get('flip', False)) for f in first]
+            if 'sequence' in first[0]:
+                ev['sequence'] = [int(f['sequence']) for f in first]
         batch0 = ev
     else:
         batch0 = torch.stack(first)
-    rest = [torch.stack([s[i] for s in samples]) for i in range(1, 6)]
-    return (batch0, *rest, [s[6] for s in samples])
+    n = len(samples[0])
+    rest = [torch.stack([s[i] for s in samples]) for i in range(1, n - 1)]
+    return (batch0, *rest, [s[n - 1] for s in samples])

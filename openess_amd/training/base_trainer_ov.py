@@ -115,6 +115,7 @@ class BaseTrainer(object):
             train_ds, val_ds = builder.build_from_settings(s)
         self.sensor_geometry = (train_ds.sensor_hw, train_ds.crop_rows) if hasattr(train_ds, 'sensor_hw') else None
         self.rectify_maps = torch.from_numpy(train_ds.rectify_map[None]).to(self.device) if hasattr(train_ds, 'rectify_map') else None
+        self._voxel_ds = {'train': train_ds, 'val': val_ds}            # un-wrapped datasets: Subset has no voxelize_batch
         if self.world > 1:
             train_ds = Subset(train_ds, shard_indices(len(train_ds), self.rank, self.world).tolist())
         self.train_loader_sensor_b = DataLoader(train_ds, batch_size=s.batch_size_b, num_workers=s.num_cpu_workers,
@@ -122,14 +123,19 @@ class BaseTrainer(object):
         self.val_loader_sensor_b = DataLoader(val_ds, batch_size=s.batch_size_b, num_workers=s.num_cpu_workers,
                                               pin_memory=True, shuffle=False, drop_last=False, collate_fn=collate)
 
-    def prepare_batch(self, sample_batched):
+    def prepare_batch(self, sample_batched, split='train'):
         """Host batch -> device batch.  A raw-event dict becomes the B x (nr_events_data*C) x H x W voxel tensor
         via ONE batched launch sequence of the HIP voxelizer (rectification, time normalisation, crop fused)."""
         s = self.settings
         first = sample_batched[0]
         rest = [t.to(self.device, non_blocking=True) if torch.is_tensor(t) else t for t in sample_batched[1:]]
+        if len(rest) == 5:                      # DDD17's 6-tuple has no sam_feat (ddd17_events_loader.py:290): keep slot 5 = None
+            rest = rest[:4] + [None] + rest[4:]
+        ds = self._voxel_ds[split]
         if isinstance(first, dict) and 'events_list' in first:            # DDD17: int64 [N,4] rows per sample
-            first = self.train_loader_sensor_b.dataset.voxelize_batch(first['events_list'], self.device)
+            first = ds.voxelize_batch(first['events_list'], self.device, flips=first.get('flip'))
+        elif isinstance(first, dict) and 'seg_offsets' in first:          # DSEC: raw columns + explicit sub-window offsets
+            first = ds.voxelize_batch(first, self.device)
         elif isinstance(first, dict):
             (H, W), crop = self.sensor_geometry
             C, nwin = s.nr_temporal_bins_b, s.nr_events_data_b
@@ -195,7 +201,7 @@ class BaseTrainer(object):
     def valEpoch(self, data_loader, sensor_name):
         cumulative = {}
         for i_batch, sample_batched in enumerate(data_loader):
-            batch = self.prepare_batch(sample_batched)
+            batch = self.prepare_batch(sample_batched, 'val')
             out = self.val_step(batch[:-4], sensor_name, i_batch, -1, sample_batched[-1])
             for k, v in out[0].items():
                 cumulative[k] = cumulative.get(k, 0) + v

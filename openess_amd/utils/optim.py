@@ -49,10 +49,12 @@ class AdamW(torch.optim.AdamW):
                 by_step.setdefault(int(st['step'].item()), []).append(p)
             for step, plist in by_step.items():
                 dev = plist[0].device
-                rows, cmap = [], []
+                rows, cmap, keep_alive = [], [], []
                 for ti, p in enumerate(plist):
                     st = self.state[p]
                     g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                    keep_alive.append(g)       # a contiguous temporary must outlive the launch (the caching allocator would
+                    #                            hand its block to the `table` / `chunks` uploads below)
                     rows.append((p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel()))
                     cmap.extend((ti, c) for c in range((p.numel() + CHUNK - 1) // CHUNK))
                 table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev, non_blocking=True)
@@ -65,4 +67,7 @@ class AdamW(torch.optim.AdamW):
                            "oess_adamw_multi_f32")
                 # the kernel wrote through raw pointers: tell autograd (and the packed-weight caches keyed on ._version)
                 increment_version(list(plist) + [self.state[p][k] for p in plist for k in ('exp_avg', 'exp_avg_sq')])
+                for g in keep_alive:           # stream-ordered: blocks freed from here on are reused only after the kernel
+                    g.record_stream(torch.cuda.current_stream(dev))
+                del keep_alive
         return loss

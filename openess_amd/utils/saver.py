@@ -32,8 +32,9 @@ class CheckpointSaver(object):
         return path
 
     def load_checkpoint(self, models, optimizers, checkpoint_file=None, load_optimizer=False):
-        """The reference's resume path reads keys no saver writes (utils/saver.py:68-71) and is broken; here the
-        model keys that exist are loaded and epoch / step_count default to 0 when absent."""
+        """Model keys that exist are loaded; `epoch` / `step_count` must be present (KeyError otherwise, as utils/saver.py:67-71).
+        The reference additionally reads `batch_size_a/b`, which no saver writes -- its resume path is broken there; those
+        two keys are not required here."""
         ckpt = torch.load(checkpoint_file, map_location='cpu')
         for name in models:
             if name in ckpt:
@@ -42,12 +43,14 @@ class CheckpointSaver(object):
             for name in optimizers:
                 if name in ckpt:
                     optimizers[name].load_state_dict(ckpt[name])
-        return {'epoch': ckpt.get('epoch', 0), 'step_count': ckpt.get('step_count', 0)}
+        return {'epoch': ckpt['epoch'], 'step_count': ckpt['step_count']}       # KeyError on a foreign file, as the reference (:67-71)
 
     def load_pretrained_weights(self, models, models_to_load, checkpoint_file=None, frozen_backbone=False):
         """Shape-filtered partial load; with frozen_backbone the `classifier*` tensors are skipped (:73-96)."""
         ckpt = torch.load(checkpoint_file, map_location='cpu')
         for name in models_to_load:
+            if name in ('front_sensor_b', 'e2vid_decoder'):       # never taken from a stage-1 checkpoint (saver.py:78-79)
+                continue
             if name not in ckpt or name not in models:
                 continue
             own = models[name].state_dict()

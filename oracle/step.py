@@ -99,8 +99,11 @@ class OracleSupervisedStep:
         else:
             self.net = on.DeepLabV3(num_classes, output_stride)
         if linear_probing:
-            for p in self.net.parameters():
-                p.requires_grad = False
+            for name, p in self.net.named_parameters():
+                # style_networks.py:113-131 freezes decoder_scale_1..4 + ch256 + ch512 but NOT the (unused) decoder_scale_5,
+                # which therefore stays in the optimiser with grad None; deeplabv3.py:162-168 freezes backbone + classifier
+                if not name.startswith('decoder_scale_5'):
+                    p.requires_grad = False
             self.net.linear_probe = torch.nn.Conv2d(num_classes, num_classes, 1)
         self.optim = torch.optim.AdamW([p for p in self.net.parameters() if p.requires_grad], lr=lr)
 

@@ -247,6 +247,10 @@ if __name__ == "__main__":
         GROUPS.update(gen_golden_nets.GROUPS)
     except ImportError:
         pass
+    def _datasets():       # own process: its import stubs (h5py, cv2, torchvision, `datasets`) must not leak into the other groups
+        import subprocess
+        subprocess.run([sys.executable, os.path.join(HERE, "gen_golden_datasets.py")], check=True)
+    GROUPS["datasets"] = _datasets
     which = sys.argv[1:] or list(GROUPS)
     for g in which:
         GROUPS[g]()

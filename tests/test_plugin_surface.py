@@ -60,37 +60,38 @@ def test_checkpoint_format_roundtrip(tmp_path):
     assert torch.equal(tgt['back_end'].weight, models['back_end'].weight)
     assert torch.equal(tgt['model_recon'].weight, before)
     assert os.path.basename(sv.save_checkpoint_model_single(models, 0, 0)) == 'ckp.pt'
-
-
-def _fake_ddd17(root, n_events=9000, n_frames=3):
-    from PIL import Image
-    d = os.path.join(root, "dir0")
-    os.makedirs(os.path.join(d, "index"))
-    os.makedirs(os.path.join(d, "segmentation_masks"))
-    rng = np.random.default_rng(0)
-    t = np.sort(rng.integers(0, 10**6, n_events)).astype(np.int64).reshape(-1, 1)
-    xyp = np.stack([rng.integers(0, 346, n_events), rng.integers(0, 260, n_events), rng.integers(0, 2, n_events)], -1).astype(np.int16)
-    t.tofile(os.path.join(d, "events.dat.t"))
-    xyp.tofile(os.path.join(d, "events.dat.xyp"))
-    idx = np.array([[0, (i + 1) * n_events // n_frames, 0] for i in range(n_frames)], dtype=np.int64)
-    np.save(os.path.join(d, "index", "index_50ms.npy"), idx)
-    for i in range(n_frames):
-        Image.fromarray(rng.integers(0, 6, (260, 346)).astype(np.uint8)).save(os.path.join(d, "segmentation_masks", f"segmentation_{i + 1:08d}.png"))
-    return d, t, xyp, idx
+    # front_sensor_b / e2vid_decoder are never taken from a stage-1 checkpoint (utils/saver.py:78-79)
+    torch.save({'front_sensor_b': torch.nn.Linear(2, 2).state_dict(), 'back_end': models['back_end'].state_dict()}, str(tmp_path / 'x.pt'))
+    tgt = {'front_sensor_b': torch.nn.Linear(2, 2), 'back_end': torch.nn.Linear(3, 2)}
+    keep = tgt['front_sensor_b'].weight.clone()
+    sv.load_pretrained_weights(tgt, tgt.keys(), str(tmp_path / 'x.pt'))
+    assert torch.equal(tgt['front_sensor_b'].weight, keep) and torch.equal(tgt['back_end'].weight, models['back_end'].weight)
+    with pytest.raises(KeyError):
+        sv.load_checkpoint(tgt, {}, checkpoint_file=str(tmp_path / 'x.pt'))
 
 
 def test_ddd17_memmap_reader(tmp_path):
+    """Raw event rows of a sample == the memmap slice the reference extracts (example_loader_ddd17.py:39-54)."""
     from openess_amd.datasets.ddd17_events_loader import DDD17Events
-    d, t, xyp, idx = _fake_ddd17(str(tmp_path))
-    ds = DDD17Events(str(tmp_path), nr_events_data=4, nr_events_per_data=500, nr_bins_per_data=5)
-    assert len(ds) == 3
-    item = ds[1]
+    from tests import synth_datasets as sd
+    root = sd.make_ddd17_tree(str(tmp_path))
+    ds = DDD17Events(root, nr_events_data=4, nr_events_per_data=500, nr_bins_per_data=5, config_option='frame2voxel',
+                     pl_sources='pl_fcclip_rgb', superpixel_sources='sp_sam_rgb')
+    assert len(ds) == 5 * 4 and not any('dir1' in f for f in ds.files)             # get_split('train'): dir1 held out
+    i = next(k for k, f in enumerate(ds.files) if f.endswith('dir2/segmentation_masks/segmentation_00000002.png'))
+    item = ds[i]
     ev = item[0]['events'].numpy()
+    d = os.path.join(root, 'dir2')
+    idx = np.load(os.path.join(d, 'index', 'index_50ms.npy'))
+    t = np.fromfile(os.path.join(d, 'events.dat.t'), dtype=np.int64)
+    xyp = np.fromfile(os.path.join(d, 'events.dat.xyp'), dtype=np.int16).reshape(-1, 3)
     hi = idx[1, 1]
     lo = max(hi - 4 * 500, 0)
     assert ev.shape == (hi - lo, 4) and ev.dtype == np.int64
-    assert np.array_equal(ev[:, 2], t[lo:hi, 0]) and np.array_equal(ev[:, [0, 1, 3]], xyp[lo:hi].astype(np.int64))
+    assert np.array_equal(ev[:, 2], t[lo:hi]) and np.array_equal(ev[:, [0, 1, 3]], xyp[lo:hi].astype(np.int64))
     assert item[1].shape == (200, 352) and item[1].dtype == torch.int64
+    assert len(item) == 6 and item[2].shape == (3, 200, 352) and item[3].shape == (200, 352)      # frame, pl (pseudo-labels, not GT)
+    assert not torch.equal(item[3], item[1])
 
 
 @pytest.mark.gpu
@@ -98,8 +99,10 @@ def test_ddd17_batch_voxelization_matches_oracle(tmp_path):
     import torch.nn.functional as f
     from openess_amd.datasets.ddd17_events_loader import DDD17Events
     from oracle import events as oe
-    _fake_ddd17(str(tmp_path))
-    ds = DDD17Events(str(tmp_path), nr_events_data=4, nr_events_per_data=500, nr_bins_per_data=5)
+    from tests import synth_datasets as sd
+    root = sd.make_ddd17_tree(str(tmp_path))
+    ds = DDD17Events(root, nr_events_data=4, nr_events_per_data=500, nr_bins_per_data=5, config_option='frame2voxel',
+                     pl_sources='pl_fcclip_rgb', superpixel_sources='sp_sam_rgb')
     evs = [ds[i][0]['events'] for i in (1, 2)]
     vox = ds.voxelize_batch(evs, torch.device("cuda"))
     assert vox.shape == (2, 20, 200, 352)
