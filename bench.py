@@ -10,11 +10,28 @@ One "step" = one batch of B=8 synthetic DSEC-shaped samples per GPU, ENTIRELY in
 Random-init weights of the reference architectures, synthetic data (no network / datasets here).
 N > 1: one process per GPU (torch.distributed nccl = RCCL), per-rank batch 8 (weak scaling), gradient
 all-reduce of the trainable parameters, max-over-ranks timing.
+
+The ONE JSON line rank 0 prints carries, besides the headline `value` (inputs resident in HBM, as the contract says):
+  roofline      dominant kernel family (MFMA implicit-GEMM conv), live HIP-event durations inside the timed region;
+                `traffic` = HBM bytes per launch from two rocprofv3 PMC passes THIS invocation drives (N=1; --no-pmc skips)
+  stages        per-stage rooflines measured live after the timed region (HIP events, N=1): voxelizer (uniform and
+                structured-locality events), superpixel scatter-mean (fp32 / bf16, block / random ids), DeepLabv3 forward,
+                teacher forward, MaskCLIP tower forward
+  configs       the other single-GPU BASELINE configurations timed the same way: frame2voxel_full (configs[2]),
+                frame2recon_full
+  ingest        the same step with the raw events starting in PINNED HOST buffers: H2D copy + voxelizer of batch i+1 on a
+                side HIP stream under step i (never `value`)
+  cpu_baseline  the oracle on this host's CPU (1 warm-up + 3 timed, median)
 """
 import argparse
+import glob
 import json
 import os
+import re
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC for RCCL on this host driver (before torch loads HIP)
@@ -29,17 +46,25 @@ sys.path.insert(0, ROOT)
 C, H_SENSOR, W_SENSOR, CROP, NWIN, N_PER, B = 5, 480, 640, 40, 20, 100000, 8
 H_NET = H_SENSOR - CROP
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0           # MI355X HBM3E (MI355X_MICROARCH.md)
+# algorithmic work per batch of 8 (SURVEY 8d / BASELINE.md section 4)
+VOX_BYTES = 16 * B * NWIN * N_PER + 4 * B * NWIN * C * H_SENSOR * W_SENSOR           # 1.239 GB
+GFLOP_FWD = {"deeplabv3_resnet50": 106.8 * B, "dilated_r50_teacher": 845.1 * B}
+DOMINANT = re.compile(r"conv_fwd_dma_kernel<(128|64), 128, 2, (true|false), [01](, 256)?>|conv_fwd_dma32_kernel<128, true, 0, 3")
 
 
-def make_inputs(rank, device, workload):
-    from tests import synth
-    xs, ys, ts, ps = [], [], [], []
-    for b in range(B):
-        x, y, t, p = synth.dsec_raw_events(NWIN * N_PER, H_SENSOR, W_SENSOR, seed=1205 + rank * B + b)
-        xs.append(x); ys.append(y); ts.append(t); ps.append(p)
-    ev = dict(x=torch.from_numpy(np.concatenate(xs)).to(device), y=torch.from_numpy(np.concatenate(ys)).to(device),
-              t=torch.from_numpy(np.concatenate(ts)).to(device), p=torch.from_numpy(np.concatenate(ps)).to(device),
-              maps=torch.from_numpy(synth.rectify_map(H_SENSOR, W_SENSOR)[None]).to(device),
+def make_events(rank, structured=False):
+    from openess_amd.datasets import _synth
+    gen = _synth.dsec_structured_events if structured else _synth.dsec_raw_events
+    cols = [gen(NWIN * N_PER, H_SENSOR, W_SENSOR, seed=1205 + rank * B + b) for b in range(B)]
+    return {k: torch.from_numpy(np.concatenate([c[i] for c in cols])) for i, k in enumerate("xytp")}
+
+
+def make_inputs(rank, device):
+    from openess_amd.datasets import _synth
+    host = make_events(rank)
+    ev = {k: v.to(device) for k, v in host.items()}
+    ev.update(maps=torch.from_numpy(_synth.rectify_map(H_SENSOR, W_SENSOR)[None]).to(device),
               seg_map=torch.zeros(B * NWIN, dtype=torch.int32, device=device),
               seg=torch.arange(0, (B * NWIN + 1) * N_PER, N_PER, dtype=torch.int64))
     g = torch.Generator().manual_seed(99 + rank)
@@ -49,71 +74,332 @@ def make_inputs(rank, device, workload):
     yy = (torch.arange(H_NET) * 10 // H_NET)[:, None]
     xx = (torch.arange(W_SENSOR) * 10 // W_SENSOR)[None, :]
     sp = (yy * 10 + xx)[None].repeat(B, 1, 1).long()
-    return ev, frame, pl.to(device), sp.to(device), (B - 1) * 100 + 100
+    return host, ev, frame, pl.to(device), sp.to(device), (B - 1) * 100 + 100
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _median_time(fn, warm=1, n=3):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), ts
 
 
 def cpu_baseline(sample_events, rectify_map):
-    """Oracle (CPU port) timed on this host on ONE full-size sample (= one event-frame, about 10 s of CPU work):
-    scalar C voxelizer (2M events -> 100x440x640) + fp32 PyTorch-CPU teacher forward, 20 recurrent E2VID encoder
-    steps, SemSegE2VID forward + backward + AdamW at B=1.  64 torch threads (more threads oversubscribe: the same
-    step took 345 s with 256 threads on this 256-core host)."""
-    from oracle import losses as ol
-    from oracle import nets as on
-    from oracle.step import OracleStep, voxelize_sample
+    """The oracle (CPU port of the reference path, validated against the reference's golden vectors) on this host.
+    Every leg: 1 warm-up + 3 timed, median.  Legs: (i) voxelizer of ONE full-size event-frame -- the reference-faithful
+    8-pass masked-scatter algorithm (oracle/events.py = representations.py:15-54, sequential and with the reference's 8
+    threads, sequence_ov.py:304-305) and the scalar C port; (ii) fp32 PyTorch-CPU teacher forward + 20 recurrent E2VID
+    encoder steps + SemSegE2VID forward/backward + AdamW at B=1 (configs[1] shape); (iii) the CPU-runnable configs[0]:
+    DDD17-shaped 200x352, K=6, B=2 step.  `value` = 1 / (fastest voxelizer + net step) event-frames/s."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import events as oe
+    from oracle.step import OracleStep
     ncores = os.cpu_count() or 1
-    nthr = min(ncores, 64)
+    nthr = min(ncores, 64)           # more torch threads oversubscribe: the same step took 345 s with 256 threads on a 256-core host
     torch.set_num_threads(nthr)
     torch.manual_seed(1205)
     x, y, t, p = sample_events
-    t0 = time.perf_counter()
-    try:       # scalar C port (oracle/voxel_oracle.c) when built, else the NumPy restatement
+    legs = {}
+    # (i) voxelizer
+    xy = rectify_map[y.astype(np.int64), x.astype(np.int64)]
+    n = x.shape[0] // NWIN
+
+    def chunk(i):
+        s, e = i * n, (i + 1) * n
+        return oe.voxelgrid_trilinear(xy[s:e, 0], xy[s:e, 1], p[s:e].astype(np.float32), oe.dsec_time_normalise(t[s:e]), C, H_SENSOR, W_SENSOR)
+    legs["voxelizer_8pass_numpy_1thread_s"], _ = _median_time(lambda: [chunk(i) for i in range(NWIN)], warm=1, n=3)
+    with ThreadPoolExecutor(8) as pool:
+        legs["voxelizer_8pass_numpy_8threads_s"], _ = _median_time(lambda: list(pool.map(chunk, range(NWIN))), warm=1, n=3)
+    ev = None
+    try:
         from oracle import cport
-        ev = torch.from_numpy(cport.dsec_event_tensor(x, y, t, p, rectify_map, NWIN, C, H_SENSOR, W_SENSOR, CROP))[None]
-        vox_kind = "C port, 1 thread"
-    except Exception:
-        ev = voxelize_sample(x, y, t, p, rectify_map, NWIN, C, H_SENSOR, W_SENSOR, CROP)[None]
-        vox_kind = "NumPy"
-    t_vox = time.perf_counter() - t0
+        fn = lambda: cport.dsec_event_tensor(x, y, t, p, rectify_map, NWIN, C, H_SENSOR, W_SENSOR, CROP)  # noqa: E731
+        legs["voxelizer_c_port_1thread_s"], _ = _median_time(fn, warm=1, n=3)
+        ev = torch.from_numpy(fn())[None]
+    except Exception as e:
+        legs["voxelizer_c_port_error"] = repr(e)
+    if ev is None:
+        ev = torch.from_numpy(oe.dsec_event_tensor(x, y, t, p, rectify_map, NWIN, C, H_SENSOR, W_SENSOR, CROP))[None]
+    t_vox = min(v for k, v in legs.items() if k.startswith("voxelizer") and k.endswith("_s"))
+    # (ii) configs[1]-shaped step at B=1
     step = OracleStep('frame2voxel', 11, NWIN, C, False)
     g = torch.Generator().manual_seed(5)
     frame = torch.rand(1, 3, H_NET, W_SENSOR, generator=g)
     pl = torch.randint(0, 11, (1, H_NET, W_SENSOR), generator=g)
-    t1 = time.perf_counter()
-    step.train_step((ev, None, frame, pl))
-    t_net = time.perf_counter() - t1
+    t_net, all_net = _median_time(lambda: step.train_step((ev, None, frame, pl)), warm=1, n=3)
+    legs["net_step_B1_s"] = t_net
+    # (iii) BASELINE configs[0]: DDD17-shaped CPU step (200x352, K=6, B=2, 20 sub-windows x 5 bins)
+    try:
+        step0 = OracleStep('frame2voxel', 6, NWIN, C, False)
+        ev0 = (torch.randn(2, NWIN * C, 200, 352, generator=g) * (torch.rand(2, NWIN * C, 200, 352, generator=g) > 0.9)).contiguous()
+        fr0, pl0 = torch.rand(2, 3, 200, 352, generator=g), torch.randint(0, 6, (2, 200, 352), generator=g)
+        t0, _ = _median_time(lambda: step0.train_step((ev0, None, fr0, pl0)), warm=1, n=3)
+        legs["ddd17_config0_step_B2_s"] = t0
+        legs["ddd17_config0_event_frames_per_s"] = round(2.0 / t0, 4)
+    except Exception as e:
+        legs["ddd17_config0_error"] = repr(e)
     total = t_vox + t_net
     return {"value": round(1.0 / total, 5), "unit": "event-frames/s", "cores": nthr, "kind": "port",
-            "sample": f"oracle on host CPU ({ncores} cores, {nthr} torch threads), ONE full-size event-frame: voxelizer "
-                      f"({vox_kind}) {t_vox:.2f}s + fp32 teacher fwd / 20 E2VID steps / SemSegE2VID fwd+bwd+AdamW at B=1 "
-                      f"{t_net:.2f}s = {total:.1f}s"}
+            "sample": f"oracle on host CPU ({ncores} cores; {nthr} torch threads used), ONE full-size event-frame, 1 warm-up + 3 timed, "
+                      f"median: fastest CPU voxelizer {t_vox:.3f}s + fp32 teacher fwd / 20 E2VID steps / SemSegE2VID fwd+bwd+AdamW at "
+                      f"B=1 {t_net:.2f}s = {total:.2f}s",
+            "legs": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in legs.items()}}
 
 
-def _pmc_traffic(workload):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
-    (profiles/r01_conv_hbm_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 read correction applied).
-    PMC counters cannot be sampled from inside the timed process, so the number travels with the repo; None when the
-    profile is absent or belongs to another workload."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_conv_hbm_traffic.json")
-    if workload != "frame2voxel_pixel_distill" or not os.path.exists(path):
-        return None
+# ------------------------------------------------------------------------------------------------ PMC traffic (live)
+def _pmc_pass(counter, timeout_s):
+    """One `rocprofv3 --pmc <counter> --kernel-trace` pass over a 1+1-step child of this script; returns
+    (launches, sum of counter in KiB) over the dominant kernel family, or raises."""
+    out = tempfile.mkdtemp(prefix=f"oess_pmc_{counter}_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--",
+           sys.executable, os.path.abspath(__file__), "--child", "--steps", "1", "--warmup", "1"]
     try:
-        with open(path) as f:
-            return round(json.load(f)["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+        subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        import csv
+        n, kib = 0, 0.0
+        for fn in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            with open(fn) as f:
+                for r in csv.DictReader(f):
+                    if r.get("Counter_Name") == counter and DOMINANT.search(r["Kernel_Name"]):
+                        n += 1
+                        kib += float(r["Counter_Value"])
+        if n == 0:
+            raise RuntimeError("no dominant-kernel rows in the counter collection")
+        return n, kib
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def pmc_traffic(timeout_s=420):
+    """HBM bytes per launch of the dominant kernel family: separate FETCH_SIZE / WRITE_SIZE passes (the guide's HBM section:
+    counters in KiB; on gfx950 FETCH_SIZE reports half of a 16 B/lane coalesced read stream -> read = 2 * FETCH_SIZE * 1024)."""
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    try:
+        nf, f_kib = _pmc_pass("FETCH_SIZE", timeout_s)
+        nw, w_kib = _pmc_pass("WRITE_SIZE", timeout_s)
+        return {"hbm_bytes_per_launch": round((2 * f_kib / nf + w_kib / nw) * 1024), "read_bytes_per_launch": round(2 * f_kib / nf * 1024),
+                "write_bytes_per_launch": round(w_kib / nw * 1024), "launches_counted": nf}, None
+    except Exception as e:      # counters must never cost the throughput number
+        return None, repr(e)[:300]
+
+
+# ------------------------------------------------------------------------------------------------ the step
+class Workload:
+    def __init__(self, name, rank, world, device, inputs):
+        from openess_amd.training.ddp import GradAllReduce, broadcast_module_states
+        from openess_amd.training.pretrain_step import PretrainStep
+        self.name, self.device, self.world = name, device, world
+        self.host, self.ev, self.frame, self.pl, self.sp, self.S = inputs
+        self.contrastive = name in ("frame2voxel_full", "frame2recon_full")
+        self.online_teacher = None
+        if name.endswith("_online"):
+            from openess_amd.models.maskclip_model import maskClipFeatureExtractor
+            torch.manual_seed(1205)
+            self.online_teacher = maskClipFeatureExtractor(text_categories=11).to(device).eval()
+        self.option = "frame2recon" if name.startswith("frame2recon") else "frame2voxel"
+        self.step = PretrainStep(config_option=self.option, img_size=(H_NET, W_SENSOR), nr_events_data=NWIN, nr_temporal_bins=C,
+                                 if_spatial_contrastive=self.contrastive, superpixel_size=100, device=device)
+        if world > 1:      # identical initial weights on every rank
+            broadcast_module_states(self.step.models_dict.values())
+        self.reducer = GradAllReduce([p for m in self.step.models_dict.values() for p in m.parameters()], world)
+        self.voxels = [torch.empty((B, NWIN * C, H_NET, W_SENSOR), dtype=torch.float32, device=device)]
+
+    def voxelize(self, ev, out):
+        from openess_amd import hip
+        hip.voxelize_dsec_raw(ev["x"], ev["y"], ev["t"], ev["p"], self.ev["maps"], self.ev["seg_map"], self.ev["seg"], C, H_SENSOR,
+                              W_SENSOR, crop_rows=CROP, out=out.view(B * NWIN * C, H_NET, W_SENSOR))
+
+    def train(self, voxels):
+        first = self.frame if self.option == "frame2recon" else voxels
+        labels = self.pl if self.online_teacher is None else self.online_teacher(self.frame).argmax(dim=1)
+        for opt in self.step.optimizers_dict.values():
+            opt.zero_grad()
+        t_loss, losses, _ = self.step.task_train_step((first, None, self.frame, labels, self.sp, self.S))
+        t_loss.backward()
+        self.reducer()
+        for opt in self.step.optimizers_dict.values():
+            opt.step()
+        return t_loss
+
+    def one_step(self):
+        self.voxelize(self.ev, self.voxels[0])
+        return self.train(self.voxels[0])
+
+    def fence(self):
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, steps, warmup, conv_timing=False):
+        from openess_amd import hip
+        for _ in range(warmup):
+            self.one_step()
+        if conv_timing:
+            hip.conv_timing_begin()
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = self.one_step()
+        self.fence()
+        dt = time.perf_counter() - t0
+        stats = hip.conv_timing_end() if conv_timing else None
+        if self.world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=self.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, float(loss.detach()), stats
+
+    def timed_with_ingest(self, steps, warmup):
+        """The raw event columns of EVERY step start in pinned host memory (what DataLoader(pin_memory=True) hands over,
+        13 B/event = 208 MB per batch): H2D copy + voxelizer of batch i+1 run on a side HIP stream under step i
+        (double-buffered device columns and voxel tensors)."""
+        side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        pinned = {k: v.pin_memory() for k, v in self.host.items()}
+        dev = [{k: torch.empty_like(v, device=self.device) for k, v in self.host.items()} for _ in range(2)]
+        if len(self.voxels) < 2:
+            self.voxels.append(torch.empty_like(self.voxels[0]))
+        ready, consumed = [None, None], [None, None]
+
+        def produce(slot):
+            with torch.cuda.stream(side):
+                if consumed[slot] is not None:
+                    side.wait_event(consumed[slot])            # step i-1 has finished reading voxels[slot]
+                for k in pinned:
+                    dev[slot][k].copy_(pinned[k], non_blocking=True)
+                self.voxelize(dev[slot], self.voxels[slot])
+                e = torch.cuda.Event()
+                e.record(side)
+                ready[slot] = e
+
+        def loop(n):
+            loss = None
+            produce(0)
+            for i in range(n):
+                slot = i & 1
+                main.wait_event(ready[slot])
+                if i + 1 < n:
+                    produce(1 - slot)
+                loss = self.train(self.voxels[slot])
+                e = torch.cuda.Event()
+                e.record(main)
+                consumed[slot] = e
+            return loss
+        loop(max(warmup, 2))
+        self.fence()
+        t0 = time.perf_counter()
+        loop(steps)
+        self.fence()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=self.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+
+# ------------------------------------------------------------------------------------------------ per-stage rooflines
+def _ev_time(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def _hbm(ms, nbytes, note):
+    a = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "ms": round(ms, 4), "algorithmic_bytes": int(nbytes), "achieved": round(a, 1), "peak": PEAK_HBM_GBS,
+            "unit": "GB/s", "frac": round(a / PEAK_HBM_GBS, 4), "note": note}
+
+
+def _mfma(ms, gflop, note):
+    a = gflop / ms              # GFLOP / ms = TFLOP/s
+    return {"bound": "mfma", "ms": round(ms, 3), "algorithmic_gflop": round(gflop, 1), "achieved": round(a, 1), "peak": PEAK_BF16_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(a / PEAK_BF16_TFLOPS, 4), "note": note}
+
+
+def stage_rooflines(wl, rank, device):
+    """Live HIP-event timings (current stream = the launch stream of every kernel) of the hot-path stages on their own,
+    at the BASELINE size, with the algorithmic figures of SURVEY 8d."""
+    from openess_amd import hip
+    st = {}
+    out = wl.voxels[0]
+    st["voxelizer"] = _hbm(_ev_time(lambda: wl.voxelize(wl.ev, out)), VOX_BYTES,
+                           "raw u16/u16/i64/u8 columns + rectify gather + tri-linear splat + crop, B=8 x 20 x 100k uniform events; "
+                           "algorithmic bytes = 16 B/event + 4 B/voxel at 480 rows (SURVEY 8d; the kernel ingests 13 B/event)")
+    ev_s = {k: v.to(device) for k, v in make_events(rank, structured=True).items()}
+    st["voxelizer_structured_events"] = _hbm(_ev_time(lambda: wl.voxelize(ev_s, out)), VOX_BYTES,
+                                             "same, 70 % of the events on 200 moving edges (SURVEY 8d locality variant)")
+    del ev_s
+    # K7 superpixel scatter-mean, forward and backward, the reference's fp32 features and this pipeline's bf16 features
+    ids_rand = torch.randint(0, 256, (B, H_NET // 8, W_SENSOR // 8), device=device).repeat_interleave(8, 1).repeat_interleave(8, 2)
+    for dt, tag in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
+        feat = torch.randn(B, H_NET, W_SENSOR, 256, device=device).to(dt).permute(0, 3, 1, 2).requires_grad_(True)
+        fb = feat.numel() * feat.element_size()
+        for ids, name, S in ((wl.sp, "blocks", B * 100), (ids_rand, "random_ids_le_255", (B - 1) * 100 + 256)):
+            ms_f = _ev_time(lambda: hip.superpixel_pool(feat.detach(), ids, 100, S=S))
+            k = hip.superpixel_pool(feat, ids, 100, S=S)
+            g = torch.randn_like(k)
+            ms_fb = _ev_time(lambda: torch.autograd.grad(hip.superpixel_pool(feat, ids, 100, S=S), feat, g))
+            st[f"scatter_mean_{tag}_{name}"] = _hbm(ms_fb, 2 * fb + 2 * ids.numel() * 8 + 2 * S * 256 * 4,
+                                                    f"K7 forward + backward, {tag} features (SURVEY 8d counts fp32 = 4.63 GB); forward alone "
+                                                    f"{ms_f:.3f} ms = {(fb + ids.numel() * 8) / ms_f / 1e6:.0f} GB/s")
+        del feat
+    # forward-only MFMA stages (train-mode BatchNorm = what the step runs; no autograd bookkeeping)
+    from openess_amd.training.pretrain_step import PretrainStep
+    recon = torch.rand(B, 3, H_NET, W_SENSOR, device=device)
+    with torch.no_grad():
+        teacher = wl.step.model_frame
+        teacher.train()
+        st["dilated_r50_teacher_forward"] = _mfma(_ev_time(lambda: teacher(wl.frame), iters=10), GFLOP_FWD["dilated_r50_teacher"],
+                                                  "DilationFeatureExtractor forward incl. BatchNorm(train), x4 bilinear, L2 (a10)")
+        dl = PretrainStep(config_option="frame2recon", img_size=(H_NET, W_SENSOR), nr_events_data=NWIN, device=device).model_recon
+        dl.train()
+        st["deeplabv3_forward"] = _mfma(_ev_time(lambda: dl(recon), iters=10), GFLOP_FWD["deeplabv3_resnet50"],
+                                        "deeplabv3_resnet50 forward incl. ASPP 6/12/18, BatchNorm(train), 2 bilinear resizes (a12; north_star 'ASPP forward')")
+        del dl
+        try:
+            from openess_amd.models.maskclip_model import maskClipFeatureExtractor
+            torch.manual_seed(0)
+            m = maskClipFeatureExtractor(text_categories=11).to(device).eval()
+            L, Cw = 1121, 768
+            gemm = 2.0 * B * L * (11 * (Cw * 3 * Cw + Cw * Cw) + (Cw * Cw + Cw * Cw) + 12 * 2 * Cw * 4 * Cw) + 2.0 * B * 1120 * (3 * 256 * Cw + Cw * 512 + 512 * 11)
+            attn = 11 * 2 * 2.0 * B * 12 * L * L * 64
+            st["maskclip_vit_b16_forward"] = _mfma(_ev_time(lambda: m(wl.frame), iters=10), (gemm + attn) / 1e9,
+                                                   "MaskCLIP ViT-B/16 tower, 1121 tokens, value-path last block (a19; north_star 'CLIP forward')")
+            del m
+        except Exception as e:
+            st["maskclip_vit_b16_forward"] = {"error": repr(e)[:200]}
+    torch.cuda.empty_cache()
+    return st
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="frame2voxel_pixel_distill",
                     choices=["frame2voxel_pixel_distill", "frame2voxel_full", "frame2recon_full",
                              "frame2voxel_pixel_distill_online"],
                     help="..._online: the pseudo-labels are argmax of the frozen MaskCLIP ViT-B/16 tower run inside the step "
                          "(SURVEY 8f rank 1) instead of the offline PNG labels the reference reads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC child passes (roofline.traffic = null)")
+    ap.add_argument("--no-extras", action="store_true", help="headline + roofline only: no stages / configs / ingest blocks")
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)        # profiled child of pmc_traffic(): steps only
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,63 +413,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    from openess_amd import hip
-    from openess_amd.training.ddp import GradAllReduce, broadcast_module_states
-    from openess_amd.training.pretrain_step import PretrainStep
-
-    contrastive = a.workload in ("frame2voxel_full", "frame2recon_full")
-    online_teacher = None
-    if a.workload.endswith("_online"):
-        from openess_amd.models.maskclip_model import maskClipFeatureExtractor
-        torch.manual_seed(1205)
-        online_teacher = maskClipFeatureExtractor(text_categories=11).to(device).eval()
-    option = "frame2recon" if a.workload.startswith("frame2recon") else "frame2voxel"
-    step = PretrainStep(config_option=option, img_size=(H_NET, W_SENSOR), nr_events_data=NWIN, nr_temporal_bins=C,
-                        if_spatial_contrastive=contrastive, superpixel_size=100, device=device)
-    if world > 1:      # identical initial weights on every rank
-        broadcast_module_states(step.models_dict.values())
-    trainable = [p for m in step.models_dict.values() for p in m.parameters()]
-    reducer = GradAllReduce(trainable, world)
-    ev, frame, pl, sp, S = make_inputs(rank, device, a.workload)
-    voxels = torch.empty((B, NWIN * C, H_NET, W_SENSOR), dtype=torch.float32, device=device)
-
-    def one_step():
-        hip.voxelize_dsec_raw(ev["x"], ev["y"], ev["t"], ev["p"], ev["maps"], ev["seg_map"], ev["seg"], C, H_SENSOR,
-                              W_SENSOR, crop_rows=CROP, out=voxels.view(B * NWIN * C, H_NET, W_SENSOR))
-        first = frame if option == "frame2recon" else voxels
-        labels = pl if online_teacher is None else online_teacher(frame).argmax(dim=1)
-        batch = (first, None, frame, labels, sp, S)
-        for opt in step.optimizers_dict.values():
-            opt.zero_grad()
-        t_loss, losses, _ = step.task_train_step(batch)
-        t_loss.backward()
-        reducer()
-        for opt in step.optimizers_dict.values():
-            opt.step()
-        return t_loss
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        one_step()
-    hip.conv_timing_begin()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = one_step()
-    fence()
-    dt = time.perf_counter() - t0
-    conv_stats = hip.conv_timing_end()
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    inputs = make_inputs(rank, device)
+    wl = Workload(a.workload, rank, world, device, inputs)
+    if a.child:
+        wl.timed(a.steps, a.warmup)
+        return
+    dt, loss, conv_stats = wl.timed(a.steps, a.warmup, conv_timing=True)
     if rank == 0 and os.environ.get("OESS_CONV_BREAKDOWN") and conv_stats:
         for k, (n, tm, fl) in sorted(conv_stats["by_shape"].items(), key=lambda kv: -kv[1][1]):
             print(f"# conv HxWxCin->Cout k,s,d {k}: {n // a.steps:3d}/step {tm / a.steps:7.3f} ms/step {fl / tm / 1e9:7.1f} TF/s", file=sys.stderr)
+    extras = not a.no_extras
+    out = None
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = world * B * a.steps / dt
@@ -192,24 +432,63 @@ def main():
             ach = conv_stats["flops"] / (conv_stats["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "conv_fwd_dma_kernel<{128|64},128,2> + short-K conv_fwd_dma32_kernel<128,..,3> (implicit-GEMM bf16 MFMA, LDS-DMA; all fwd + dgrad launches with Cout > 64, incl. the fused ConvLSTM-epilogue variant: conv FLOPs only)",
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": _pmc_traffic(a.workload),
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                     "launches_per_step": conv_stats["launches"] // a.steps,
                     "avg_launch_us": round(conv_stats["ms"] * 1e3 / max(conv_stats["launches"], 1), 2),
+                    "algorithmic_gflop_per_launch": round(conv_stats["flops"] / max(conv_stats["launches"], 1) / 1e9, 2),
                     "share_of_step_time": round(conv_stats["ms"] / (dt * 1e3), 3)}
         out = {"metric": "event-frames/sec fwd+bwd @640x480 B=8", "value": round(value, 2), "unit": "event-frames/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-               "data": "synthetic", "loss": round(float(loss.detach()), 4),
+               "data": "synthetic", "loss": round(loss, 4),
                "config": {"workload": f"DSEC 640x480 5-bin x20 voxelizer + {a.workload} pre-train step "
                                       f"(E2VID-recurrent encoder x20, SemSegE2VID decoder, dilated-R50 teacher, Dice+CE), "
                                       f"batch {B}/GPU, random-init weights", "global_batch": world * B,
                           "parallelism": f"dp{world}"},
                "roofline": roof}
+    # ---- ingest-inclusive rate of the same workload (all ranks take part: the reducer is a collective)
+    if extras:
+        n_in = max(10, a.steps // 4)
+        dt_in = wl.timed_with_ingest(n_in, 2)
+        if rank == 0:
+            out["ingest"] = {"value": round(world * B * n_in / dt_in, 2), "unit": "event-frames/s", "ms_per_step": round(dt_in / n_in * 1e3, 3),
+                             "steps": n_in, "h2d_bytes_per_step": int(sum(v.numel() * v.element_size() for v in wl.host.values())),
+                             "note": "raw event columns start in PINNED HOST buffers every step; H2D + voxelizer of batch i+1 on a side "
+                                     "HIP stream under step i (north_star 'straight from pinned host event buffers'); never `value`"}
+        if world == 1:
+            out["stages"] = stage_rooflines(wl, rank, device)
+    # ---- the other single-GPU BASELINE configurations, same timing protocol
+    if extras and a.workload == "frame2voxel_pixel_distill":
+        del wl
+        torch.cuda.empty_cache()
+        cfgs = {}
+        for name in ("frame2voxel_full", "frame2recon_full"):
+            w2 = Workload(name, rank, world, device, inputs)
+            n2 = max(10, a.steps // 4)
+            dt2, loss2, _ = w2.timed(n2, 3)
+            cfgs[name] = {"value": round(world * B * n2 / dt2, 2), "unit": "event-frames/s", "ms_per_step": round(dt2 / n2 * 1e3, 3),
+                          "steps": n2, "loss": round(loss2, 4)}
+            del w2
+            torch.cuda.empty_cache()
+        if rank == 0:
+            cfgs["frame2voxel_full"]["what"] = "BASELINE configs[2]: configs[1] + superpixel scatter-mean + InfoNCE (differentiable teacher head)"
+            cfgs["frame2recon_full"]["what"] = "frame2recon pre-training: DeepLabv3/ASPP student + teacher + superpixel InfoNCE + Dice/CE"
+            out["configs"] = cfgs
+    if rank == 0:
+        if world == 1 and not a.no_pmc and out["roofline"] is not None:
+            torch.cuda.empty_cache()
+            tr, err = pmc_traffic()
+            if tr is not None:
+                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_detail"] = dict(tr, method="2 rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over a 1+1-step child "
+                                                                    "of this command, gfx950 read correction x2")
+            else:
+                out["roofline"]["traffic_error"] = err
         if not a.no_cpu_baseline and world == 1:
-            from tests import synth
-            sample = synth.dsec_raw_events(NWIN * N_PER, H_SENSOR, W_SENSOR, seed=1205)
+            from openess_amd.datasets import _synth
+            sample = _synth.dsec_raw_events(NWIN * N_PER, H_SENSOR, W_SENSOR, seed=1205)
             try:
-                out["cpu_baseline"] = cpu_baseline(sample, synth.rectify_map(H_SENSOR, W_SENSOR))
+                out["cpu_baseline"] = cpu_baseline(sample, _synth.rectify_map(H_SENSOR, W_SENSOR))
             except Exception as e:      # the baseline must never cost the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
