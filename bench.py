@@ -221,6 +221,7 @@ class Workload:
         labels = self.pl if self.online_teacher is None else self.online_teacher(self.frame).argmax(dim=1)
         for opt in self.step.optimizers_dict.values():
             opt.zero_grad()
+        self.reducer.prepare()
         t_loss, losses, _ = self.step.task_train_step((first, None, self.frame, labels, self.sp, self.S))
         t_loss.backward()
         self.reducer()

@@ -90,6 +90,7 @@ class _SupervisedTrainer(BaseTrainer):
     def train_step(self, batch):
         for opt in self.optimizers_dict.values():
             opt.zero_grad()
+        self.grad_reducer.prepare()          # N > 1: gradients accumulate straight into the all-reduce buckets
         t_loss, losses, outputs = self.task_train_step(batch)
         t_loss.backward()
         self.grad_reducer()

@@ -77,6 +77,7 @@ class OpenESSModel(BaseTrainer):
     def train_step(self, batch):
         for opt in self.optimizers_dict.values():
             opt.zero_grad()
+        self.grad_reducer.prepare()
         t_loss, losses, outputs = self.task_train_step(batch)
         t_loss.backward()
         self.grad_reducer()

@@ -36,6 +36,7 @@ class OpenESSPretrainModel(BaseTrainer):
     def train_step(self, batch):
         for opt in self.optimizers_dict.values():
             opt.zero_grad()
+        self.grad_reducer.prepare()          # N > 1: gradients accumulate straight into the all-reduce buckets
         t_loss, losses, outputs = self.task_train_step((batch[0], batch[1], batch[2], batch[3], batch[4], batch[-1]))
         t_loss.backward()
         self.grad_reducer()

@@ -285,3 +285,29 @@ class DeepLabV3(nn.Module):
         logits, feats = self.classifier(self.backbone(x))
         return (F.interpolate(logits, size=size, mode='bilinear', align_corners=False),
                 F.interpolate(feats, size=size, mode='bilinear', align_corners=False))
+
+
+# ------------------------------------------------------------------------------------------------
+# bf16-STORAGE emulation (test infrastructure).  The MI355X pipeline keeps fp32 master weights and fp32 accumulation but
+# STORES activations, activation gradients and the MFMA weight operand in bf16.  `emulate_bf16_storage(module)` gives the
+# fp32 oracle exactly those rounding points -- every conv / BatchNorm / residual-block output, every gradient flowing back
+# through them, and the conv weights -- and nothing else (arithmetic stays ATen fp32 on the CPU).  It is what separates
+# "rounding" from "bug": a random-weight train-mode-BatchNorm network amplifies bf16 storage noise (the common mode the next
+# BatchNorm removes carries most of the magnitude the rounding is relative to), and the HIP path has to track THIS oracle
+# closely, and the plain fp32 oracle only as closely as this one does.
+# ------------------------------------------------------------------------------------------------
+def _r16(x):
+    return x.bfloat16().float()
+
+
+def emulate_bf16_storage(module, weights=True, backward=True):
+    with torch.no_grad():
+        for m in module.modules():
+            if weights and isinstance(m, nn.Conv2d):
+                m.weight.copy_(_r16(m.weight))
+    for m in module.modules():
+        if isinstance(m, (nn.Conv2d, nn.BatchNorm2d, nn.InstanceNorm2d, Bottleneck, INSResBlock)):
+            m.register_forward_hook(lambda mod, i, o: _r16(o))
+            if backward:
+                m.register_full_backward_hook(lambda mod, gi, go: tuple(None if g is None else _r16(g) for g in gi))
+    return module

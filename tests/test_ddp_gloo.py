@@ -32,13 +32,29 @@ def _worker(rank, world, port, out):
     target = torch.randn(8, 2, 6, 6)
     idx = shard_indices(8, rank, world)
     opt = torch.optim.AdamW(list(net.parameters()) + list(unused.parameters()), lr=1e-2)
-    red = GradAllReduce(list(net.parameters()) + list(unused.parameters()), world, bucket_bytes=256)
+    red = GradAllReduce(list(net.parameters()) + list(unused.parameters()), world, bucket_bytes=64)
+    assert len(red.buckets) >= 2                          # 64-byte buckets: several messages, launched from the grad hooks
+    launched_in_backward = []
+    for it in range(2):
+        opt.zero_grad()
+        red.prepare()                                     # .grad -> views into the flat message buffers
+        loss = ((net(data[idx]) - target[idx]) ** 2).mean()
+        loss.backward()
+        launched_in_backward.append(sum(b.launched for b in red.buckets))
+        assert all(p.grad.untyped_storage().data_ptr() == red.buckets[red._where[id(p)][0]].flat.untyped_storage().data_ptr()
+                   for p in net.parameters())             # reduced in place: no cat / copy-back
+        red()
+        if it == 0:
+            opt.step()
+            w1 = [p.detach().clone() for p in net.parameters()]
+    # the un-prepared path (optimizer.zero_grad() only) must give the same averaged gradient
+    g_prepared = [p.grad.clone() for p in net.parameters()]
     opt.zero_grad()
     loss = ((net(data[idx]) - target[idx]) ** 2).mean()
     loss.backward()
     red()
-    opt.step()
-    out[rank] = {"w0": w0, "w1": [p.detach().clone() for p in net.parameters()], "idx": idx,
+    same = all(torch.allclose(a, p.grad, atol=1e-7) for a, p in zip(g_prepared, net.parameters()))
+    out[rank] = {"w0": w0, "w1": w1, "idx": idx, "launched_in_backward": launched_in_backward, "unprepared_same": same,
                  "unused_grad_none": all(p.grad is None for p in unused.parameters())}
     dist.destroy_process_group()
 
@@ -55,6 +71,8 @@ def test_two_rank_step_equals_single_process_step():
         assert torch.allclose(x, y, atol=1e-7)            # and they stay identical after the step
     assert sorted(a["idx"].tolist() + b["idx"].tolist()) == list(range(8))
     assert a["unused_grad_none"] and b["unused_grad_none"]
+    assert a["unprepared_same"] and b["unprepared_same"]
+    assert min(a["launched_in_backward"]) >= 1            # at least one bucket's all-reduce went out UNDER backward (overlap)
     # single-process reference on the union of the shards
     torch.manual_seed(100)
     net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(4, 2, 1))
