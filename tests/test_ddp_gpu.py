@@ -107,8 +107,8 @@ def test_two_rank_pretrain_step_on_one_gpu():
             assert n not in acc
             continue
         x, y = g.numpy().ravel().astype(np.float64), acc[n].numpy().ravel().astype(np.float64)
-        if np.linalg.norm(y) < 1e-12:
-            continue
+        if np.linalg.norm(y) < 1e-12 or n.endswith(("model.0.bias", "model.3.bias")):
+            continue          # conv bias in front of an affine-free InstanceNorm: the true gradient is 0 (rounding noise only)
         c = float(x @ y / (np.linalg.norm(x) * np.linalg.norm(y) + 1e-30))
         worst = min(worst, c)
         assert c > 0.999, (n, c)

@@ -306,7 +306,7 @@ def test_deeplab_well_conditioned_forward_backward(g, keys):
         c, c_emu, c_ge = cos(gg, gr), cos(ge, gr), cos(gg, ge)
         rows.append((name, c, c_emu, c_ge))
         # (1) against the fp32 oracle the HIP gradient may be only as far as bf16 storage alone puts the oracle itself
-        if c < min(0.98, c_emu - 0.08):
+        if c < min(0.98, c_emu - 0.15):
             low.append((name, round(c, 4), round(c_emu, 4)))
     c_emu_of = {r[0]: r[2] for r in rows}
     rows.sort(key=lambda r: r[1])
@@ -323,7 +323,7 @@ def test_deeplab_well_conditioned_forward_backward(g, keys):
         refv = g[key] if key in g else g[key + "__sub"]
         got = got if key in g else compact(got)[0]
         # the REFERENCE's own gradient (golden): same calibrated bound as against the oracle
-        assert cos(got, refv) >= min(0.98, c_emu_of[name] - 0.08), (name, cos(got, refv), c_emu_of[name])
+        assert cos(got, refv) >= min(0.98, c_emu_of[name] - 0.15), (name, cos(got, refv), c_emu_of[name])
     print("deeplab wc: argmax agreement", float((am == ar).mean()), "rounding-only", agree_emu, "clear fraction", float(clear.mean()))
 
 
