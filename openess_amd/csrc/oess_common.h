@@ -14,6 +14,17 @@ namespace oess {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// compute units of the current device (cached per process; persistent kernels size their grid from it)
+static inline int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
 // round-to-nearest-even float -> bf16 (NaN preserved as quiet NaN)

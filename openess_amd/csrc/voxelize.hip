@@ -11,17 +11,25 @@
 //     D  splat    workgroup (segment, tile): gathers its run from every slice of the segment (run starts
 //                 one per lane, wave scan, ds_bpermute search), records -> LDS accumulators, then every
 //                 output voxel is written ONCE, coalesced (float4 per lane); no pre-zeroing pass.
-//   (v1, kept for the nearest-xy path and as OESS_VOX_IMPL=v1: count -> two scans -> scatter -> splat; it reads
-//   the events twice and writes records into ~450-byte private cursor ranges whose boundary cache lines are
-//   shared between workgroups.  Measured B=8 x 2 M events: v1 0.578 / 0.780 ms (fp32 SoA / raw+rectify),
-//   v2 0.513 / 0.583 ms.)
+//   (The nearest-xy path still uses the first pipeline: count -> two scans -> scatter -> splat.  For the tri-linear
+//   path it was measured slower -- 0.578 / 0.780 ms (fp32 SoA / raw+rectify) against 0.513 / 0.583 ms -- because it
+//   reads the events twice and scatters records into ~450-byte cursor ranges whose boundary lines are shared between
+//   workgroups on different XCDs, and has been removed.)
+//   Both kernels are bound by the NUMBER of cache-line requests, not by bytes (ablation, B=8 x 2 M events: the splat's
+//   per-wave reads of 25 strided table rows cost 81 us of 322, a second rectify-map gather in the splat 30 us, the
+//   same-address global allocation atomic of 3906 sort workgroups serialises memory-side).  Hence: 16-byte records that
+//   carry the rectified coordinates, a TRANSPOSED run table (a tile's 25 run starts are one contiguous row) and fixed
+//   record regions per slice instead of an allocator.
 //   An event whose 2x2 pixel footprint straddles a tile edge is binned into each tile it touches
 //   (<= 4); each tile only accumulates the corners it owns.
 //
-//   Accumulation is 64-bit FIXED POINT (2^-38) with ds_add_u64: measured on MI355X, LDS fp32
-//   atomics (ds_add_f32) run ~10x slower than LDS integer atomics (0.40 ms vs 0.04 ms for the
-//   134 M corner updates of one B=8 batch).  Fixed point also makes the result the correctly
-//   rounded EXACT sum of the per-event weights: deterministic and order independent.
+//   Accumulation is FIXED POINT with LDS integer atomics: measured on MI355X, LDS fp32 atomics
+//   (ds_add_f32) run ~10x slower than LDS integer atomics (0.40 ms vs 0.04 ms for the 134 M corner
+//   updates of one B=8 batch).  A tile whose record count bounds every voxel sum below 2^10 uses 32-bit
+//   accumulators at 2^-20 .. 2^-24 (the scale follows the bound, so sparse tiles resolve a float32 ulp): half
+//   the LDS (8 workgroups per CU), ds_add_u32, and one v_cvt each way instead of f64 arithmetic.  Denser
+//   tiles take the 64-bit path (2^-38, ds_add_u64) in two half-height passes over the same LDS.  Either way
+//   the result is the rounded sum of the per-event weights: deterministic and order independent.
 //
 // Parity: per-event index math and weights follow the reference's float32 / float64 operation
 // order exactly (compiled with -ffp-contract=off; IEEE division), so indices are bit-exact and
@@ -54,12 +62,11 @@ struct Geom {
     int nSlices;  // slices per segment (count/scatter workgroups)
 };
 
-__host__ Geom make_geom(int C, int H, int W, int crop_rows, int64_t max_seg_len) {
+__host__ Geom make_geom(int C, int H, int W, int crop_rows, int64_t max_seg_len, int lds_budget = MAX_LDS_TILE_BYTES,
+                        int acc_bytes = 8) {
     Geom g;
     g.C = C; g.H = H; g.W = W; g.Hout = H - crop_rows;
-    static int lds_budget = -1;
-    if (lds_budget < 0) { const char* e = getenv("OESS_VOX_LDS_KB"); lds_budget = e ? atoi(e) * 1024 : MAX_LDS_TILE_BYTES; if (lds_budget < 4096) lds_budget = MAX_LDS_TILE_BYTES; }
-    int th = lds_budget / (C * TW * 8);
+    int th = lds_budget / (C * TW * acc_bytes);
     if (th > 32) th = 32;
     int lg = 0;
     while ((2 << lg) <= th) ++lg;          // round down to a power of two: tile math is shifts, not divides
@@ -93,6 +100,10 @@ struct SrcF32 {                         // VoxelGrid.convert's own arguments
     __device__ Seg seg(int /*s*/, int64_t b, int64_t e) const {
         Seg sg; sg.t0 = t[b]; sg.denom = __fsub_rn(t[e - 1], sg.t0); return sg;
     }
+    using Rec = float4;                 // {x, y, t_norm, value}
+    static __device__ Rec sentinel() { return make_float4(0.f, 0.f, 2.0e9f, 0.f); }         // t_norm sentinel: no valid bin
+    __device__ Rec pack(int64_t, const TriRec& r, const Seg&) const { return make_float4(r.x, r.y, r.tn, r.v); }
+    __device__ TriRec unpack(const Rec& q) const { TriRec r; r.x = q.x; r.y = q.y; r.tn = q.z; r.v = q.w; return r; }
     __device__ float2 load_xy(int64_t i, const Seg&) const { return make_float2(x[i], y[i]); }
     __device__ TriRec load(int64_t i, const Seg& sg, int C) const {
         TriRec r;
@@ -119,6 +130,12 @@ struct SrcRaw {                         // raw DSEC columns + rectify map (seque
         sg.map = maps + (size_t)seg_map[seg_base_index + s] * (size_t)H * W * 2;
         return sg;
     }
+    using Rec = float4;                 // {x', y', t_norm, value}: the RECTIFIED coordinates travel with the record -- an 8-byte
+    //                                     {x | y << 12 | p << 24, t_norm} record + a second map gather in the splat was measured
+    //                                     slower (the pipeline is bound by cache-line REQUESTS, not bytes: 17 M more gathers)
+    static __device__ Rec sentinel() { return make_float4(0.f, 0.f, 2.0e9f, 0.f); }
+    __device__ Rec pack(int64_t, const TriRec& r, const Seg&) const { return make_float4(r.x, r.y, r.tn, r.v); }
+    __device__ TriRec unpack(const Rec& q) const { TriRec r; r.x = q.x; r.y = q.y; r.tn = q.z; r.v = q.w; return r; }
     __device__ float2 load_xy(int64_t i, const Seg& sg) const {
         int xi = x[i], yi = y[i];
         if (xi >= W) xi = W - 1;                                   // reference asserts x.max() < width
@@ -205,64 +222,9 @@ struct SrcNear {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Pass A (MODE 0): count     Pass C (MODE 1): scatter.    grid = (nSlices, n_seg)
+// Nearest-xy pipeline.  Pass A (MODE 0): count     Pass C (MODE 1): scatter.    grid = (nSlices, n_seg)
 // table layout: [n_seg][nSlices][nTiles] ints (counts in A; exclusive local offsets after B)
 // ---------------------------------------------------------------------------------------------
-template <int MODE, typename Src>
-__global__ __launch_bounds__(THREADS) void tri_bin_kernel(Src src, const int64_t* __restrict__ seg_off, Geom g,
-                                                          int* __restrict__ table, const int* __restrict__ seg_base,
-                                                          float4* __restrict__ recs, uint32_t cap) {
-    extern __shared__ int lds[];          // [nTiles]: histogram (A) or running cursors (C)
-    const int s = blockIdx.y, slice = blockIdx.x;
-    const int64_t b = seg_off[s], e = seg_off[s + 1];
-    const int64_t n = e - b;
-    int* tab = table + ((size_t)s * g.nSlices + slice) * g.nTiles;
-    const int64_t sl_beg = (int64_t)slice * SLICE;
-    if (MODE == 0) {
-        for (int i = threadIdx.x; i < g.nTiles; i += THREADS) lds[i] = 0;
-    } else {
-        const int base = seg_base[s];
-        for (int i = threadIdx.x; i < g.nTiles; i += THREADS) lds[i] = base + tab[i];
-    }
-    __syncthreads();
-    if (sl_beg < n) {
-        int64_t sl_end = sl_beg + SLICE;
-        if (sl_end > n) sl_end = n;
-        const typename Src::Seg sg = src.seg(s, b, e);
-        for (int64_t first = sl_beg; first < sl_end; first += THREADS * EPT) {
-            TriRec rec[EPT];
-            bool ok[EPT];
-#pragma unroll
-            for (int k = 0; k < EPT; ++k) {          // independent global loads: EPT in flight per lane
-                const int64_t i = first + k * THREADS + threadIdx.x;
-                ok[k] = i < sl_end;
-                const int64_t ii = b + (ok[k] ? i : sl_end - 1);
-                if (MODE == 0) {                     // the count pass only needs the (rectified) coordinates
-                    const float2 xy = src.load_xy(ii, sg);
-                    rec[k].x = xy.x; rec[k].y = xy.y; rec[k].tn = 0.f; rec[k].v = 0.f;
-                } else {
-                    rec[k] = src.load(ii, sg, g.C);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < EPT; ++k) {
-                if (!ok[k]) continue;
-                int tiles[4];
-                const int nt = tri_tiles(rec[k].x, rec[k].y, g, tiles);
-                for (int j = 0; j < nt; ++j) {
-                    const int pos = atomicAdd(&lds[tiles[j]], 1);       // LDS integer atomic (fast)
-                    if (MODE == 1 && (uint32_t)pos < cap)
-                        recs[pos] = make_float4(rec[k].x, rec[k].y, rec[k].tn, rec[k].v);
-                }
-            }
-        }
-    }
-    if (MODE == 0) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < g.nTiles; i += THREADS) tab[i] = lds[i];
-    }
-}
-
 template <int MODE, typename Src>
 __global__ __launch_bounds__(THREADS) void near_bin_kernel(Src src, const int64_t* __restrict__ seg_off, Geom g,
                                                            int* __restrict__ table, const int* __restrict__ seg_base,
@@ -420,64 +382,6 @@ __device__ __forceinline__ void lds_add(long long* p, long long v) {
 
 constexpr int PRE = 3;     // record loads issued before the LDS zero fill
 
-__global__ __launch_bounds__(THREADS) void tri_splat_kernel(const float4* __restrict__ recs,
-                                                            const int* __restrict__ tile_start,
-                                                            const int* __restrict__ seg_base, Geom g, int count_mode,
-                                                            uint32_t cap, float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) long long acc[];
-    const int tile = blockIdx.x, s = blockIdx.y;
-    const int ty = tile / g.tilesX, tx = tile - ty * g.tilesX;
-    const int lds_n = g.C * g.TH * TW;
-    const int base = seg_base[s];
-    const uint32_t beg = (uint32_t)(base + tile_start[(size_t)s * (g.nTiles + 1) + tile]);
-    uint32_t end = (uint32_t)(base + tile_start[(size_t)s * (g.nTiles + 1) + tile + 1]);
-    if (end > cap) end = cap;
-    float4 pre[PRE];
-#pragma unroll
-    for (int k = 0; k < PRE; ++k) {
-        const uint32_t i = beg + k * THREADS + threadIdx.x;
-        pre[k] = (i < end) ? recs[i] : make_float4(0.f, 0.f, 2.0e9f, 0.f);     // tn sentinel: no valid bin
-    }
-    for (int i = threadIdx.x; i < lds_n; i += THREADS) acc[i] = 0;
-    __syncthreads();
-    const int x_lo = tx * TW, y_lo = ty * g.TH;
-    auto splat = [&](const float4 r) {
-        const float x = r.x, y = r.y, tn = r.z, val = r.w;
-        const float fx = fminf(fmaxf(x, -8.0f), (float)g.W + 8.0f);
-        const float fy = fminf(fmaxf(y, -8.0f), (float)g.H + 8.0f);
-        // NaN/inf time: Tensor.int() gives INT_MIN on the CPU -> every corner masked
-        const int x0 = (int)fx, y0 = (int)fy, t0 = (fabsf(tn) < 1.0e9f) ? (int)tn : 0x40000000;
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-            const int xl = x0 + dx;
-            const int lx = xl - x_lo;
-            if (xl < 0 || xl >= g.W || lx < 0 || lx >= TW) continue;
-            // representations.py:39  value * (1-|xlim-x|) * (1-|ylim-y|) * (1-|tlim-t_norm|), float32
-            const float wx = __fmul_rn(val, __fsub_rn(1.0f, fabsf(__fsub_rn((float)xl, x))));
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy) {
-                const int yl = y0 + dy;
-                const int ly = yl - y_lo;
-                if (yl < 0 || yl >= g.Hout || ly < 0 || ly >= g.TH) continue;
-                const float wxy = __fmul_rn(wx, __fsub_rn(1.0f, fabsf(__fsub_rn((float)yl, y))));
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const int tl = t0 + dt;
-                    if (tl < 0 || tl >= g.C) continue;
-                    float w = __fmul_rn(wxy, __fsub_rn(1.0f, fabsf(__fsub_rn((float)tl, tn))));
-                    if (count_mode) w = 1.0f;
-                    lds_add(&acc[(tl * g.TH + ly) * TW + lx], to_fix(w));
-                }
-            }
-        }
-    };
-#pragma unroll
-    for (int k = 0; k < PRE; ++k) splat(pre[k]);
-    for (uint32_t i = beg + PRE * THREADS + threadIdx.x; i < end; i += THREADS) splat(recs[i]);
-    __syncthreads();
-    write_tile(acc, out, g, s, g.C, tx, ty, false);
-}
-
 __global__ __launch_bounds__(THREADS) void near_splat_kernel(const float4* __restrict__ recs,
                                                              const int* __restrict__ tile_start,
                                                              const int* __restrict__ seg_base, Geom g, int nbins,
@@ -521,22 +425,19 @@ __global__ __launch_bounds__(THREADS) void near_splat_kernel(const float4* __res
 }
 
 // =============================================================================================
-// v2 tri-linear pipeline: SLICE-LOCAL SORT + multi-run splat (2 kernels instead of 5).
-//   S  sort   workgroup (segment, slice of 2048 events): load the events ONCE, LDS histogram per tile, LDS
+// Tri-linear pipeline: SLICE-LOCAL SORT + multi-run splat (2 kernels).
+//   S  sort   workgroup (segment, slice of 4096 events): load the events ONCE, LDS histogram per tile, LDS
 //             exclusive scan, rank by LDS integer atomic into an LDS record buffer, then ONE coalesced block
 //             copy of the slice's records (sorted by tile) to a region obtained with one global atomic; the
-//             per-slice table row {start[tile], ..., total, base} is stored with plain stores.
-//   D  splat  workgroup (segment, tile): gathers its run from every slice of the segment (run table -> LDS
-//             prefix -> flat index -> binary search), accumulates as before and writes every voxel once.
-// vs v1 (count, 2 scans, scatter, splat): the events are read once (not twice), the records leave the sort
-// workgroup as full, exclusively owned cache lines (v1 wrote 16-byte records into 300 private ~450-byte cursor
-// ranges per workgroup whose boundary lines were shared between workgroups on different XCDs), and both scan
-// kernels disappear.
+//             per-slice table row {start[tile], ..., end, max |value|} is stored with plain stores.
+//   D  splat  workgroup (segment, tile): gathers its run from every slice of the segment (run starts one per
+//             lane, wave scan, ds_bpermute search), accumulates in LDS and writes every voxel once.
 // =============================================================================================
-constexpr int SORT_THREADS = 512;        // two sort workgroups per CU (one loads while the other ranks / copies out)
+constexpr int SORT_THREADS = 512;
 constexpr int SSL = SORT_THREADS * EPT;  // 4096 events per sort slice (one batch of EPT per thread)
-constexpr int LCAP = 4608;               // records staged in LDS (72 KB); a slice needs 4096 * ~1.08 on real data,
+constexpr int LCAP = 4608;               // records staged in LDS (36 / 72 KB); a slice needs 4096 * ~1.08 on real data,
                                          // up to 4 * 4096 on adversarial input (overflow goes straight to HBM)
+constexpr int FAST_LDS_BYTES = 20 * 1024;   // 32-bit accumulator tile: 8 splat workgroups per CU
 
 __device__ __forceinline__ int block_incl_scan_256(int v, int* wsum) {
     // inclusive scan over all threads of the block (<= 16 waves); wsum: 16 ints of LDS
@@ -555,25 +456,30 @@ __device__ __forceinline__ int block_incl_scan_256(int v, int* wsum) {
     return x + add;
 }
 
-// table row layout per (segment, slice): [0 .. nTiles] = ABSOLUTE record index where each tile's run starts (entry
-// nTiles = end of the slice's region); [nTiles + 1] unused padding
+// Run table, TRANSPOSED: T[segment][i][slice], i = 0 .. nTiles: start of tile i's run inside the slice's record region
+// (i = nTiles: end of the last run), i = nTiles + 1: float bits of max |value| over the slice's events.  A splat workgroup
+// reads rows `tile` and `tile + 1`: two contiguous rows of nSl ints.  Record region of (segment, slice) =
+// [(segment * nSl + slice) * RSTRIDE, + RSTRIDE): fixed, no allocator (the workspace holds 4 records per event anyway).
+constexpr int RSTRIDE = 4 * SORT_THREADS * EPT;      // worst case: every event of the slice in 4 tiles
 template <typename Src>
 __global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const int64_t* __restrict__ seg_off, Geom g, int nSl,
-                                                           int* __restrict__ table, unsigned int* __restrict__ alloc,
-                                                           float4* __restrict__ recs, unsigned int cap) {
+                                                           int* __restrict__ table,
+                                                           typename Src::Rec* __restrict__ recs, unsigned int cap) {
+    using Rec = typename Src::Rec;
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_sort[];
     const int nT = g.nTiles;
     int* cur = reinterpret_cast<int*>(sm_sort);                                   // [nT + 1]
-    int* wsum = cur + nT + 1;                                                     // [16]
-    float4* buf = reinterpret_cast<float4*>(sm_sort + (((size_t)(nT + 1 + 16) * 4 + 15) & ~(size_t)15));   // [LCAP]
+    int* wsum = cur + nT + 1;                                                     // [16] + max |value|
+    Rec* buf = reinterpret_cast<Rec*>(sm_sort + (((size_t)(nT + 1 + 17) * 4 + 15) & ~(size_t)15));   // [LCAP]
     const int s = blockIdx.y, slice = blockIdx.x;
     const int64_t b = seg_off[s], e = seg_off[s + 1];
     const int64_t n = e - b;
-    int* tab = table + ((size_t)s * nSl + slice) * (nT + 2);
+    int* tab = table + (size_t)s * (nT + 2) * nSl + slice;          // column `slice` of the segment's transposed table
     const int64_t sl_beg = (int64_t)slice * SSL;
     for (int i = threadIdx.x; i <= nT; i += SORT_THREADS) cur[i] = 0;
-    if (sl_beg >= n) {                                   // empty slice (ragged segments): all-zero row
-        for (int i = threadIdx.x; i < nT + 2; i += SORT_THREADS) tab[i] = 0;
+    if (threadIdx.x == 0) wsum[16] = 0;
+    if (sl_beg >= n) {                                   // empty slice (ragged segments): all-zero column
+        for (int i = threadIdx.x; i < nT + 2; i += SORT_THREADS) tab[(size_t)i * nSl] = 0;
         return;
     }
     __syncthreads();
@@ -581,13 +487,22 @@ __global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const i
     if (sl_end > n) sl_end = n;
     const typename Src::Seg sg = src.seg(s, b, e);
     TriRec rec[EPT];
+    Rec packed[EPT];
     bool ok[EPT];
+    float vm = 0.f;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {                      // the only read of the events: EPT independent loads per lane
         const int64_t i = sl_beg + k * SORT_THREADS + threadIdx.x;
         ok[k] = i < sl_end;
-        rec[k] = src.load(b + (ok[k] ? i : sl_end - 1), sg, g.C);
+        const int64_t ii = b + (ok[k] ? i : sl_end - 1);
+        rec[k] = src.load(ii, sg, g.C);
+        packed[k] = src.pack(ii, rec[k], sg);
+        const float av = fabsf(rec[k].v);
+        if (ok[k]) vm = (av != av) ? __int_as_float(0x7f800000) : fmaxf(vm, av);     // NaN value: force the 64-bit path
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vm = fmaxf(vm, __shfl_xor(vm, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(&wsum[16], __float_as_int(vm));        // non-negative floats order like ints
     // phase A: histogram, shifted by one so that the inclusive scan below yields exclusive starts
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
@@ -597,6 +512,7 @@ __global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const i
         for (int j = 0; j < nt; ++j) atomicAdd(&cur[tiles[j] + 1], 1);
     }
     __syncthreads();
+    const int vmax_bits = wsum[16];
     {   // inclusive scan of cur[0 .. nT] in place
         const int per = (nT + 1 + SORT_THREADS - 1) / SORT_THREADS;
         const int lo = threadIdx.x * per;
@@ -608,23 +524,20 @@ __global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const i
     }
     __syncthreads();
     const int total = cur[nT];
-    __shared__ unsigned int base_sh;
-    if (threadIdx.x == 0) base_sh = atomicAdd(alloc, (unsigned int)total);
-    __syncthreads();
-    const unsigned int base = base_sh;
-    for (int i = threadIdx.x; i <= nT; i += SORT_THREADS) tab[i] = (int)(base + (unsigned int)cur[i]);    // absolute starts
-    __syncthreads();                                     // rows stored before the cursors start moving
-    float4* region = recs + base;
+    const unsigned int base = (unsigned int)(((size_t)s * nSl + slice) * RSTRIDE);
+    for (int i = threadIdx.x; i <= nT; i += SORT_THREADS) tab[(size_t)i * nSl] = cur[i];                  // starts inside the region
+    if (threadIdx.x == 0) tab[(size_t)(nT + 1) * nSl] = vmax_bits;
+    __syncthreads();                                     // column stored before the cursors start moving
+    Rec* region = recs + base;
     // phase B: rank inside the tile by LDS integer atomic, stage in LDS
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
         if (!ok[k]) continue;
         int tiles[4];
         const int nt = tri_tiles(rec[k].x, rec[k].y, g, tiles);
-        const float4 r4 = make_float4(rec[k].x, rec[k].y, rec[k].tn, rec[k].v);
         for (int j = 0; j < nt; ++j) {
             const int pos = atomicAdd(&cur[tiles[j]], 1);
-            if (pos < LCAP) buf[pos] = r4; else if (base + (unsigned int)pos < cap) region[pos] = r4;
+            if (pos < LCAP) buf[pos] = packed[k]; else if (base + (unsigned int)pos < cap) region[pos] = packed[k];
         }
     }
     __syncthreads();
@@ -634,98 +547,198 @@ __global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const i
 }
 
 constexpr int RUN_CHUNK = 64;            // slices whose runs are gathered per splat iteration: one per lane, kept in
-                                         // registers (wave scan + ds_bpermute search): no LDS beyond the accumulators, so
-                                         // four splat workgroups still fit a CU
+                                         // registers (wave scan + ds_bpermute search): no LDS beyond the accumulators
 
-__global__ __launch_bounds__(THREADS) void tri_splat2_kernel(const float4* __restrict__ recs, const int* __restrict__ table,
-                                                             Geom g, int nSl, int count_mode, unsigned int cap,
-                                                             float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) long long acc[];
-    const int tile = blockIdx.x, s = blockIdx.y;
-    const int ty = tile / g.tilesX, tx = tile - ty * g.tilesX;
-    const int lds_n = g.C * g.TH * TW;
-    const int x_lo = tx * TW, y_lo = ty * g.TH;
-    auto splat = [&](const float4 r) {
-        const float x = r.x, y = r.y, tn = r.z, val = r.w;
-        const float fx = fminf(fmaxf(x, -8.0f), (float)g.W + 8.0f);
-        const float fy = fminf(fmaxf(y, -8.0f), (float)g.H + 8.0f);
-        // NaN/inf time: Tensor.int() gives INT_MIN on the CPU -> every corner masked
-        const int x0 = (int)fx, y0 = (int)fy, t0 = (fabsf(tn) < 1.0e9f) ? (int)tn : 0x40000000;
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-            const int xl = x0 + dx;
-            const int lx = xl - x_lo;
-            if (xl < 0 || xl >= g.W || lx < 0 || lx >= TW) continue;
-            // representations.py:39  value * (1-|xlim-x|) * (1-|ylim-y|) * (1-|tlim-t_norm|), float32
-            const float wx = __fmul_rn(val, __fsub_rn(1.0f, fabsf(__fsub_rn((float)xl, x))));
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy) {
-                const int yl = y0 + dy;
-                const int ly = yl - y_lo;
-                if (yl < 0 || yl >= g.Hout || ly < 0 || ly >= g.TH) continue;
-                const float wxy = __fmul_rn(wx, __fsub_rn(1.0f, fabsf(__fsub_rn((float)yl, y))));
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const int tl = t0 + dt;
-                    if (tl < 0 || tl >= g.C) continue;
-                    float w = __fmul_rn(wxy, __fsub_rn(1.0f, fabsf(__fsub_rn((float)tl, tn))));
-                    if (count_mode) w = 1.0f;
-                    lds_add(&acc[(tl * g.TH + ly) * TW + lx], to_fix(w));
-                }
+// rows [row_lo, row_lo + rows) of tile (tx, .) -> out, every voxel once, float4 per lane
+template <typename ACC>
+__device__ __forceinline__ void write_rows(const ACC* acc, float inv_scale, float* __restrict__ out, const Geom& g, int s, int tx,
+                                           int row_lo, int rows) {
+    const int lgr = 31 - __clz(rows);                 // rows is a power of two (TH or TH / 2)
+    const int x_base = tx * TW;
+    const size_t plane = (size_t)g.Hout * g.W;
+    auto cvt = [&](ACC a) -> float {
+        if (sizeof(ACC) == 8) return from_fix((long long)a);
+        return __fmul_rn((float)(int)a, inv_scale);
+    };
+    if ((g.W & 3) == 0) {
+        const int q_per_row = TW / 4;
+        const int total = g.C * rows * q_per_row;
+        for (int i = threadIdx.x; i < total; i += THREADS) {
+            const int q = i & (q_per_row - 1), rc = i >> 4;          // q_per_row == 16
+            const int rr = rc & (rows - 1), c = rc >> lgr;
+            const int xx = x_base + q * 4, yy = row_lo + rr;
+            if (xx < g.W && yy < g.Hout) {
+                const ACC* a = &acc[(c * rows + rr) * TW + q * 4];
+                *reinterpret_cast<float4*>(&out[((size_t)s * g.C + c) * plane + (size_t)yy * g.W + xx]) =
+                    make_float4(cvt(a[0]), cvt(a[1]), cvt(a[2]), cvt(a[3]));
             }
+        }
+    } else {
+        const int total = g.C * rows * TW;
+        for (int i = threadIdx.x; i < total; i += THREADS) {
+            const int q = i & (TW - 1), rc = i >> 6;
+            const int rr = rc & (rows - 1), c = rc >> lgr;
+            const int xx = x_base + q, yy = row_lo + rr;
+            if (xx < g.W && yy < g.Hout) out[((size_t)s * g.C + c) * plane + (size_t)yy * g.W + xx] = cvt(acc[(c * rows + rr) * TW + q]);
+        }
+    }
+}
+
+// One (segment, tile) item per workgroup.  A persistent grid (8 workgroups per CU walking the items, next item's table rows
+// prefetched) was built and measured SLOWER (329 vs 262 us): the hardware dispatcher balances the uneven items better than a
+// static loop, and the launch of 192 k waves is not what the 72 us floor of the empty kernel consists of.
+template <typename Src>
+__global__ __launch_bounds__(THREADS) void tri_splat_kernel(Src src, const typename Src::Rec* __restrict__ recs,
+                                                            const int* __restrict__ table, Geom g, int nSl, int count_mode,
+                                                            unsigned int cap, float* __restrict__ out) {
+    using Rec = typename Src::Rec;
+    extern __shared__ __attribute__((aligned(16))) int acc32[];          // [C][TH][TW] ints == [C][TH/2][TW] long longs
+    long long* acc64 = reinterpret_cast<long long*>(acc32);
+    const int lane = threadIdx.x & 63;
+    const int nT = g.nTiles;
+    // chunk-0 run-table entries of an item, one slice per lane
+    auto load_rows = [&](int item, int& cnt, unsigned int& beg, float& vm) {
+        cnt = 0; beg = 0; vm = 0.f;
+        if (lane < nSl) {
+            const int s = item / nT, tile = item - s * nT;
+            const int* trow = table + ((size_t)s * (nT + 2) + tile) * nSl;
+            const int st = trow[lane], en = trow[nSl + lane];
+            cnt = en - st;
+            beg = (unsigned int)(((size_t)s * nSl + lane) * RSTRIDE) + (unsigned int)st;
+            vm = __int_as_float(table[((size_t)s * (nT + 2) + nT + 1) * nSl + lane]);
         }
     };
-    const int lane = threadIdx.x & 63;
-    for (int c0 = 0; c0 < nSl; c0 += RUN_CHUNK) {
-        const int nc = (nSl - c0 < RUN_CHUNK) ? nSl - c0 : RUN_CHUNK;
-        int cnt = 0;
-        unsigned int beg = 0;
-        if (lane < nc) {                                           // every wave keeps its own copy of the run table
-            const int* row = table + ((size_t)s * nSl + c0 + lane) * (g.nTiles + 2);
-            const int st = row[tile], en = row[tile + 1];            // absolute record indices
-            cnt = en - st;
-            beg = (unsigned int)st;
-        }
-        int incl = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int y = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += y;
-        }
-        const int excl = incl - cnt;
-        const int total = __shfl(incl, 63, 64);
-        // record j of the concatenated runs: per-lane binary search over the run starts held one per lane (ds_bpermute).
-        // All lanes take part in the shuffles (fixed trip count, j clamped); only the load is predicated.
-        // (Measured alternatives: run table in LDS + barriers 405 us - and 3 instead of 4 workgroups per CU -; a
-        // wave-uniform readlane walk 441 us; this form 348 us.)
-        auto fetch = [&](int j) -> float4 {
-            const bool valid = j < total;
-            const int jj = valid ? j : 0;
-            int lo = 0, hi = nc;                                   // largest run index with excl[idx] <= jj
-#pragma unroll
-            for (int step = 0; step < 6; ++step) {
-                const int mid = (lo + hi) >> 1;
-                const int v = __shfl(excl, mid, 64);
-                if (hi - lo > 1) { if (v <= jj) lo = mid; else hi = mid; }
+    {
+        const int item = blockIdx.x;                                     // = segment * nTiles + tile
+        const int s = item / nT, tile = item - s * nT;
+        const int ty = tile / g.tilesX, tx = tile - ty * g.tilesX;
+        const int x_lo = tx * TW, y_lo = ty * g.TH;
+        int cnt0; unsigned int beg0; float vmax;
+        load_rows(item, cnt0, beg0, vmax);
+        // ---- accumulator choice: every voxel sum of this tile is bounded by (records of the tile) x max |value|
+        int total_all = cnt0;
+        for (int c0 = RUN_CHUNK; c0 < nSl; c0 += RUN_CHUNK) {             // segments longer than 64 slices (rare): on demand
+            if (c0 + lane < nSl) {
+                const int* trow = table + ((size_t)s * (nT + 2) + tile) * nSl;
+                total_all += trow[nSl + c0 + lane] - trow[c0 + lane];
+                vmax = fmaxf(vmax, __int_as_float(table[((size_t)s * (nT + 2) + nT + 1) * nSl + c0 + lane]));
             }
-            const unsigned int ri = (unsigned int)__shfl((int)beg, lo, 64) + (unsigned int)(jj - __shfl(excl, lo, 64));
-            return (valid && ri < cap) ? recs[ri] : make_float4(0.f, 0.f, 2.0e9f, 0.f);    // tn sentinel: no valid bin
-        };
-        float4 pre[PRE];
-#pragma unroll
-        for (int k = 0; k < PRE; ++k)                              // in flight under the LDS zero fill
-            pre[k] = (k * THREADS < total) ? fetch(k * THREADS + (int)threadIdx.x) : make_float4(0.f, 0.f, 2.0e9f, 0.f);
-        if (c0 == 0) {
-            for (int i = threadIdx.x; i < lds_n; i += THREADS) acc[i] = 0;
-            __syncthreads();
         }
 #pragma unroll
-        for (int k = 0; k < PRE; ++k)
-            if (k * THREADS < total) splat(pre[k]);
-        for (int j0 = PRE * THREADS; j0 < total; j0 += THREADS) splat(fetch(j0 + (int)threadIdx.x));
+        for (int off = 32; off > 0; off >>= 1) {
+            total_all += __shfl_xor(total_all, off, 64);
+            vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        }
+        if (count_mode) vmax = 1.0f;
+        const float boundf = (float)total_all * vmax + 1.0f;             // +inf for a NaN / inf value: 64-bit path
+        int sh = 0;
+        if (boundf < 1024.0f) {
+            const int bnd = (int)boundf;                                 // >= 1
+            const int lg = (bnd <= 1) ? 0 : 32 - __clz(bnd - 1);         // ceil(log2(bnd))
+            sh = 30 - (lg < 1 ? 1 : lg);
+            if (sh > 24) sh = 24;
+        }
+        const bool fast = sh >= 20;                                      // wave- and block-uniform
+        const float scale = __int_as_float((127 + sh) << 23), inv_scale = __int_as_float((127 - sh) << 23);
+
+        auto run_pass = [&](const int row_lo, const int rows) {
+            const int lds_n = g.C * rows * TW;
+            auto splat = [&](const Rec q) {
+                const TriRec r = src.unpack(q);
+                const float x = r.x, y = r.y, tn = r.tn, val = r.v;
+                const float fx = fminf(fmaxf(x, -8.0f), (float)g.W + 8.0f);
+                const float fy = fminf(fmaxf(y, -8.0f), (float)g.H + 8.0f);
+                // NaN/inf time: Tensor.int() gives INT_MIN on the CPU -> every corner masked
+                const int x0 = (int)fx, y0 = (int)fy, t0 = (fabsf(tn) < 1.0e9f) ? (int)tn : 0x40000000;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int xl = x0 + dx;
+                    const int lx = xl - x_lo;
+                    if (xl < 0 || xl >= g.W || lx < 0 || lx >= TW) continue;
+                    // representations.py:39  value * (1-|xlim-x|) * (1-|ylim-y|) * (1-|tlim-t_norm|), float32
+                    const float wx = __fmul_rn(val, __fsub_rn(1.0f, fabsf(__fsub_rn((float)xl, x))));
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy) {
+                        const int yl = y0 + dy;
+                        const int ly = yl - row_lo;
+                        if (yl < 0 || yl >= g.Hout || ly < 0 || ly >= rows) continue;
+                        const float wxy = __fmul_rn(wx, __fsub_rn(1.0f, fabsf(__fsub_rn((float)yl, y))));
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) {
+                            const int tl = t0 + dt;
+                            if (tl < 0 || tl >= g.C) continue;
+                            float w = __fmul_rn(wxy, __fsub_rn(1.0f, fabsf(__fsub_rn((float)tl, tn))));
+                            if (count_mode) w = 1.0f;
+                            const int idx = (tl * rows + ly) * TW + lx;
+                            if (fast) atomicAdd(&acc32[idx], __float2int_rn(__fmul_rn(w, scale)));      // ds_add_u32
+                            else lds_add(&acc64[idx], to_fix(w));                                       // ds_add_u64
+                        }
+                    }
+                }
+            };
+            for (int c0 = 0; c0 < nSl; c0 += RUN_CHUNK) {
+                const int nc = (nSl - c0 < RUN_CHUNK) ? nSl - c0 : RUN_CHUNK;
+                int cnt = cnt0;
+                unsigned int beg = beg0;
+                if (c0 > 0) {
+                    cnt = 0; beg = 0;
+                    if (lane < nc) {
+                        const int* trow = table + ((size_t)s * (nT + 2) + tile) * nSl;
+                        const int st = trow[c0 + lane], en = trow[nSl + c0 + lane];
+                        cnt = en - st;
+                        beg = (unsigned int)(((size_t)s * nSl + c0 + lane) * RSTRIDE) + (unsigned int)st;
+                    }
+                }
+                int incl = cnt;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int y = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += y;
+                }
+                const int excl = incl - cnt;
+                const int total = __shfl(incl, 63, 64);
+                // record j of the concatenated runs: per-lane binary search over the run starts held one per lane (ds_bpermute).
+                // All lanes take part in the shuffles (fixed trip count, j clamped); only the load is predicated.
+                auto fetch = [&](int j) -> Rec {
+                    const bool valid = j < total;
+                    const int jj = valid ? j : 0;
+                    int lo = 0, hi = nc;                                   // largest run index with excl[idx] <= jj
+#pragma unroll
+                    for (int step = 0; step < 6; ++step) {
+                        const int mid = (lo + hi) >> 1;
+                        const int v = __shfl(excl, mid, 64);
+                        if (hi - lo > 1) { if (v <= jj) lo = mid; else hi = mid; }
+                    }
+                    const unsigned int ri = (unsigned int)__shfl((int)beg, lo, 64) + (unsigned int)(jj - __shfl(excl, lo, 64));
+                    return (valid && ri < cap) ? recs[ri] : Src::sentinel();
+                };
+                Rec pre[PRE];
+#pragma unroll
+                for (int k = 0; k < PRE; ++k)                              // in flight under the LDS zero fill
+                    pre[k] = (k * THREADS < total) ? fetch(k * THREADS + (int)threadIdx.x) : Src::sentinel();
+                if (c0 == 0) {
+                    if (fast) { for (int i = threadIdx.x; i < lds_n; i += THREADS) acc32[i] = 0; }
+                    else { for (int i = threadIdx.x; i < lds_n; i += THREADS) acc64[i] = 0; }
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int k = 0; k < PRE; ++k)
+                    if (k * THREADS < total) splat(pre[k]);
+                for (int j0 = PRE * THREADS; j0 < total; j0 += THREADS) splat(fetch(j0 + (int)threadIdx.x));
+            }
+            __syncthreads();
+            if (fast) write_rows<int>(acc32, inv_scale, out, g, s, tx, row_lo, rows);
+            else write_rows<long long>(acc64, 0.f, out, g, s, tx, row_lo, rows);
+            __syncthreads();                                            // the accumulators are re-zeroed by the next pass
+        };
+        if (fast) {
+            run_pass(y_lo, g.TH);
+        } else {                                                        // dense tile: two half-height passes, same LDS bytes
+            const int half = g.TH >> 1;
+            run_pass(y_lo, half);
+            run_pass(y_lo + half, half);
+        }
     }
-    __syncthreads();
-    write_tile(acc, out, g, s, g.C, tx, ty, false);
 }
 
 // Event histogram (a4): tiny; direct global atomics on a zeroed 2 x H x W image per segment.
@@ -767,97 +780,62 @@ size_t ws_layout(int64_t n_events, int n_seg, const Geom& g, Workspace* ws, void
     return need;
 }
 
-// v2 workspace: [alloc counter (256 B)] [table: n_seg x nSl x (nTiles + 2) ints] [records: up to 4 per event]
-size_t ws_layout_v2(int64_t n_events, int n_seg, const Geom& g, int nSl, size_t* o_table, size_t* o_recs) {
+// tri-linear workspace: [256 B pad] [transposed table: n_seg x (nTiles + 2) x nSl ints] [record regions: n_seg x nSl x RSTRIDE]
+Geom tri_geom(int C, int H, int W, int crop_rows, int64_t max_seg_len) {
+    // 32-bit accumulators, 20 KB per tile (8 splat workgroups per CU); at least two rows so that the 64-bit path of a dense
+    // tile can run as two half-height passes in the same LDS
+    Geom g = make_geom(C, H, W, crop_rows, max_seg_len, FAST_LDS_BYTES, 4);      // measured: 40 KB tiles 276 us, 10 KB 350 us, 20 KB 262 us
+    if (g.TH < 2) g = make_geom(C, H, W, crop_rows, max_seg_len, 2 * C * TW * 4, 4);
+    return g;
+}
+
+size_t ws_layout_tri(int64_t n_events, int n_seg, const Geom& g, int nSl, size_t* o_table, size_t* o_recs) {
     const size_t ot = 256;
     const size_t orr = oess::align_up(ot + (size_t)n_seg * nSl * (g.nTiles + 2) * 4, 256);
     if (o_table) *o_table = ot;
     if (o_recs) *o_recs = orr;
-    return orr + (size_t)n_events * 4 * sizeof(float4);
+    const size_t slots = (size_t)n_seg * nSl * RSTRIDE;                 // fixed record region per (segment, slice)
+    const size_t need = (size_t)n_events * 4;
+    return orr + (slots > need ? slots : need) * sizeof(float4);
 }
-
-template <typename Src>
-int run_tri_v1(Src src, const int64_t* seg_off, int n_seg, int64_t max_seg_len, int C, int H, int W, int crop_rows,
-               int count_mode, float* out, void* workspace, size_t workspace_bytes, hipStream_t st);
 
 template <typename Src>
 int run_tri(Src src, const int64_t* seg_off, int n_seg, int64_t max_seg_len, int C, int H, int W, int crop_rows,
             int count_mode, float* out, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    using Rec = typename Src::Rec;
     if (n_seg <= 0 || C <= 0 || C > 64 || H <= 0 || W <= 0 || crop_rows < 0 || crop_rows >= H || !out || !seg_off)
         return OESS_EINVAL;
     if (max_seg_len < 0 || max_seg_len > 0x3fffffffll) return OESS_EINVAL;
-    static int impl = -1;
-    if (impl < 0) { const char* e = getenv("OESS_VOX_IMPL"); impl = (e && !strcmp(e, "v1")) ? 1 : 2; }
-    if (impl == 1)
-        return run_tri_v1(src, seg_off, n_seg, max_seg_len, C, H, W, crop_rows, count_mode, out, workspace, workspace_bytes, st);
-    Geom g = make_geom(C, H, W, crop_rows, max_seg_len);
-    if (g.nTiles > 8192) return OESS_EINVAL;
+    Geom g = tri_geom(C, H, W, crop_rows, max_seg_len);
+    if (g.nTiles > 8192 || g.TH < 2) return OESS_EINVAL;
     int64_t nsl64 = (max_seg_len + SSL - 1) / SSL;
     if (nsl64 < 1) nsl64 = 1;
     const int nSl = (int)nsl64;
     size_t o_table, o_recs;
-    ws_layout_v2(0, n_seg, g, nSl, &o_table, &o_recs);
-    if (!workspace || workspace_bytes < o_recs + sizeof(float4)) return OESS_ENOMEM;
+    const size_t need = ws_layout_tri(0, n_seg, g, nSl, &o_table, &o_recs);
+    if (!workspace || workspace_bytes < need) return OESS_ENOMEM;
+    if ((size_t)n_seg * nSl * RSTRIDE > 0xffff0000ull) return OESS_EINVAL;      // 32-bit record indices
     // record capacity of the caller's workspace (oess_voxelize_workspace_bytes sizes it for 4 records per event, the
     // worst case); records beyond it are dropped rather than written out of bounds
-    size_t cap_sz = (workspace_bytes - o_recs) / sizeof(float4);
+    size_t cap_sz = (workspace_bytes - o_recs) / sizeof(Rec);
     if (cap_sz > 0xffff0000ull) cap_sz = 0xffff0000ull;
     const unsigned int cap = (unsigned int)cap_sz;
     char* wb = (char*)workspace;
-    unsigned int* alloc = (unsigned int*)wb;
     int* table = (int*)(wb + o_table);
-    float4* recs = (float4*)(wb + o_recs);
-    OESS_HIP(hipMemsetAsync(alloc, 0, 4, st));
+    Rec* recs = (Rec*)(wb + o_recs);
     Src src_c = src;
     src_c.seg_base_index = 0;
-    const size_t sort_lds = (((size_t)(g.nTiles + 1 + 16) * 4 + 15) & ~(size_t)15) + (size_t)LCAP * sizeof(float4);
-    if (sort_lds + 64 > 160 * 1024)  // very fine tilings: the tile table does not fit beside the record buffer
-        return run_tri_v1(src, seg_off, n_seg, max_seg_len, C, H, W, crop_rows, count_mode, out, workspace, workspace_bytes, st);
+    const size_t sort_lds = (((size_t)(g.nTiles + 1 + 17) * 4 + 15) & ~(size_t)15) + (size_t)LCAP * sizeof(Rec);
+    if (sort_lds + 64 > 160 * 1024) return OESS_EINVAL;
+    const size_t splat_lds = (size_t)g.C * g.TH * TW * sizeof(int);
     OESS_HIP(hipFuncSetAttribute((const void*)&tri_sort_kernel<Src>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
-    hipLaunchKernelGGL((tri_sort_kernel<Src>), dim3(nSl, n_seg), dim3(SORT_THREADS), sort_lds, st, src_c, seg_off, g, nSl, table, alloc,
+    hipLaunchKernelGGL((tri_sort_kernel<Src>), dim3(nSl, n_seg), dim3(SORT_THREADS), sort_lds, st, src_c, seg_off, g, nSl, table,
                        recs, cap);
-    OESS_HIP(hipFuncSetAttribute((const void*)&tri_splat2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)g.C * g.TH * TW * sizeof(long long))));
-    hipLaunchKernelGGL(tri_splat2_kernel, dim3(g.nTiles, n_seg), dim3(THREADS), (size_t)g.C * g.TH * TW * sizeof(long long), st,
-                       (const float4*)recs, (const int*)table, g, nSl, count_mode, cap, out);
-    OESS_HIP(hipGetLastError());
-    return OESS_OK;
-}
-
-template <typename Src>
-int run_tri_v1(Src src, const int64_t* seg_off, int n_seg, int64_t max_seg_len, int C, int H, int W, int crop_rows,
-            int count_mode, float* out, void* workspace, size_t workspace_bytes, hipStream_t st) {
-    if (n_seg <= 0 || C <= 0 || C > 64 || H <= 0 || W <= 0 || crop_rows < 0 || crop_rows >= H || !out || !seg_off)
-        return OESS_EINVAL;
-    if (max_seg_len < 0 || max_seg_len > 0x3fffffffll) return OESS_EINVAL;
-    Geom g = make_geom(C, H, W, crop_rows, max_seg_len);
-    if (g.nTiles > 8192) return OESS_EINVAL;
-    // Optional chunking over segments (OESS_VOX_CHUNK=n): meant to keep a chunk's record buffer resident in the
-    // 256 MiB Infinity Cache between scatter and splat.  MEASURED SLOWER on MI355X (0.61 ms whole batch vs 0.76 /
-    // 0.96 / 1.58 ms at 40 / 20 / 10 segments per chunk): the passes are not HBM-bound enough for the saved
-    // traffic to pay for 4-16x more, smaller launches.  Default: one chunk.
-    static int chunk_env = -1;
-    if (chunk_env < 0) { const char* e = getenv("OESS_VOX_CHUNK"); chunk_env = e ? atoi(e) : 0; if (chunk_env <= 0) chunk_env = 1 << 30; }
-    const int chunk = chunk_env < n_seg ? chunk_env : n_seg;
-    Workspace ws;
-    const size_t min_need = ws_layout(0, chunk, g, &ws, workspace, workspace_bytes);
-    if (!workspace || workspace_bytes < min_need) return OESS_ENOMEM;
-    for (int s0 = 0; s0 < n_seg; s0 += chunk) {
-        const int ns = (n_seg - s0 < chunk) ? n_seg - s0 : chunk;
-        const int64_t* so = seg_off + s0;
-        Src src_c = src;
-        src_c.seg_base_index = s0;
-        float* out_c = out + (size_t)s0 * g.C * g.Hout * g.W;
-        const dim3 bin_grid(g.nSlices, ns);
-        hipLaunchKernelGGL((tri_bin_kernel<0, Src>), bin_grid, dim3(THREADS), g.nTiles * sizeof(int), st, src_c, so, g,
-                           ws.table, ws.seg_base, ws.recs, ws.cap);
-        hipLaunchKernelGGL(scan_seg_kernel, dim3(ns), dim3(1024), 0, st, ws.table, ws.tile_start, ws.seg_total, g);
-        hipLaunchKernelGGL(scan_base_kernel, dim3(1), dim3(1024), 0, st, ws.seg_total, ws.seg_base, ns);
-        hipLaunchKernelGGL((tri_bin_kernel<1, Src>), bin_grid, dim3(THREADS), g.nTiles * sizeof(int), st, src_c, so, g,
-                           ws.table, ws.seg_base, ws.recs, ws.cap);
-        hipLaunchKernelGGL(tri_splat_kernel, dim3(g.nTiles, ns), dim3(THREADS),
-                           (size_t)g.C * g.TH * TW * sizeof(long long), st, ws.recs, ws.tile_start, ws.seg_base, g,
-                           count_mode, ws.cap, out_c);
-    }
+    OESS_HIP(hipFuncSetAttribute((const void*)&tri_splat_kernel<Src>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)splat_lds));
+    const long long n_items = (long long)g.nTiles * n_seg;
+    if (n_items > 0x7fffffffll) return OESS_EINVAL;
+    hipLaunchKernelGGL((tri_splat_kernel<Src>), dim3((unsigned)n_items), dim3(THREADS), splat_lds, st, src_c, (const Rec*)recs,
+                       (const int*)table, g, nSl, count_mode, cap, out);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }
@@ -898,11 +876,11 @@ size_t oess_voxelize_workspace_bytes(int64_t n_events, int n_seg, int64_t max_se
                                      int crop_rows) {
     if (n_events < 0 || n_seg <= 0 || max_seg_len < 0 || C <= 0 || H <= 0 || W <= 0 || crop_rows < 0 || crop_rows >= H)
         return 0;
-    Geom g = make_geom(C, H, W, crop_rows, max_seg_len);
-    const size_t v1 = ws_layout(n_events, n_seg, g, nullptr, nullptr, 0);
+    // one query serves both pipelines (nearest-xy: 2 x nbins accumulator channels <= C passed by the caller)
+    const size_t v1 = ws_layout(n_events, n_seg, make_geom(C, H, W, crop_rows, max_seg_len), nullptr, nullptr, 0);
     int64_t nsl = (max_seg_len + SSL - 1) / SSL;
     if (nsl < 1) nsl = 1;
-    const size_t v2 = ws_layout_v2(n_events, n_seg, g, (int)nsl, nullptr, nullptr);
+    const size_t v2 = ws_layout_tri(n_events, n_seg, tri_geom(C, H, W, crop_rows, max_seg_len), (int)nsl, nullptr, nullptr);
     return v1 > v2 ? v1 : v2;
 }
 
