@@ -691,6 +691,211 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_dma_kernel(ConvArgs a) {
 }
 
 // =================================================================================================
+// 3x3 / stride-1 / "same" convolutions with ROW-HALO REUSE of the pixel operand (conv3x3_halo_kernel).
+//
+// In the implicit GEMM above, every K-slab = (filter tap, 64 input channels) fetches its own 128 x 64 im2col block, yet the
+// blocks of the three taps of one filter ROW (dx = 0, 1, 2) are the same 128 pixels shifted by `dil` pixels.  Here the
+// K loop runs in (dy, channel chunk, dx) order -- the standard packed weight already holds each (tap, chunk) as 64
+// contiguous k, so no new packing -- and the pixel operand of the three dx taps is ONE halo buffer in LDS:
+//   halo rows = [dil lead pixels][segment 0][dil gap][segment 1][dil gap] ... [last segment][dil trail pixels]
+// where a segment is a run of tile pixels inside one image row; the gap rows are written as zeros by out-of-range DMA
+// offsets, so a side tap that crosses an image-row (or image) boundary lands on zeros exactly like the im2col padding.
+// Tile pixel i sits at halo row hrow(i); tap dx reads row hrow(i) + (dx - 1) * dil.  Per K-slab the workgroup now moves
+// 16 KB of weights + a third of a <= 20 KB halo instead of 32 KB: ~30 % fewer L2->LDS bytes and LDS-DMA writes on the
+// layers that make up most of the step (ConvLSTM gates, decoder and teacher 3x3 convs).
+// LDS: 2 halo buffers (2 x 20 KB) + 2 weight stages (2 x 16 KB) = 72 KB -> still two workgroups per CU.
+// =================================================================================================
+constexpr int HALO_ROWS = 160;
+
+template <int EPI>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a) {
+    constexpr int BMX = 128, BN = 128, NWAVES = 4, WAVES_N = 2, WM = 64, WN = 64, MT = 2, NT = 2;
+    constexpr int H_INSTR = HALO_ROWS / 8 / NWAVES;      // 5 DMA instructions per thread per halo
+    constexpr int B_INSTR = BN * 8 / 64 / NWAVES;        // 4
+    constexpr int HALO_BYTES = HALO_ROWS * 128, BST_BYTES = BN * 128;
+    constexpr int NFRAG = MT + NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [halo 0][halo 1][weights 0][weights 1]
+
+    const int nwg = a.tiles_m * a.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
+    const int m0 = tile_m * BMX, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int nch = a.Cin >> 6;                          // 64-channel chunks
+    const int NJ = 3 * nch;                              // macro steps (dy, chunk); 3 K-slabs each
+    const int W = a.W, dil = a.dil, wd = W + dil;
+
+    const long long in_bytes = (((long long)a.B * a.H * a.W - 1) * a.in_pix_stride + a.Cin) * 2;
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7ffffff0, 0x00020000);
+
+    // tile origin (wave-uniform)
+    const int hw = a.H * W;
+    const int b0 = m0 / hw, rem0 = m0 - b0 * hw;
+    const int oy0 = rem0 / W, ox0 = rem0 - oy0 * W;
+    const int L0 = (W - ox0 < BMX) ? W - ox0 : BMX;      // tile pixels in the first image row
+
+    // ---- halo DMA geometry: lane (lrow, slot) of instruction q writes halo row h = q*8 + lrow, 16-byte slot `slot`
+    const int lrow = lane >> 3, slot = lane & 7;
+    int hy[H_INSTR], hoff[H_INSTR];
+#pragma unroll
+    for (int i = 0; i < H_INSTR; ++i) {
+        const int h = (wave * H_INSTR + i) * 8 + lrow;
+        const int hp = h - dil;
+        int m_seg, px;                                   // first tile pixel of the row's segment, x coordinate of this halo row
+        if (hp < L0 + dil) { m_seg = m0; px = ox0 + hp; }
+        else {
+            const int h2 = hp - (L0 + dil);
+            const int q = h2 / wd, r = h2 - q * wd;
+            m_seg = m0 + L0 + q * W; px = r;
+        }
+        const bool valid = m_seg < a.M && (m_seg == m0 || m_seg - m0 < BMX) && (unsigned)px < (unsigned)W;
+        const int ms = valid ? m_seg : 0;
+        const int b = ms / hw, rr = ms - b * hw;
+        const int oy = rr / W;
+        hy[i] = valid ? oy : -0x4000;
+        hoff[i] = (int)((((long long)b * a.H + oy) * W + px) * a.in_pix_stride * 2) + (slot ^ ((h >> 1) & 7)) * 16;
+    }
+    int boff[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int r = (wave * B_INSTR + i) * 8 + lrow;
+        boff[i] = ((n0 + r) * a.Kpad + (slot ^ ((r >> 1) & 7)) * 8) * 2;
+    }
+    // halo part `part` (instructions [i0, i1)) of macro step j -> halo buffer j & 1
+    auto issue_halo = [&](int j, int i0, int i1) {
+        const int dy = j / nch, cc = j - dy * nch;
+        const int ddy = (dy - 1) * dil;
+        const int tapoff = (ddy * W * (int)a.in_pix_stride + cc * 64) * 2;
+        unsigned char* st = smem + (j & 1) * HALO_BYTES;
+#pragma unroll
+        for (int i = 0; i < H_INSTR; ++i) {
+            if (i < i0 || i >= i1) continue;
+            const bool ok = (unsigned)(hy[i] + ddy) < (unsigned)a.H;
+            const unsigned voff = ok ? (unsigned)(hoff[i] + tapoff) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave * H_INSTR + i) * 1024),
+                                                     16, voff, 0, 0, 0);
+        }
+    };
+    // weight slab of (macro step j, dx) -> weight stage kt & 1, kt = 3*j + dx
+    auto issue_w = [&](int j, int dx) {
+        const int dy = j / nch, cc = j - dy * nch;
+        const int koff = ((dy * 3 + dx) * a.Cin + cc * 64) * 2;
+        unsigned char* st = smem + 2 * HALO_BYTES + ((3 * j + dx) & 1) * BST_BYTES;
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(st + (wave * B_INSTR + i) * 1024),
+                                                     16, (unsigned)(boff[i] + koff), 0, 0, 0);
+    };
+
+    f32x16_t acc[MT][NT];
+    if constexpr (EPI == 1) {
+        lstm_bias_init<MT, NT>(a, acc, n0, wn, lane);
+    } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    }
+
+    // ---- fragment addresses.  Pixel fragments: halo row of tile pixel (wm*64 + i*32 + lane&31), shifted per dx tap
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    uint32_t fa_row[MT][3], fa_sw[MT][3], fb_off[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int r = wm * WM + i * 32 + (lane & 31);
+        int hr;
+        if (r < L0) hr = r;                              // (+ dil lead rows, - dil for the dx = 0 tap)
+        else {
+            const int t = r - L0, q = t / W, rr = t - q * W;
+            hr = L0 + dil + q * wd + rr;
+        }
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int h = hr + dx * dil;
+            fa_row[i][dx] = (uint32_t)h * 128;
+            fa_sw[i][dx] = (uint32_t)((h >> 1) & 7);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb_off[j] = (uint32_t)(2 * HALO_BYTES + (wn * WN + j * 32 + (lane & 31)) * 128);
+    const uint32_t half = (uint32_t)(lane >> 5);
+    const uint32_t rswb = (uint32_t)(((lane & 31) >> 1) & 7);
+
+    issue_halo(0, 0, H_INSTR);
+    issue_w(0, 0);
+    constexpr bool LSTM_PREF = (EPI == 1);
+    LstmPrefetch pref;
+    if constexpr (LSTM_PREF) lstm_prefetch(a, pref, m0, n0, tid);
+
+#define OESS_HFRAG_READ(DST_A, DST_B, KS, DX)                                                                    \
+    {                                                                                                            \
+        const uint32_t c_ = (uint32_t)((KS) * 2) + half;                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                           \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(DST_A[i]) : "v"(hbase_ + fa_row[i][DX] + ((c_ ^ fa_sw[i][DX]) << 4)) : "memory"); \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                           \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(DST_B[j]) : "v"(wbase_ + fb_off[j] + ((c_ ^ rswb) << 4)) : "memory"); \
+    }
+#define OESS_HFRAG_MMA(SRC_A, SRC_B)                                                                             \
+    {                                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                           \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                       \
+                acc[i][j] = (EPI == 1) ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(SRC_B[j], SRC_A[i], acc[i][j], 0, 0, 0)     \
+                                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(SRC_A[i], SRC_B[j], acc[i][j], 0, 0, 0);   \
+    }
+#define OESS_HWAIT(N_, FA_, FB_)                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(FA_[0]), "+v"(FA_[1]), "+v"(FB_[0]), "+v"(FB_[1]) : "n"(N_) : "memory");
+
+    for (int j = 0; j < NJ; ++j) {
+        const uint32_t hbase_ = lds0 + (uint32_t)((j & 1) * HALO_BYTES);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();               // slab (j, dx) complete for every wave; the other buffers are free
+            // next weight slab, and a third of the next macro step's halo, travel under this slab's MFMAs
+            if (dx < 2) issue_w(j, dx + 1);
+            else if (j + 1 < NJ) issue_w(j + 1, 0);
+            if (j + 1 < NJ) {
+                if (dx == 0) issue_halo(j + 1, 0, 2);
+                else if (dx == 1) issue_halo(j + 1, 2, 4);
+                else issue_halo(j + 1, 4, H_INSTR);
+            }
+            const uint32_t wbase_ = lds0 + (uint32_t)(((3 * j + dx) & 1) * BST_BYTES);
+            bf16x8_t fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+            __builtin_amdgcn_s_setprio(3);
+            OESS_HFRAG_READ(fa0, fb0, 0, dx)
+            OESS_HFRAG_READ(fa1, fb1, 1, dx)
+            OESS_HWAIT(NFRAG, fa0, fb0)
+            OESS_HFRAG_MMA(fa0, fb0)
+            OESS_HFRAG_READ(fa0, fb0, 2, dx)
+            OESS_HWAIT(NFRAG, fa1, fb1)
+            OESS_HFRAG_MMA(fa1, fb1)
+            OESS_HFRAG_READ(fa1, fb1, 3, dx)
+            OESS_HWAIT(NFRAG, fa0, fb0)
+            OESS_HFRAG_MMA(fa0, fb0)
+            OESS_HWAIT(0, fa1, fb1)
+            OESS_HFRAG_MMA(fa1, fb1)
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+#undef OESS_HFRAG_READ
+#undef OESS_HFRAG_MMA
+#undef OESS_HWAIT
+    __syncthreads();
+
+    if constexpr (EPI == 1) lstm_epilogue<MT, NT, true, false>(a, acc, smem, m0, n0, wm, wn, lane, tid, &pref);
+    else conv_epilogue<BMX, BN, BN + 8, 256, WAVES_N>(a, acc, smem, m0, n0, wm, wn, lane, tid);
+}
+
+// =================================================================================================
 // v4: BK = 32 slabs in a 4-deep LDS ring (same 64 KB per workgroup, still 2 workgroups per CU).
 // The 2-stage BK = 64 kernel has ONE slab in flight per workgroup and must hide the whole L2 -> LDS round trip
 // (~1.0-1.3 us under load) behind one slab of MFMAs (0.54 us when two workgroups share the CU): it is latency bound
@@ -1522,6 +1727,7 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
                              (const void*)&conv_fwd_dma_kernel<256, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<256, 128, 2, true>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 2, false, 1>, (const void*)&conv_fwd_dma_kernel<128, 128, 2, true, 1>,
                              (const void*)&conv_fwd_t256_kernel<0>, (const void*)&conv_fwd_t256_kernel<1>,
+                             (const void*)&conv3x3_halo_kernel<0>, (const void*)&conv3x3_halo_kernel<1>,
                              (const void*)&conv_fwd_dma32_kernel<128, false, 0>, (const void*)&conv_fwd_dma32_kernel<128, true, 0>,
                              (const void*)&conv_fwd_dma32_kernel<64, false, 0>, (const void*)&conv_fwd_dma32_kernel<64, true, 0>,
                              (const void*)&conv_fwd_dma32_kernel<128, false, 1>, (const void*)&conv_fwd_dma32_kernel<128, true, 1>,
@@ -1611,6 +1817,24 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
         hipLaunchKernelGGL((conv_smallcin_kernel<5, 5>), dim3(tiles < sc_wgs ? tiles : sc_wgs), dim3(256), 0, st, a);
         OESS_HIP(hipGetLastError());
         return OESS_OK;
+    }
+    // 3x3 stride-1 'same' convolutions with Cin % 64 == 0: row-halo reuse of the pixel operand (conv3x3_halo_kernel), unless the
+    // 64-row tiling below is what the layer wants (tile quantisation of small maps).
+    static int halo = -1;
+    if (halo < 0) { const char* e = getenv("OESS_CONV_HALO"); halo = e ? atoi(e) : 1; }
+    if (halo && dma_ok && use == 2 && R == 3 && S == 3 && stride == 1 && pad == dil && (Cin % 64) == 0 && bn == 128 &&
+        a.Kpad == 9 * Cin && a.Ho == H && a.Wo == W && (dil + 127 + dil * ((BM + W - 2) / W) + dil + 1) <= HALO_ROWS) {
+        const long long t128 = (long long)a.tiles_m * a.tiles_n;
+        const long long t64 = (long long)((a.M + 63) / 64) * a.tiles_n;
+        const double e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
+        const double e64 = 0.88 * (double)t64 / (double)(((t64 + 767) / 768) * 768);
+        if (lstm || tile_stats || halo == 2 || !(e64 > e128 * 1.04)) {
+            const size_t lds = (size_t)2 * HALO_ROWS * 128 + (size_t)2 * 128 * 128;
+            if (lstm) hipLaunchKernelGGL((conv3x3_halo_kernel<1>), grid, block, lds, st, a);
+            else hipLaunchKernelGGL((conv3x3_halo_kernel<0>), grid, block, lds, st, a);
+            OESS_HIP(hipGetLastError());
+            return OESS_OK;
+        }
     }
     // 256 x 256 tile, 4 waves x (128 x 128), software-pipelined BK = 32 ring (conv_fwd_t256_kernel).  Measured
     // (tools/conv_ablate.py, same box): while all 256 CUs hold a tile it runs 1150 TF/s against 1030 TF/s for the
