@@ -323,6 +323,9 @@ def test_deeplab_well_conditioned_forward_backward(g, keys):
         refv = g[key] if key in g else g[key + "__sub"]
         got = got if key in g else compact(got)[0]
         # the REFERENCE's own gradient (golden): same calibrated bound as against the oracle
+        if not np.any(refv):           # the strided golden sample can land on taps that are out of range for every pixel (rate 18 at 14x20)
+            assert not np.any(got), name
+            continue
         assert cos(got, refv) >= min(0.98, c_emu_of[name] - 0.15), (name, cos(got, refv), c_emu_of[name])
     print("deeplab wc: argmax agreement", float((am == ar).mean()), "rounding-only", agree_emu, "clear fraction", float(clear.mean()))
 
