@@ -424,6 +424,61 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     }
 }
 
+// reduce_partials_kernel + finalize_kernel in ONE launch (the frozen teacher and the DeepLab forward issue 53-59 of each per pass,
+// ~4 us apiece): the tile partials are summed in DOUBLE (one double atomic per (block, channel)), and the block that takes the
+// last ticket of its 32-channel group computes mean / rstd / scale / shift / running statistics from the totals -- in double, so
+// E[x^2] - E[x]^2 does not cancel in fp32 -- and leaves the accumulators and its ticket counter zeroed for the next call.
+__global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ part, int tiles, int C, double* __restrict__ sum,
+                                                              double* __restrict__ sumsq, unsigned int* __restrict__ counter,
+                                                              float count, float eps, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var, float momentum,
+                                                              float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                              float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double red[8][32][2];
+    __shared__ unsigned int ticket;
+    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int t = blockIdx.y * 8 + tl; t < tiles; t += gridDim.y * 8) {
+            s1 += (double)part[((size_t)t * 2) * C + c];
+            s2 += (double)part[((size_t)t * 2 + 1) * C + c];
+        }
+    red[tl][cl][0] = s1; red[tl][cl][1] = s2;
+    __syncthreads();
+    if (tl == 0 && c < C) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }
+        atomicAdd(&sum[c], s1);
+        atomicAdd(&sumsq[c], s2);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) ticket = atomicAdd(&counter[blockIdx.x], 1u);
+    __syncthreads();
+    if (ticket != gridDim.y - 1) return;
+    __threadfence();
+    if (tl == 0 && c < C) {
+        const double S = atomicAdd(&sum[c], 0.0), Q = atomicAdd(&sumsq[c], 0.0);      // device-coherent reads of the totals
+        const double m = S / (double)count;
+        double var = Q / (double)count - m * m;                                         // biased variance
+        if (var < 0.0) var = 0.0;
+        const float r = (float)(1.0 / sqrt(var + (double)eps));
+        mean_out[c] = (float)m; rstd_out[c] = r;
+        const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+        scale[c] = ga * r;
+        shift[c] = be - (float)m * ga * r;
+        if (running_mean) {                                                             // nn.BatchNorm2d: unbiased running_var
+            const float unb = count > 1.f ? (float)(var * (double)count / ((double)count - 1.0)) : (float)var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+        }
+        sum[c] = 0.0; sumsq[c] = 0.0;
+    }
+    if (threadIdx.x == 0) counter[blockIdx.x] = 0u;
+}
+
 // chunks per group.  Every workgroup ends with 2*C float atomics on the same few cache lines, and those serialise in L2:
 // measured on a 72 MB tensor, forward statistics 34.6 us with 1024 workgroups, 16.1 us with 256 (four 16-byte loads in
 // flight per lane keep the HBM stream busy); the backward sums read two or three tensors and want 512.
@@ -491,6 +546,21 @@ int oess_norm_reduce_tile_stats(const float* tile_stats, int tiles, int C, float
     if (gy > 32) gy = 32;
     if (gy < 1) gy = 1;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 31) / 32, gy), dim3(256), 0, st, tile_stats, tiles, C, sum, sumsq);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_norm_reduce_finalize_tile_stats(const float* tile_stats, int tiles, int C, double* sum, double* sumsq,
+                                         unsigned int* counters, float count, float eps, const float* gamma, const float* beta,
+                                         float* running_mean, float* running_var, float momentum, float* mean, float* rstd,
+                                         float* scale, float* shift, oess_stream_t stream) {
+    if (!tile_stats || !sum || !sumsq || !counters || !mean || !rstd || !scale || !shift || tiles <= 0 || C <= 0 || count <= 0.f)
+        return OESS_EINVAL;
+    int gy = (tiles + 63) / 64;                    // >= 8 tiles per tile lane
+    if (gy > 32) gy = 32;
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL(reduce_finalize_kernel, dim3((C + 31) / 32, gy), dim3(256), 0, (hipStream_t)stream, tile_stats, tiles, C, sum, sumsq,
+                       counters, count, eps, gamma, beta, running_mean, running_var, momentum, mean, rstd, scale, shift);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }

@@ -636,6 +636,8 @@ _STATS_SCRATCH = {}
 class _StatsScratch:
     def __init__(self, n, device):
         self.buf = torch.zeros((2, n), dtype=torch.float32, device=device)
+        self.buf64 = torch.zeros((2, n), dtype=torch.float64, device=device)       # tile-statistics totals (double) ...
+        self.tickets = torch.zeros(((n + 31) // 32,), dtype=torch.int32, device=device)   # ... and their last-block tickets
         self.busy = False
 
     def acquire(self):
@@ -977,14 +979,11 @@ def conv_bn_train_nhwc(x, packed, Cout, R, S, stride, pad, dil, bn, relu=False, 
     y = conv2d_nhwc(x, packed, None, Cout, R, S, stride, pad, dil, tile_stats=part)
     st = torch.empty((6, 1, Cout), dtype=torch.float32, device=x.device)
     sc = _stats_scratch(Cout, x.device)
-    acc = sc.acquire()
-    _lib.check(lib.oess_norm_reduce_tile_stats(_ptr(part), tiles, Cout, _ptr(acc[0]), _ptr(acc[1]), 1, _stream()),
-               "oess_norm_reduce_tile_stats")
     mom = 0.0 if bn.momentum is None else bn.momentum
-    _lib.check(lib.oess_norm_finalize(_ptr(acc[0]), _ptr(acc[1]), 1, 1, Cout, float(M), float(bn.eps), _ptr(bn.weight.detach()),
-                                      _ptr(bn.bias.detach()), _ptr(bn.running_mean), _ptr(bn.running_var), float(mom),
-                                      _ptr(st[2]), _ptr(st[3]), _ptr(st[4]), _ptr(st[5]), _stream()), "oess_norm_finalize")
-    sc.release()
+    _lib.check(lib.oess_norm_reduce_finalize_tile_stats(_ptr(part), tiles, Cout, _ptr(sc.buf64[0]), _ptr(sc.buf64[1]), _ptr(sc.tickets),
+                                                        float(M), float(bn.eps), _ptr(bn.weight.detach()), _ptr(bn.bias.detach()),
+                                                        _ptr(bn.running_mean), _ptr(bn.running_var), float(mom), _ptr(st[2]), _ptr(st[3]),
+                                                        _ptr(st[4]), _ptr(st[5]), _stream()), "oess_norm_reduce_finalize_tile_stats")
     rps = 0
     if residual is not None:
         _, _, _, _, rps = _nhwc_geom(residual)
