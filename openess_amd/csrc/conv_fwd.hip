@@ -59,7 +59,6 @@ struct ConvArgs {
     uint16_t* lstm_h;          // hidden output, bf16, pixel stride lstm_h_stride (must NOT alias the conv input)
     long long lstm_h_stride;
     int lstm_C;
-    float rcp_hw, rcp_wo;      // persistent kernel: float reciprocals for the per-tile row decode (M < 2^22)
     unsigned inv_cpt, inv_s;   // exact small-range reciprocals: kc / cpt == (kc * inv_cpt) >> 20, tap / S == (tap * inv_s) >> 16
 };
 
@@ -75,9 +74,7 @@ __device__ __forceinline__ float conv_act(float v, int mode) {
     return v;
 }
 
-// PITCH: row pitch (elements) of the bf16 LDS image.  BN + 8 pads the image; BN (no padding) makes it exactly one
-// ring stage (the persistent kernel parks it in the stage it has just finished reading) and still reads conflict
-// free: the 16-lane groups of ds_read_b128 cover 16 distinct 16-byte chunks of a 256-byte row pair.
+// PITCH: row pitch (elements) of the bf16 LDS image (BN + 8: padded, conflict-free 16-byte row reads).
 template <int BMX, int BN, int PITCH = BN + 8, int NTHREADS = conv_tile_threads(BMX), int WAVES_N = (BN == 128) ? 2 : 1>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
                                               f32x16_t (&acc)[BMX / ((NTHREADS / 64) / WAVES_N) / 32][(BN / WAVES_N) / 32],
@@ -1075,389 +1072,6 @@ __global__ __launch_bounds__(256) void conv_fwd_dma32_kernel(ConvArgs a) {
     else conv_epilogue<BMX, BN>(a, acc, smem, m0, n0, wm, wn, lane, tid);
 }
 
-// =================================================================================================
-// v5: 256 x 256 tile, 4 waves, 128 x 128 WAVE tile (the vendor GEMM's shape: 16 MFMAs per 8 fragment reads, half the
-// LDS read bytes per FLOP of the 64 x 64 wave tile), BK = 32 slabs in a 4-deep ring (128 KB), one workgroup per CU.
-// With ONE wave per SIMD nothing hides a stall, so the loop is software pipelined by hand:
-//   * a slab is DMA-issued three slabs before it is consumed (3 x 1024 MFMA cycles > the L2 -> LDS round trip),
-//     and the 8 DMA instructions of a thread are spread between the MFMAs of k-step 0;
-//   * fragments of the next k-step (also across the slab boundary) are read under the current k-step's MFMAs;
-//   * the only barrier per slab sits between the two k-steps, when the MFMA pipe still holds k-step 0's tail.
-// Needs Cin % 32 == 0 (one filter tap per slab -> scalar tap decode).
-// =================================================================================================
-template <int EPI>
-__global__ __launch_bounds__(256) void conv_fwd_t256_kernel(ConvArgs a) {
-    constexpr int BMX = 256, BN = 256, BKS = 32, NST = 4;
-    constexpr int WM = 128, WN = 128, MT = 4, NT = 4;
-    constexpr int A_INSTR = 4, B_INSTR = 4;             // 16 rows x 64 B per wave instruction, 4 waves
-    constexpr int A_BYTES = BMX * 64;
-    constexpr int STAGE_BYTES = (BMX + BN) * 64;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int nwg = a.tiles_m * a.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
-    const int m0 = tile_m * BMX, n0 = tile_n * BN;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int KT = a.Kpad / BKS;
-    const int cpt = a.Cin >> 3, ntaps = a.R * a.S;
-
-    const long long in_bytes = (((long long)a.B * a.H * a.W - 1) * a.in_pix_stride + a.Cin) * 2;
-    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)in_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7ffffff0, 0x00020000);
-
-    const int lrow = lane >> 2, slot = lane & 3;       // 16 rows x 4 chunk slots per wave instruction
-    int iy0[A_INSTR], ix0[A_INSTR], rowoff[A_INSTR];
-#pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) {
-        const int r = (wave * A_INSTR + i) * 16 + lrow;
-        const int m = m0 + r;
-        const bool valid = m < a.M;
-        const int mm = valid ? m : 0;
-        const int hw = a.Ho * a.Wo;
-        const int b = mm / hw, rem = mm - b * hw;
-        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-        iy0[i] = valid ? oy * a.stride - a.pad : -0x4000;
-        ix0[i] = ox * a.stride - a.pad;
-        rowoff[i] = (int)((((long long)b * a.H + (oy * a.stride - a.pad)) * a.W + ix0[i]) * a.in_pix_stride * 2) +
-                    (slot ^ ((r >> 2) & 3)) * 16;
-    }
-    int boff[B_INSTR];
-#pragma unroll
-    for (int i = 0; i < B_INSTR; ++i) {
-        const int r = (wave * B_INSTR + i) * 16 + lrow;
-        boff[i] = ((n0 + r) * a.Kpad + (slot ^ ((r >> 2) & 3)) * 8) * 2;
-    }
-
-    // wave-uniform decode of slab kt (one filter tap, 32 channels of it)
-    int s_dy = 0, s_dx = 0, s_tapoff = 0;
-    unsigned s_boff = 0;
-    bool s_ok = false;
-    unsigned char* s_st = smem;
-    auto decode = [&](int kt) {
-        const unsigned kc0 = (unsigned)(kt * 4);
-        const unsigned tap = (kc0 * a.inv_cpt) >> 20;
-        const int cc0 = (int)(kc0 - tap * cpt);
-        const unsigned r = (tap * a.inv_s) >> 16;
-        const int sx = (int)(tap - r * a.S);
-        s_dy = (int)r * a.dil; s_dx = sx * a.dil;
-        s_tapoff = ((s_dy * a.W + s_dx) * (int)a.in_pix_stride + cc0 * 8) * 2;
-        s_ok = (int)tap < ntaps && kt < KT;
-        s_st = smem + (kt & (NST - 1)) * STAGE_BYTES;
-        s_boff = kt < KT ? (unsigned)(kt * BKS * 2) : 0x80000000u;     // dummy slab: out of range -> zeros
-    };
-    auto issue_a = [&](int i) {
-        const bool ok = s_ok && (unsigned)(iy0[i] + s_dy) < (unsigned)a.H && (unsigned)(ix0[i] + s_dx) < (unsigned)a.W;
-        const unsigned voff = ok ? (unsigned)(rowoff[i] + s_tapoff) : 0x80000000u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(s_st + (wave * A_INSTR + i) * 1024),
-                                                 16, voff, 0, 0, 0);
-    };
-    auto issue_b = [&](int i) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(s_st + A_BYTES + (wave * B_INSTR + i) * 1024),
-                                                 16, (unsigned)boff[i] + s_boff, 0, 0, 0);
-    };
-
-    f32x16_t acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-    uint32_t fa_off[MT], fb_off[NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) fa_off[i] = (uint32_t)(wm * WM + i * 32 + (lane & 31)) * 64;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) fb_off[j] = (uint32_t)(A_BYTES + (wn * WN + j * 32 + (lane & 31)) * 64);
-    const int half = lane >> 5;
-    const int rsw = ((lane & 31) >> 2) & 3;
-    const uint32_t sl0 = (uint32_t)(((0 + half) ^ rsw) * 16), sl1 = (uint32_t)(((2 + half) ^ rsw) * 16);
-
-#pragma unroll
-    for (int s = 0; s < NST - 1; ++s) {
-        decode(s);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { issue_a(i); issue_b(i); }
-    }
-
-#define OESS_FR(DST_A, DST_B, SL)                                                                                \
-    {                                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                           \
-            asm volatile("ds_read_b128 %0, %1" : "=v"(DST_A[i]) : "v"(stage_ + fa_off[i] + SL) : "memory");     \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                           \
-            asm volatile("ds_read_b128 %0, %1" : "=v"(DST_B[j]) : "v"(stage_ + fb_off[j] + SL) : "memory");     \
-    }
-#define OESS_MFMA(I_, J_, SA_, SB_)                                                                              \
-    acc[I_][J_] = (EPI == 1) ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(SB_[J_], SA_[I_], acc[I_][J_], 0, 0, 0)   \
-                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(SA_[I_], SB_[J_], acc[I_][J_], 0, 0, 0);
-#define OESS_WAITF(N_, FA_, FB_)                                                                                 \
-    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(FA_[0]), "+v"(FA_[1]), "+v"(FA_[2]), "+v"(FA_[3]),               \
-                 "+v"(FB_[0]), "+v"(FB_[1]), "+v"(FB_[2]), "+v"(FB_[3]) : "n"(N_) : "memory");
-
-    // Branch-free loop: slabs beyond KT are issued as dummies (out-of-range offsets: the DMA writes zeros into a stage
-    // nobody reads again), so every iteration issues exactly 8 DMA instructions per thread and the retire wait is
-    // always vmcnt(16) = "the two younger slabs may stay in flight".  (A branchy version made hipcc shuffle the 256
-    // accumulators between AGPRs and VGPRs on every iteration.)
-    bf16x8_t fa0[MT], fb0[NT], fa1[MT], fb1[NT];
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    uint32_t stage_ = lds0;
-    OESS_FR(fa0, fb0, sl0)
-
-    for (int kt = 0; kt < KT; ++kt) {
-        OESS_FR(fa1, fb1, sl1)                           // k-step 1 of slab kt, in flight under k-step 0's MFMAs
-        OESS_WAITF(8, fa0, fb0)
-        __builtin_amdgcn_sched_barrier(0);
-        decode(kt + NST - 1);                            // its stage held slab kt-1, free since the last barrier
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) { OESS_MFMA(i, j, fa0, fb0) }
-            issue_a(i);
-            issue_b(i);
-        }
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // slab kt+1: this thread's parts (the barrier makes it everyone's)
-        OESS_WAITF(0, fa1, fb1)                          // every read of slab kt has landed in registers
-        __builtin_amdgcn_s_barrier();
-        stage_ = lds0 + (uint32_t)(((kt + 1) & (NST - 1)) * STAGE_BYTES);
-        OESS_FR(fa0, fb0, sl0)                           // k-step 0 of slab kt+1 under k-step 1's MFMAs
-        __builtin_amdgcn_sched_barrier(0);               // keep all 8 reads in front of the 16 MFMAs that hide them
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) { OESS_MFMA(i, j, fa1, fb1) }
-    }
-#undef OESS_FR
-#undef OESS_MFMA
-#undef OESS_WAITF
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // dummy slabs must land before the epilogue reuses the LDS
-    __syncthreads();
-
-    if constexpr (EPI == 1) lstm_epilogue<MT, NT>(a, acc, smem, m0, n0, wm, wn, lane, tid);
-    else conv_epilogue<BMX, BN, BN + 8, 256, 2>(a, acc, smem, m0, n0, wm, wn, lane, tid);
-}
-
-// =================================================================================================
-// v3: PERSISTENT LDS-DMA kernel.  Same tile, ring and fragment pipeline as conv_fwd_dma_kernel<128, BN, 2>,
-// but one workgroup walks a strided list of output tiles of its XCD:
-//   * the first K-slab of the NEXT tile is DMA'd under the last K-slab of the current one, so a tile's
-//     pipeline fill (decode + issue + ~1 us DMA round trip) and the workgroup launch disappear from the
-//     critical path (tools/probes/mfma_loop_probe.hip: the bare K loop runs 1.22 PF as 4400 short workgroups
-//     and 1.43 PF as 512 persistent ones at K = 2304);
-//   * the epilogue's global stores are never waited for: the next tile's slab 0 is retired BEFORE the
-//     epilogue (vmcnt(0) there is the only full drain), its first barrier needs no vmcnt, and the stores
-//     complete under its first slab;
-//   * the bf16 output image is parked, unpadded, in the ring stage that was read last (exactly 32 KB at
-//     BN = 128), the other stage already holds the next tile's slab 0.
-// =================================================================================================
-__device__ __forceinline__ int div_small(int m, int d, float rcp) {     // exact for 0 <= m < 2^22
-    int q = (int)((float)m * rcp);
-    const int r = m - q * d;
-    q -= (r < 0);
-    q += (r >= d);
-    return q;
-}
-
-template <int BN, bool FASTK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_fwd_persist_kernel(ConvArgs a) {
-    constexpr int BMX = 128, NSTAGE = 2, NWAVES = 4;
-    constexpr int WAVES_N = (BN == 128) ? 2 : 1;
-    constexpr int WAVES_M = NWAVES / WAVES_N;
-    constexpr int WM = BMX / WAVES_M;
-    constexpr int WN = BN / WAVES_N;
-    constexpr int MT = WM / 32, NT = WN / 32;
-    constexpr int A_INSTR = BMX * 8 / 64 / NWAVES;
-    constexpr int B_INSTR = BN * 8 / 64 / NWAVES;
-    constexpr int STAGE_BYTES = (BMX + BN) * 8 * 16;
-    constexpr int NFRAG = MT + NT;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* red = reinterpret_cast<float*>(smem + NSTAGE * STAGE_BYTES);
-
-    // ---- tile schedule: XCD x owns the contiguous tile range [lo, lo + cnt); its workgroups stride through it,
-    // so at any time one XCD's L2 holds a compact band of input rows and all n-tiles of the same m-tiles.
-    const int nt_all = a.tiles_m * a.tiles_n;
-    const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
-    int t, t_end;
-    {
-        const int q = nt_all >> 3, r = nt_all & 7;
-        const int lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        t = lo + wslot;
-        t_end = lo + q + (xcd < r ? 1 : 0);
-    }
-    if (t >= t_end) return;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int KT = a.Kpad / BK;
-    const int cpt = a.Cin >> 3, ntaps = a.R * a.S;
-    const int hw = a.Ho * a.Wo;
-
-    const long long in_bytes = (((long long)a.B * a.H * a.W - 1) * a.in_pix_stride + a.Cin) * 2;
-    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)in_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7ffffff0, 0x00020000);
-
-    const int lrow = lane >> 3, slot = lane & 7;
-    int iy0[A_INSTR], ix0[A_INSTR], rowoff[A_INSTR], csrc[A_INSTR], boff[B_INSTR], bbase[B_INSTR];
-#pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) csrc[i] = slot ^ ((((wave * A_INSTR + i) * 8 + lrow) >> 1) & 7);
-#pragma unroll
-    for (int i = 0; i < B_INSTR; ++i) {
-        const int r = (wave * B_INSTR + i) * 8 + lrow;
-        bbase[i] = (r * a.Kpad + (slot ^ ((r >> 1) & 7)) * 8) * 2;
-    }
-    int m0 = 0, n0 = 0;
-    // per-tile row decode of the gather lanes (float-reciprocal division: exact below 2^22 rows, host checked)
-    auto setup = [&](int tile) {
-        const int tile_n = tile % a.tiles_n, tile_m = tile / a.tiles_n;
-        m0 = tile_m * BMX;
-        n0 = tile_n * BN;
-#pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) {
-            const int r = (wave * A_INSTR + i) * 8 + lrow;
-            const int m = m0 + r;
-            const bool valid = m < a.M;
-            const int mm = valid ? m : 0;
-            const int b = div_small(mm, hw, a.rcp_hw), rem = mm - b * hw;
-            const int oy = div_small(rem, a.Wo, a.rcp_wo), ox = rem - oy * a.Wo;
-            iy0[i] = valid ? oy * a.stride - a.pad : -0x4000;
-            ix0[i] = ox * a.stride - a.pad;
-            rowoff[i] = (int)((((long long)b * a.H + (oy * a.stride - a.pad)) * a.W + ix0[i]) * a.in_pix_stride * 2);
-        }
-#pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) boff[i] = bbase[i] + n0 * a.Kpad * 2;
-    };
-
-    auto issue = [&](int kt, int stage) {
-        unsigned char* st = smem + stage * STAGE_BYTES;
-        if constexpr (FASTK) {
-            const unsigned kc0 = (unsigned)(kt * 8);
-            const unsigned tap = (kc0 * a.inv_cpt) >> 20;
-            const int cc0 = (int)(kc0 - tap * cpt);
-            const unsigned r = (tap * a.inv_s) >> 16;
-            const int sx = (int)(tap - r * a.S);
-            const int dy = (int)r * a.dil, dx = sx * a.dil;
-            const int tapoff = ((dy * a.W + dx) * (int)a.in_pix_stride + cc0 * 8) * 2;
-            const bool tap_ok = (int)tap < ntaps;
-#pragma unroll
-            for (int i = 0; i < A_INSTR; ++i) {
-                const bool ok = tap_ok && (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
-                const unsigned voff = ok ? (unsigned)(rowoff[i] + csrc[i] * 16 + tapoff) : 0x80000000u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave * A_INSTR + i) * 1024),
-                                                         16, voff, 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < A_INSTR; ++i) {
-                const unsigned kc = (unsigned)(kt * 8 + csrc[i]);
-                const unsigned tap = (kc * a.inv_cpt) >> 20;
-                const int cc = (int)(kc - tap * cpt);
-                const unsigned r = (tap * a.inv_s) >> 16;
-                const int sx = (int)(tap - r * a.S);
-                const int dy = (int)r * a.dil, dx = sx * a.dil;
-                const bool ok = (int)tap < ntaps && (unsigned)(iy0[i] + dy) < (unsigned)a.H && (unsigned)(ix0[i] + dx) < (unsigned)a.W;
-                const unsigned voff = ok ? (unsigned)(rowoff[i] + ((dy * a.W + dx) * (int)a.in_pix_stride + cc * 8) * 2) : 0x80000000u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave * A_INSTR + i) * 1024),
-                                                         16, voff, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_INSTR; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(st + BMX * 128 + (wave * B_INSTR + i) * 1024),
-                                                     16, (unsigned)(boff[i] + kt * BK * 2), 0, 0, 0);
-    };
-
-    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-    uint32_t fa_off[MT], fb_off[NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) fa_off[i] = (uint32_t)(wm * WM + i * 32 + (lane & 31)) * 128;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) fb_off[j] = (uint32_t)(BMX * 128 + (wn * WN + j * 32 + (lane & 31)) * 128);
-    const int half = lane >> 5;
-    const int rsw = ((lane & 31) >> 1) & 7;
-
-#define OESS_FRAG_READ(DST_A, DST_B, KS)                                                                         \
-    {                                                                                                            \
-        const uint32_t sl_ = (uint32_t)((((KS) * 2 + half) ^ rsw) * 16);                                         \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                           \
-            asm volatile("ds_read_b128 %0, %1" : "=v"(DST_A[i]) : "v"(stage_ + fa_off[i] + sl_) : "memory");   \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                           \
-            asm volatile("ds_read_b128 %0, %1" : "=v"(DST_B[j]) : "v"(stage_ + fb_off[j] + sl_) : "memory");   \
-    }
-#define OESS_FRAG_MMA(SRC_A, SRC_B)                                                                              \
-    {                                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                           \
-            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                       \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(SRC_A[i], SRC_B[j], acc[i][j], 0, 0, 0);     \
-    }
-#define OESS_WAIT_FRAGS(N_, FA_, FB_)                                                                            \
-    {                                                                                                            \
-        if constexpr (MT == 2 && NT == 2)                                                                        \
-            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(FA_[0]), "+v"(FA_[1]), "+v"(FB_[0]), "+v"(FB_[1]) : "n"(N_) : "memory"); \
-        else if constexpr (MT == 1 && NT == 2)                                                                   \
-            asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(FA_[0]), "+v"(FB_[0]), "+v"(FB_[1]) : "n"(N_) : "memory"); \
-        else                                                                                                     \
-            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(FA_[0]), "+v"(FB_[0]) : "n"(N_) : "memory");             \
-    }
-
-    setup(t);
-    issue(0, 0);
-    int g = 0;                  // ring position of the slab consumed next (runs across tiles)
-    bool drain = true;          // slab 0 of the first tile still has to be waited for
-    for (;;) {
-        f32x16_t acc[MT][NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-        const int m0c = m0, n0c = n0;
-        const int tn = t + nslot;
-        const bool has_next = tn < t_end;
-        for (int kt = 0; kt < KT; ++kt) {
-            if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            drain = true;
-            __builtin_amdgcn_s_barrier();
-            if (kt + 1 < KT) issue(kt + 1, (g + 1) & 1);
-            else if (has_next) { setup(tn); issue(0, (g + 1) & 1); }
-            const uint32_t stage_ = lds0 + (uint32_t)((g & 1) * STAGE_BYTES);
-            bf16x8_t fa0[MT], fb0[NT], fa1[MT], fb1[NT];
-            OESS_FRAG_READ(fa0, fb0, 0)
-            OESS_FRAG_READ(fa1, fb1, 1)
-            OESS_WAIT_FRAGS(NFRAG, fa0, fb0)
-            OESS_FRAG_MMA(fa0, fb0)
-            OESS_FRAG_READ(fa0, fb0, 2)
-            OESS_WAIT_FRAGS(NFRAG, fa1, fb1)
-            OESS_FRAG_MMA(fa1, fb1)
-            OESS_FRAG_READ(fa1, fb1, 3)
-            OESS_WAIT_FRAGS(NFRAG, fa0, fb0)
-            OESS_FRAG_MMA(fa0, fb0)
-            OESS_WAIT_FRAGS(0, fa1, fb1)
-            OESS_FRAG_MMA(fa1, fb1)
-            ++g;
-        }
-        // retire the prefetched slab 0 of the next tile, then everybody is done with the stage read last
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        conv_epilogue<BMX, BN, BN>(a, acc, smem + ((g - 1) & 1) * STAGE_BYTES, m0c, n0c, wm, wn, lane, tid, red);
-        if (!has_next) break;
-        t = tn;
-        drain = false;          // slab 0 is in LDS already; the epilogue's stores complete under it
-    }
-#undef OESS_FRAG_READ
-#undef OESS_FRAG_MMA
-#undef OESS_WAIT_FRAGS
-}
 
 // =================================================================================================
 // Small-Cin convolution (Cin == 8: one 16-byte chunk per pixel, e.g. the E2VID head on the 5-bin voxel grid padded
@@ -1707,39 +1321,23 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
     a.lstm_h = lstm ? (uint16_t*)lstm->h : nullptr; a.lstm_h_stride = lstm ? lstm->h_stride : 0; a.lstm_C = lstm ? lstm->C : 0;
     a.tiles_m = (a.M + BM - 1) / BM;
     hipStream_t st = (hipStream_t)stream;
-    // implementation selector (A/B testing): OESS_CONV_IMPL = v1 | dma2 | dma3 | dma4 ; default below
-    static int impl = -1;
-    if (impl < 0) {
-        const char* e = getenv("OESS_CONV_IMPL");
-        impl = 2;       // measured best: 2-stage LDS-DMA ring, 2 workgroups per CU (bench_conv.py)
-        if (e) {
-            if (!strcmp(e, "v1")) impl = 0;
-            else if (!strcmp(e, "dma2")) impl = 2;
-            else if (!strcmp(e, "dma3")) impl = 3;
-            else if (!strcmp(e, "persist")) impl = 4;
-            else if (!strcmp(e, "dma32")) impl = 5;
-        }
+    static bool attrs_set = false;
+    if (!attrs_set) {       // > 64 KiB of dynamic LDS needs an explicit opt-in
         const void* fns[] = {(const void*)&conv_fwd_kernel<128>, (const void*)&conv_fwd_kernel<64>, (const void*)&conv_fwd_kernel<32>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<128, 64, 2, false>, (const void*)&conv_fwd_dma_kernel<128, 32, 2, false>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 2, true>, (const void*)&conv_fwd_dma_kernel<128, 64, 2, true>, (const void*)&conv_fwd_dma_kernel<128, 32, 2, true>,
-                             (const void*)&conv_fwd_dma_kernel<128, 128, 3, false>, (const void*)&conv_fwd_dma_kernel<128, 64, 3, false>, (const void*)&conv_fwd_dma_kernel<128, 32, 3, false>,
-                             (const void*)&conv_fwd_dma_kernel<256, 128, 3, false>, (const void*)&conv_fwd_dma_kernel<256, 128, 3, true>,
-                             (const void*)&conv_fwd_dma_kernel<256, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<256, 128, 2, true>,
+                             (const void*)&conv_fwd_dma_kernel<64, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<64, 128, 2, true>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 2, false, 1>, (const void*)&conv_fwd_dma_kernel<128, 128, 2, true, 1>,
-                             (const void*)&conv_fwd_t256_kernel<0>, (const void*)&conv_fwd_t256_kernel<1>,
                              (const void*)&conv3x3_halo_kernel<0>, (const void*)&conv3x3_halo_kernel<1>,
-                             (const void*)&conv_fwd_dma32_kernel<128, false, 0>, (const void*)&conv_fwd_dma32_kernel<128, true, 0>,
-                             (const void*)&conv_fwd_dma32_kernel<64, false, 0>, (const void*)&conv_fwd_dma32_kernel<64, true, 0>,
-                             (const void*)&conv_fwd_dma32_kernel<128, false, 1>, (const void*)&conv_fwd_dma32_kernel<128, true, 1>,
-                             (const void*)&conv_fwd_persist_kernel<128, false>, (const void*)&conv_fwd_persist_kernel<64, false>, (const void*)&conv_fwd_persist_kernel<32, false>,
-                             (const void*)&conv_fwd_persist_kernel<128, true>, (const void*)&conv_fwd_persist_kernel<64, true>, (const void*)&conv_fwd_persist_kernel<32, true>};
-        for (const void* f : fns)      // > 64 KiB of dynamic LDS needs an explicit opt-in
-            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                             (const void*)&conv_fwd_dma32_kernel<128, true, 0, 3>};
+        for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attrs_set = true;
     }
+    // The LDS-DMA kernels address the input with 32-bit buffer offsets and decode filter taps with exact small-range
+    // reciprocals (verified here over the whole range); anything outside takes the register-staged generic kernel.
     const long long in_extent = (((long long)B * H * W - 1) * in_pix_stride + Cin) * 2;
-    int use = (in_extent >= 0x7ffffff0ll) ? 0 : impl;              // 32-bit buffer offsets in the DMA kernels
     bool dma_ok = in_extent < 0x7ffffff0ll;
-    {   // exact reciprocals for the in-kernel tap arithmetic (checked over the whole range; else fall back)
+    {
         const unsigned cpt = (unsigned)(Cin >> 3), nkc = (unsigned)(a.Kpad / 8);
         a.inv_cpt = ((1u << 20) + cpt - 1) / cpt;
         a.inv_s = ((1u << 16) + (unsigned)S - 1) / (unsigned)S;
@@ -1747,196 +1345,94 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
         for (unsigned kc = 0; exact && kc < nkc; ++kc) exact = ((kc * a.inv_cpt) >> 20) == kc / cpt;
         const unsigned maxtap = nkc / cpt + 1;
         for (unsigned t = 0; exact && t <= maxtap; ++t) exact = ((t * a.inv_s) >> 16) == t / (unsigned)S;
-        if (!exact) { use = 0; dma_ok = false; }
-        a.rcp_hw = 1.0f / (float)(a.Ho * a.Wo);
-        a.rcp_wo = 1.0f / (float)a.Wo;
-        if (use == 4 && M >= (1ll << 22)) use = 2;     // float-reciprocal row decode is exact below 2^22 rows
+        if (!exact) dma_ok = false;
     }
     // the packed weight has Npad = multiple of 128 rows, so any BN <= 128 tiles it safely
     const int bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
     a.tiles_n = (Cout + bn - 1) / bn;
     const dim3 grid(a.tiles_m * a.tiles_n), block(CONV_THREADS);
-    const size_t tab = (size_t)(a.Kpad / 8) * 8;
-    const bool fastk = (Cin % 64) == 0 && !getenv("OESS_CONV_NOFASTK");
-    const bool fastk32 = (Cin % 32) == 0 && !getenv("OESS_CONV_NOFASTK");
+    const bool fastk = (Cin % 64) == 0, fastk32 = (Cin % 32) == 0;
     const size_t epi = (size_t)BM * (bn + 8) * 2 + 4096;     // output image + BatchNorm partials
-#define OESS_LAUNCH_V1(BN_)                                                                  \
-    {                                                                                        \
-        size_t lds = (size_t)2 * (BM + BN_) * 8 * 16 + tab;                                  \
-        if (lds < epi) lds = epi;                                                            \
-        hipLaunchKernelGGL(conv_fwd_kernel<BN_>, grid, block, lds, st, a);                   \
-    }
-#define OESS_LAUNCH_DMA(BN_, NS_)                                                            \
-    {                                                                                        \
-        size_t lds = (size_t)NS_ * (BM + BN_) * 8 * 16;                                      \
-        if (lds < epi) lds = epi;                                                            \
-        if (fastk) hipLaunchKernelGGL((conv_fwd_dma_kernel<128, BN_, NS_, true>), grid, block, lds, st, a);   \
-        else hipLaunchKernelGGL((conv_fwd_dma_kernel<128, BN_, NS_, false>), grid, block, lds, st, a);        \
-    }
-#define OESS_LAUNCH_PERSIST(BN_)                                                             \
-    {                                                                                        \
-        const size_t lds = (size_t)2 * (BM + BN_) * 8 * 16 + 2048;                           \
-        const int nt_ = a.tiles_m * a.tiles_n;                                               \
-        const dim3 pgrid(nt_ >= 512 ? 512 : (nt_ + 7) / 8 * 8);                              \
-        if (fastk) hipLaunchKernelGGL((conv_fwd_persist_kernel<BN_, true>), pgrid, block, lds, st, a);   \
-        else hipLaunchKernelGGL((conv_fwd_persist_kernel<BN_, false>), pgrid, block, lds, st, a);        \
-    }
-#define OESS_LAUNCH_DMA32(BN_)                                                               \
-    {                                                                                        \
-        if (BN_ >= 64) {                                                                     \
-            constexpr int BNX = BN_ >= 64 ? BN_ : 64;                                        \
-            size_t lds = (size_t)4 * (BM + BNX) * 64;                                        \
-            if (lds < epi) lds = epi;                                                        \
-            static int nst3 = -1;                                                            \
-            if (nst3 < 0) { const char* e_ = getenv("OESS_CONV_DMA32_NST"); nst3 = (e_ && atoi(e_) == 3) ? 1 : 0; }   \
-            if (nst3 && fastk32) {                                                           \
-                size_t lds3 = (size_t)3 * (BM + BNX) * 64;                                   \
-                if (lds3 < epi) lds3 = epi;                                                  \
-                hipLaunchKernelGGL((conv_fwd_dma32_kernel<BNX, true, 0, 3>), grid, block, lds3, st, a);   \
-            } else                                                                           \
-            if (fastk32) hipLaunchKernelGGL((conv_fwd_dma32_kernel<BNX, true, 0>), grid, block, lds, st, a);   \
-            else hipLaunchKernelGGL((conv_fwd_dma32_kernel<BNX, false, 0>), grid, block, lds, st, a);          \
-        } else OESS_LAUNCH_DMA(BN_, 2)                                                       \
-    }
-#define OESS_DISPATCH(BN_)                                                                   \
-    switch (use) {                                                                           \
-        case 2: OESS_LAUNCH_DMA(BN_, 2) break;                                               \
-        case 4: OESS_LAUNCH_PERSIST(BN_) break;                                              \
-        case 5: OESS_LAUNCH_DMA32(BN_) break;                                                \
-        case 3: OESS_LAUNCH_DMA(BN_, 3) break;                                               \
-        default: OESS_LAUNCH_V1(BN_) break;                                                  \
-    }
-    // Cin == 8 stencil layers (E2VID head): LDS halo tile instead of the im2col gather
-    static int smallcin = -1;
-    if (smallcin < 0) { const char* e = getenv("OESS_CONV_SMALLCIN"); smallcin = e ? atoi(e) : 1; }
-    if (smallcin && !lstm && Cin == 8 && stride == 1 && dil == 1 && R == 5 && S == 5 && Cout <= 32 && (Cout & 3) == 0 &&
-        !residual && !out_f32 && !tile_stats && (out_pix_stride & 3) == 0 && a.Kpad == 256) {
+    // tile-quantisation model shared by the rules below: 128-row tiles run two workgroups per CU (512 slots), 64-row tiles
+    // three (768 slots) at 0.88 of the per-tile efficiency (measured)
+    const long long t128 = (long long)a.tiles_m * a.tiles_n;
+    const long long t64 = (long long)((a.M + 63) / 64) * a.tiles_n;
+    const double e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
+    const double e64 = 0.88 * (double)t64 / (double)(((t64 + 767) / 768) * 768);
+    const bool want64 = bn == 128 && !tile_stats && !lstm && e64 > e128 * 1.04;
+
+    // (1) Cin == 8 stencil layers (E2VID head): LDS halo tile instead of the im2col gather
+    if (!lstm && Cin == 8 && stride == 1 && dil == 1 && R == 5 && S == 5 && Cout <= 32 && (Cout & 3) == 0 && !residual && !out_f32 &&
+        !tile_stats && (out_pix_stride & 3) == 0 && a.Kpad == 256 && dma_ok) {
         const int tiles = B * ((a.Ho + 7) / 8) * ((a.Wo + 63) / 64);
-        static int sc_wgs = -1;
-        if (sc_wgs < 0) { const char* e = getenv("OESS_SMALLCIN_WGS"); sc_wgs = e ? atoi(e) : 512; }     // 2 resident workgroups per CU (242 registers per lane)
-        hipLaunchKernelGGL((conv_smallcin_kernel<5, 5>), dim3(tiles < sc_wgs ? tiles : sc_wgs), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_smallcin_kernel<5, 5>), dim3(tiles < 512 ? tiles : 512), dim3(256), 0, st, a);   // persistent: 2 workgroups per CU
         OESS_HIP(hipGetLastError());
         return OESS_OK;
     }
-    // 3x3 stride-1 'same' convolutions with Cin % 64 == 0: row-halo reuse of the pixel operand (conv3x3_halo_kernel), unless the
-    // 64-row tiling below is what the layer wants (tile quantisation of small maps).
-    static int halo = -1;
-    if (halo < 0) { const char* e = getenv("OESS_CONV_HALO"); halo = e ? atoi(e) : 1; }
-    if (halo && dma_ok && use == 2 && R == 3 && S == 3 && stride == 1 && pad == dil && (Cin % 64) == 0 && bn == 128 &&
-        a.Kpad == 9 * Cin && a.Ho == H && a.Wo == W && (dil + 127 + dil * ((BM + W - 2) / W) + dil + 1) <= HALO_ROWS) {
-        const long long t128 = (long long)a.tiles_m * a.tiles_n;
-        const long long t64 = (long long)((a.M + 63) / 64) * a.tiles_n;
-        const double e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
-        const double e64 = 0.88 * (double)t64 / (double)(((t64 + 767) / 768) * 768);
-        if (lstm || tile_stats || halo == 2 || !(e64 > e128 * 1.04)) {
-            const size_t lds = (size_t)2 * HALO_ROWS * 128 + (size_t)2 * 128 * 128;
-            if (lstm) hipLaunchKernelGGL((conv3x3_halo_kernel<1>), grid, block, lds, st, a);
-            else hipLaunchKernelGGL((conv3x3_halo_kernel<0>), grid, block, lds, st, a);
-            OESS_HIP(hipGetLastError());
-            return OESS_OK;
-        }
+    if (!dma_ok) {
+        if (lstm) return OESS_EINVAL;       // the fused ConvLSTM epilogue exists only in the LDS-DMA kernels
+        const size_t tab = (size_t)(a.Kpad / 8) * 8;
+        size_t lds = (size_t)2 * (BM + bn) * 8 * 16 + tab;
+        if (lds < epi) lds = epi;
+        if (bn == 128) hipLaunchKernelGGL(conv_fwd_kernel<128>, grid, block, lds, st, a);
+        else if (bn == 64) hipLaunchKernelGGL(conv_fwd_kernel<64>, grid, block, lds, st, a);
+        else hipLaunchKernelGGL(conv_fwd_kernel<32>, grid, block, lds, st, a);
+        OESS_HIP(hipGetLastError());
+        return OESS_OK;
     }
-    // 256 x 256 tile, 4 waves x (128 x 128), software-pipelined BK = 32 ring (conv_fwd_t256_kernel).  Measured
-    // (tools/conv_ablate.py, same box): while all 256 CUs hold a tile it runs 1150 TF/s against 1030 TF/s for the
-    // 128 x 128 kernel (+11 %), but one workgroup per CU means 256 slots, and on the model's shapes the coarser tile
-    // quantisation gives all of it back (gates / gk4: 1100 tiles = 4.3 rounds -> 5; 989 vs 986 TF/s end to end), and
-    // small layers lose outright.  Opt-in until the remainder is balanced stream-K style:
-    // OESS_CONV_T256 = 0 off (default), 1 when the round model predicts a gain, 2 always (when legal).
-    static int t256 = -1;
-    if (t256 < 0) { const char* e = getenv("OESS_CONV_T256"); t256 = e ? atoi(e) : 0; }
-    if (use == 2 && t256 && (Cout % 256) == 0 && fastk32) {
-        const long long tm = (a.M + 255) / 256, tn = Cout / 256, t = tm * tn;
-        const long long t128 = (long long)a.tiles_m * a.tiles_n;
-        const double e256 = 1.11 * (double)t / (double)(((t + 255) / 256) * 256);
-        const double e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
-        if (t256 == 2 || (t >= 512 && e256 > e128 * 1.03)) {
-            a.tiles_m = (int)tm; a.tiles_n = (int)tn;
-            const size_t lds = lstm ? (size_t)4 * 512 * 64 : (size_t)256 * (256 + 8) * 2 + 4096;   // ring 128 KB; output image 132 KB + partials
-            if (lstm) hipLaunchKernelGGL((conv_fwd_t256_kernel<1>), dim3((unsigned)t), dim3(256), lds, st, a);
-            else hipLaunchKernelGGL((conv_fwd_t256_kernel<0>), dim3((unsigned)t), dim3(256), lds, st, a);
-            OESS_HIP(hipGetLastError());
-            return OESS_OK;
-        }
+    // (2) 3x3 stride-1 'same' convolutions with Cin % 64 == 0: row-halo reuse of the pixel operand, unless the 64-row tiling
+    //     is what the layer wants (tile quantisation of small maps)
+    if (R == 3 && S == 3 && stride == 1 && pad == dil && fastk && bn == 128 && a.Kpad == 9 * Cin && a.Ho == H && a.Wo == W &&
+        (dil + 127 + dil * ((BM + W - 2) / W) + dil + 1) <= HALO_ROWS && !want64) {
+        const size_t lds = (size_t)2 * HALO_ROWS * 128 + (size_t)2 * 128 * 128;
+        if (lstm) hipLaunchKernelGGL((conv3x3_halo_kernel<1>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((conv3x3_halo_kernel<0>), grid, block, lds, st, a);
+        OESS_HIP(hipGetLastError());
+        return OESS_OK;
     }
-    if (lstm) {     // fused ConvLSTM cell update: transposed MFMA + lane-local gate algebra (needs the LDS-DMA kernel)
-        if (use < 2) {      // the fused epilogue exists only in the LDS-DMA kernels (32-bit offsets, exact tap reciprocals)
-            if (!dma_ok) return OESS_EINVAL;
-            use = 2;        // OESS_CONV_IMPL=v1 (debug knob) does not apply to this entry point
-        }
+    // (3) fused ConvLSTM cell update on geometries the halo kernel does not take
+    if (lstm) {
         const size_t lds = (size_t)2 * (BM + 128) * 8 * 16;
-        if (use == 5) {
-            if (fastk32) hipLaunchKernelGGL((conv_fwd_dma32_kernel<128, true, 1>), grid, block, lds, st, a);
-            else hipLaunchKernelGGL((conv_fwd_dma32_kernel<128, false, 1>), grid, block, lds, st, a);
-        } else
         if (fastk) hipLaunchKernelGGL((conv_fwd_dma_kernel<128, 128, 2, true, 1>), grid, block, lds, st, a);
         else hipLaunchKernelGGL((conv_fwd_dma_kernel<128, 128, 2, false, 1>), grid, block, lds, st, a);
         OESS_HIP(hipGetLastError());
         return OESS_OK;
     }
-    // Short reductions (K <= 256, i.e. the 1x1 bottleneck convs): a workgroup lives ~6 us of which the K loop is a
-    // fraction (launch, first DMA round trip, store acknowledgements), so residency matters more than the main loop:
-    // BK = 32 slabs in a 3-deep ring = 48 KB -> 3 workgroups per CU.  tools/conv_ablate.py: K=64 0.121 -> 0.096 ms,
-    // K=256 (pw) 0.0414 -> 0.0369 ms; from K = 512 up the BK = 64 kernel wins again (half the barriers per FLOP).
-    static int shortk = -1;
-    if (shortk < 0) { const char* e = getenv("OESS_CONV_SHORTK"); shortk = e ? atoi(e) : 1; }
-    if (use == 2 && shortk && bn == 128 && fastk32 && a.Kpad <= 256) {
+    // (4) short reductions (K <= 256, the 1x1 bottleneck convs): a workgroup lives ~6 us of which the K loop is a fraction, so
+    //     residency matters more than the main loop: BK = 32 slabs in a 3-deep ring = 48 KB -> 3 workgroups per CU
+    //     (K = 64: 0.121 -> 0.096 ms, K = 256: 0.0414 -> 0.0369 ms; from K = 512 up the BK = 64 kernel wins again)
+    if (bn == 128 && fastk32 && a.Kpad <= 256) {
         size_t lds3 = (size_t)3 * (BM + 128) * 64;
         if (lds3 < epi) lds3 = epi;
         hipLaunchKernelGGL((conv_fwd_dma32_kernel<128, true, 0, 3>), grid, block, lds3, st, a);
         OESS_HIP(hipGetLastError());
         return OESS_OK;
     }
-    // 64 x 128 tiles (48 KB of LDS: 3 workgroups per CU) when the 128-row tiling leaves most of its last round of
-    // workgroups empty: e.g. 550 tiles over 512 slots run as two rounds at 54 % - 1100 half tiles over 768 slots do not.
-    static int small_m = -1;
-    if (small_m < 0) { const char* e = getenv("OESS_CONV_BM64"); small_m = e ? atoi(e) : 1; }
-    if (use == 2 && small_m && bn == 128 && !tile_stats) {
-        const long long t128 = (long long)a.tiles_m * a.tiles_n;
-        const long long t64 = (long long)((a.M + 63) / 64) * a.tiles_n;
-        const double e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
-        const double e64 = 0.88 * (double)t64 / (double)(((t64 + 767) / 768) * 768);      // 0.88: measured per-tile efficiency
-        if (small_m == 2 || e64 > e128 * 1.04) {
-            a.tiles_m = (a.M + 63) / 64;
-            const dim3 grid64(a.tiles_m * a.tiles_n);
-            size_t lds = (size_t)2 * (64 + 128) * 8 * 16;
-            const size_t epi64 = (size_t)64 * (128 + 8) * 2 + 4096;
-            if (lds < epi64) lds = epi64;
-            if (fastk) hipLaunchKernelGGL((conv_fwd_dma_kernel<64, 128, 2, true>), grid64, block, lds, st, a);
-            else hipLaunchKernelGGL((conv_fwd_dma_kernel<64, 128, 2, false>), grid64, block, lds, st, a);
-            OESS_HIP(hipGetLastError());
-            return OESS_OK;
-        }
+    // (5) 64 x 128 tiles (48 KB of LDS: 3 workgroups per CU) when the 128-row tiling leaves most of its last round of
+    //     workgroups empty: e.g. 550 tiles over 512 slots run as two rounds at 54 % - 1100 half tiles over 768 slots do not
+    if (want64) {
+        a.tiles_m = (a.M + 63) / 64;
+        const dim3 grid64(a.tiles_m * a.tiles_n);
+        size_t lds = (size_t)2 * (64 + 128) * 8 * 16;
+        const size_t epi64 = (size_t)64 * (128 + 8) * 2 + 4096;
+        if (lds < epi64) lds = epi64;
+        if (fastk) hipLaunchKernelGGL((conv_fwd_dma_kernel<64, 128, 2, true>), grid64, block, lds, st, a);
+        else hipLaunchKernelGGL((conv_fwd_dma_kernel<64, 128, 2, false>), grid64, block, lds, st, a);
+        OESS_HIP(hipGetLastError());
+        return OESS_OK;
     }
-    // 256 x 128 tile, 8 waves, 1 workgroup per CU: 25 % fewer L2->LDS bytes per FLOP.  Measured neutral against the
-    // 128-row kernel (tools/conv_ablate.py: +-3 % per layer) because the wave tile, hence the LDS fragment traffic,
-    // is unchanged, so it is opt-in: OESS_CONV_BIG=3 (3-slab ring) or 2 (2-slab ring).
-    static int big = -1;
-    if (big < 0) { const char* e = getenv("OESS_CONV_BIG"); big = e ? atoi(e) : 0; }
-    const int tiles_m256 = (a.M + 255) / 256;
-    if (use >= 2 && big > 0 && bn == 128 && (long long)tiles_m256 * a.tiles_n >= 768) {
-        a.tiles_m = tiles_m256;
-        const dim3 grid2(a.tiles_m * a.tiles_n);
-        const size_t epi2 = (size_t)256 * (128 + 8) * 2 + 4096;
-        if (big == 3) {
-            size_t lds = (size_t)3 * (256 + 128) * 8 * 16;
-            if (lds < epi2) lds = epi2;
-            if (fastk) hipLaunchKernelGGL((conv_fwd_dma_kernel<256, 128, 3, true>), grid2, dim3(512), lds, st, a);
-            else hipLaunchKernelGGL((conv_fwd_dma_kernel<256, 128, 3, false>), grid2, dim3(512), lds, st, a);
-        } else {
-            size_t lds = (size_t)2 * (256 + 128) * 8 * 16;
-            if (lds < epi2) lds = epi2;
-            if (fastk) hipLaunchKernelGGL((conv_fwd_dma_kernel<256, 128, 2, true>), grid2, dim3(512), lds, st, a);
-            else hipLaunchKernelGGL((conv_fwd_dma_kernel<256, 128, 2, false>), grid2, dim3(512), lds, st, a);
-        }
-    } else
-    if (bn == 128) OESS_DISPATCH(128)
-    else if (bn == 64) OESS_DISPATCH(64)
-    else OESS_DISPATCH(32)
-#undef OESS_DISPATCH
+    // (6) the general LDS-DMA kernel: 128 x {128, 64, 32} tiles, 2-stage ring, 2 workgroups per CU
+    {
+        size_t lds = (size_t)2 * (BM + bn) * 8 * 16;
+        if (lds < epi) lds = epi;
+#define OESS_LAUNCH_DMA(BN_)                                                                                  \
+        if (fastk) hipLaunchKernelGGL((conv_fwd_dma_kernel<128, BN_, 2, true>), grid, block, lds, st, a);        \
+        else hipLaunchKernelGGL((conv_fwd_dma_kernel<128, BN_, 2, false>), grid, block, lds, st, a);
+        if (bn == 128) { OESS_LAUNCH_DMA(128) }
+        else if (bn == 64) { OESS_LAUNCH_DMA(64) }
+        else { OESS_LAUNCH_DMA(32) }
 #undef OESS_LAUNCH_DMA
-#undef OESS_LAUNCH_PERSIST
-#undef OESS_LAUNCH_DMA32
-#undef OESS_LAUNCH_V1
+    }
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }

@@ -218,15 +218,12 @@ int oess_conv2d_wgrad_bf16(const void* x, long long x_pix_stride, int B, int H, 
     a.Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
     if (a.Ho <= 0 || a.Wo <= 0) return OESS_EINVAL;
     a.Kdim = R * S * Cin_x;
-    static int narrow = -1;
-    if (narrow < 0) { const char* e = getenv("OESS_WGRAD_NARROW"); narrow = e ? atoi(e) : 1; }
-    const int tmv = (narrow && Cout <= 32) ? 32 : ((narrow && Cout <= 64) ? 64 : TM);
+    const int tmv = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : TM);      // narrow layers: 32- / 64-row tiles (-10 % on the decoder's 32/64-channel layers)
     a.tiles_m = (Cout + tmv - 1) / tmv;
     a.tiles_n = (a.Kdim + TN - 1) / TN;
     a.rows_total = B * a.Ho;
     const int tiles = a.tiles_m * a.tiles_n;
-    static int target = -1;
-    if (target < 0) { const char* e = getenv("OESS_WGRAD_TARGET"); target = e ? atoi(e) : 512; if (target < 1) target = 512; }
+    const int target = 512;
     int splits = (target + tiles - 1) / tiles;               // ~2 workgroups per CU: measured best (1024: +3 % step time on frame2recon from the larger partial-sum traffic)
     const size_t per_split = (size_t)a.tiles_m * tmv * a.tiles_n * TN * sizeof(float);
     if (per_split > workspace_bytes) return OESS_ENOMEM;

@@ -591,18 +591,14 @@ int oess_segment_mean_fwd(const void* feat, int is_bf16, const int64_t* ids, int
     {   // vectorised kernel: Cf = LPP * (8 bf16 | 4 fp32 channels per lane), LPP in {8, 16, 32, 64}, 16-byte aligned rows
         const int cpl = is_bf16 ? 8 : 4;
         const int lpp = (Cf % cpl == 0) ? Cf / cpl : 0;
-        static int use_vec = -1;
-        if (use_vec < 0) { const char* e = getenv("OESS_SEGMEAN_VEC"); use_vec = e ? atoi(e) : 1; }
-        if (use_vec && (lpp == 8 || lpp == 16 || lpp == 32 || lpp == 64) && ((uintptr_t)feat & 15) == 0) {
+        if ((lpp == 8 || lpp == 16 || lpp == 32 || lpp == 64) && ((uintptr_t)feat & 15) == 0) {
             int vlocal = (int)((128 * 1024) / ((size_t)Cf * 4 + 4));      // ids held in the LDS table (<= 128 KB)
             if (vlocal > 256) vlocal = 256;
             const size_t lds = (size_t)vlocal * ((size_t)Cf * 4 + 4);
             // pixels per workgroup: aim at three full rounds of one workgroup per CU (measured at 8 x 440 x 640: 2048 px ->
-            // 0.436 ms, 3072 px -> 0.382 / 0.399 ms bf16 / fp32 = 38 % / 73 % of 8 TB/s); OESS_SEGMEAN_PIX overrides
-            static int ppw_env = -1;
-            if (ppw_env < 0) { const char* e = getenv("OESS_SEGMEAN_PIX"); ppw_env = e ? atoi(e) : 0; }
-            int ppw = ppw_env;
-            if (ppw < 64) {
+            // 0.436 ms, 3072 px -> 0.382 / 0.399 ms bf16 / fp32 = 38 % / 73 % of 8 TB/s)
+            int ppw = 0;
+            {
                 long long chunks = (3 * 256 + B / 2) / B;
                 if (chunks < 1) chunks = 1;
                 long long q = (pixels_per_sample + chunks - 1) / chunks;

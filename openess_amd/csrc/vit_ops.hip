@@ -3,8 +3,8 @@
 //   * LayerNorm over the channel axis of a [rows x C] bf16 token matrix (eps 1e-6 in the ViT)
 //   * multi-head self attention softmax(Q K^T / sqrt(d)) V for head dimension 64 from the fused in_proj output
 //     [B, L, 3C] (nn.MultiheadAttention's packed q | k | v layout), fp32 online softmax.
-// The attention is the small part of the tower (0.3 of 1.8 TFLOP at 8 x 1121 tokens), so it is a plain VALU kernel
-// with LDS-tiled K / V: 4 lanes own one query (16 head dims each), 64 queries per workgroup, 32 keys per tile.
+// The attention is an MFMA flash-attention kernel (a first VALU version, 4 lanes per query, took 16-18 ms per tower forward
+// against 1.25 ms and has been removed).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -89,90 +89,6 @@ __global__ __launch_bounds__(THREADS) void layernorm_vec_kernel(const uint16_t* 
                 *reinterpret_cast<uint4*>(y + r * ys + ch * 8) = pack_bf16x8(o);
             }
         }
-    }
-}
-
-// qkv: [B, L, 3*C] bf16 (row stride qs), C = heads * 64; out: [B, L, C] bf16 (row stride os)
-constexpr int QB = 64;       // queries per workgroup (4 lanes each)
-constexpr int KT = 32;       // keys per LDS tile
-__global__ __launch_bounds__(THREADS) void attention_d64_kernel(const uint16_t* __restrict__ qkv, int64_t qs, int B, int L, int heads,
-                                                                float scale, uint16_t* __restrict__ out, int64_t os) {
-    __shared__ __attribute__((aligned(16))) uint16_t lk[KT][64];
-    __shared__ __attribute__((aligned(16))) uint16_t lv[KT][64];
-    const int C = heads * 64;
-    const int qblocks = (L + QB - 1) / QB;
-    int bid = blockIdx.x;
-    const int qb = bid % qblocks; bid /= qblocks;
-    const int h = bid % heads;
-    const int b = bid / heads;
-    const int qi = qb * QB + (threadIdx.x >> 2), part = threadIdx.x & 3;
-    const bool q_ok = qi < L;
-    const uint16_t* base = qkv + (int64_t)b * L * qs;
-    float q[16], o[16];
-    {
-        const uint16_t* qp = base + (int64_t)(q_ok ? qi : 0) * qs + h * 64 + part * 16;
-        union { uint4 u[2]; uint16_t hh[16]; } r;
-        r.u[0] = *reinterpret_cast<const uint4*>(qp);
-        r.u[1] = *reinterpret_cast<const uint4*>(qp + 8);
-#pragma unroll
-        for (int d = 0; d < 16; ++d) { q[d] = bf16_to_f32(r.hh[d]) * scale; o[d] = 0.f; }
-    }
-    float m = -INFINITY, l = 0.f;
-    for (int k0 = 0; k0 < L; k0 += KT) {
-        __syncthreads();
-        {   // stage KT keys and values of this head: 32 rows x 128 B each = 256 threads x 16 B, twice
-            const int row = threadIdx.x >> 3, ch = threadIdx.x & 7;
-            const int kj = k0 + row;
-            uint4 kk = make_uint4(0u, 0u, 0u, 0u), vv = kk;
-            if (kj < L) {
-                const uint16_t* rp = base + (int64_t)kj * qs + h * 64 + ch * 8;
-                kk = *reinterpret_cast<const uint4*>(rp + C);
-                vv = *reinterpret_cast<const uint4*>(rp + 2 * C);
-            }
-            *reinterpret_cast<uint4*>(&lk[row][ch * 8]) = kk;
-            *reinterpret_cast<uint4*>(&lv[row][ch * 8]) = vv;
-        }
-        __syncthreads();
-        float s[KT];
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < KT; ++j) {
-            union { uint4 u[2]; uint16_t hh[16]; } r;
-            r.u[0] = *reinterpret_cast<const uint4*>(&lk[j][part * 16]);
-            r.u[1] = *reinterpret_cast<const uint4*>(&lk[j][part * 16 + 8]);
-            float a = 0.f;
-#pragma unroll
-            for (int d = 0; d < 16; ++d) a += q[d] * bf16_to_f32(r.hh[d]);
-            a += __shfl_xor(a, 1, 64);
-            a += __shfl_xor(a, 2, 64);
-            s[j] = (k0 + j < L) ? a : -INFINITY;
-            tmax = fmaxf(tmax, s[j]);
-        }
-        const float m_new = fmaxf(m, tmax);                  // finite: every tile holds at least one valid key
-        const float resc = __expf(m - m_new);                // exp(-inf) = 0 on the first tile
-        l *= resc;
-#pragma unroll
-        for (int d = 0; d < 16; ++d) o[d] *= resc;
-#pragma unroll
-        for (int j = 0; j < KT; ++j) {
-            const float p = __expf(s[j] - m_new);            // masked keys: exp(-inf) = 0
-            l += p;
-            union { uint4 u[2]; uint16_t hh[16]; } r;
-            r.u[0] = *reinterpret_cast<const uint4*>(&lv[j][part * 16]);
-            r.u[1] = *reinterpret_cast<const uint4*>(&lv[j][part * 16 + 8]);
-#pragma unroll
-            for (int d = 0; d < 16; ++d) o[d] += p * bf16_to_f32(r.hh[d]);
-        }
-        m = m_new;
-    }
-    if (q_ok) {
-        const float inv = 1.0f / l;
-        union { uint4 u[2]; uint16_t hh[16]; } r;
-#pragma unroll
-        for (int d = 0; d < 16; ++d) r.hh[d] = f32_to_bf16(o[d] * inv);
-        uint16_t* op = out + ((int64_t)b * L + qi) * os + h * 64 + part * 16;
-        *reinterpret_cast<uint4*>(op) = r.u[0];
-        *reinterpret_cast<uint4*>(op + 8) = r.u[1];
     }
 }
 
@@ -328,9 +244,7 @@ int oess_attention_d64_bf16(const void* qkv, long long qkv_row_stride, int B, in
     if (!qkv || !out || B <= 0 || L <= 0 || heads <= 0 || qkv_row_stride < 3ll * heads * 64 || out_row_stride < heads * 64 ||
         (qkv_row_stride & 7) || (out_row_stride & 7) || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 15))
         return OESS_EINVAL;
-    static int impl = -1;
-    if (impl < 0) { const char* e = getenv("OESS_ATTN_IMPL"); impl = (e && e[0] == 'v') ? 0 : 1; }      // "valu" = first kernel
-    if (impl == 1) {
+    {
         const long long blocks = (long long)B * heads * ((L + AQ - 1) / AQ);
         if (blocks > 0x7fffffffll) return OESS_EINVAL;
         hipLaunchKernelGGL(attention_d64_mfma_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, (hipStream_t)stream,
@@ -338,12 +252,6 @@ int oess_attention_d64_bf16(const void* qkv, long long qkv_row_stride, int B, in
         OESS_HIP(hipGetLastError());
         return OESS_OK;
     }
-    const long long blocks = (long long)B * heads * ((L + QB - 1) / QB);
-    if (blocks > 0x7fffffffll) return OESS_EINVAL;
-    hipLaunchKernelGGL(attention_d64_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, (hipStream_t)stream, (const uint16_t*)qkv,
-                       (int64_t)qkv_row_stride, B, L, heads, scale, (uint16_t*)out, (int64_t)out_row_stride);
-    OESS_HIP(hipGetLastError());
-    return OESS_OK;
 }
 
 }  // extern "C"

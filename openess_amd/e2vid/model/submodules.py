@@ -2,7 +2,6 @@
 and shapes are identical to the reference so its checkpoints load unchanged; forward passes run on the
 HIP kernels (MFMA conv + fused gate kernel).  Inference only: the reference keeps E2VID frozen and runs
 it under no_grad (e2vid/image_reconstructor.py:81)."""
-import os
 
 import torch
 import torch.nn as nn
@@ -109,7 +108,7 @@ class ConvLSTM(nn.Module):
         cur = state['cur']
         xh = state['xh'][cur]
         k, pad = g.kernel_size[0], g.padding[0]
-        if self.hidden_size % 32 == 0 and os.environ.get('OESS_LSTM_UNFUSED') is None:
+        if self.hidden_size % 32 == 0:
             pw = self._pw_fused
             key = (g.weight._version, g.bias._version)
             if pw.get('key') != key:
@@ -118,7 +117,7 @@ class ConvLSTM(nn.Module):
                     pw['bias'] = g.bias.detach().float().contiguous()
                 pw['key'] = key
             h_view = state['xh'][1 - cur][:, self.input_size:]
-            if state['fresh'] and os.environ.get('OESS_LSTM_NO_FRESH_SKIP') is None:
+            if state['fresh']:
                 # first sub-window: h_prev = 0 and c_prev = 0 (submodules.py:190-198), so the h half of the Gates
                 # reduction contributes nothing -> convolve the x half only (half the K loop), same cell update
                 if pw.get('packed_x') is None or pw.get('key_x') != key:

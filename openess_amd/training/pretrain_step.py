@@ -4,7 +4,6 @@ training/pretrain_trainer.py: buildModels (:107-208), createOptimizerDict (:211-
 smoke() and the trainer classes; it owns the models_dict / optimizers_dict with the reference's key names.
 """
 import math
-import os
 
 import torch
 
@@ -25,7 +24,6 @@ class PretrainStep:
                  e2vid_config=None, text_embeddings=None, seed=1205):
         self.config_option = config_option
         self.device = torch.device(device)
-        self._side_stream, self._side_pending = None, False
         self.nr_events_data, self.bins = nr_events_data, nr_temporal_bins
         self.if_spatial_contrastive = if_spatial_contrastive
         self.if_dense_clip_supervision = if_dense_clip_supervision
@@ -87,27 +85,8 @@ class PretrainStep:
         gradient can reach the teacher's decoder, so the forward runs without autograd bookkeeping."""
         if self.if_spatial_contrastive:
             return self.model_frame(frame)
-        if frame.is_cuda and os.environ.get('OESS_TEACHER_STREAM', '0') == '1':
-            # Opt-in: run the unused-output teacher on a side HIP stream so that its ~170 launches fill the tail rounds and
-            # latency-bound gaps of the recurrent encoder's kernels.  Measured +0.5..3 % step throughput; off by default
-            # because concurrent kernels time-share the CUs, which inflates every per-launch duration (HIP events and
-            # rocprof alike: 234 -> 384 us average for the dominant kernel) and makes the roofline figures meaningless.
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=frame.device)
-            side, cur = self._side_stream, torch.cuda.current_stream(frame.device)
-            side.wait_stream(cur)                         # frame (and the weights) are ready
-            with torch.cuda.stream(side), torch.no_grad():
-                out = self.model_frame(frame)
-            self._side_pending = True
-            return out
         with torch.no_grad():
             return self.model_frame(frame)
-
-    def join_side_stream(self):
-        """Order the current stream after the side-stream teacher forward (called at the end of every step)."""
-        if getattr(self, '_side_pending', False):
-            torch.cuda.current_stream().wait_stream(self._side_stream)
-            self._side_pending = False
 
     def _pool(self, feat, superpixels, S):
         return hip.superpixel_pool(feat, superpixels, self.superpixel_size, S=S)
@@ -152,7 +131,6 @@ class PretrainStep:
                 loss_dense = self.task_loss(logits_recon, pl) * self.weight_task_loss
                 losses['dense_clip_loss'] = loss_dense.detach()
                 t_loss = t_loss + loss_dense
-        self.join_side_stream()
         return t_loss, losses, {}
 
     # ------------------------------------------------------------------ pretrain_trainer.py:324-361

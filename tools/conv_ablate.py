@@ -1,4 +1,4 @@
-"""Time one conv shape (HIP events) - used with OESS_CONV_* env switches for A/B runs."""
+"""Time one conv shape (HIP events).  A/B two builds of the library on the same box with OESS_LIB_PATH=<other liboess.so>."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openess_amd import hip

@@ -1,4 +1,4 @@
-"""Time the fused ConvLSTM kernel on the three E2VID recurrent layers (HIP events); A/B with OESS_CONV_* switches."""
+"""Time the fused ConvLSTM kernel on the three E2VID recurrent layers (HIP events); A/B two builds with OESS_LIB_PATH."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openess_amd import hip
