@@ -82,7 +82,7 @@ SIGNATURES = {
     "oess_conv2d_fwd_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                      c_int, c_int, c_int, c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp]),
     "oess_norm_reduce_tile_stats": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
-    "oess_norm_reduce_finalize_tile_stats": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_f,
+    "oess_norm_reduce_finalize_tile_stats": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_f,
                                                      c_vp, c_vp, c_vp, c_vp, c_vp]),
 }
 

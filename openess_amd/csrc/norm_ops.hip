@@ -424,16 +424,18 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     }
 }
 
-// reduce_partials_kernel + finalize_kernel in ONE launch (the frozen teacher and the DeepLab forward issue 53-59 of each per pass,
-// ~4 us apiece): the tile partials are summed in DOUBLE (one double atomic per (block, channel)), and the block that takes the
-// last ticket of its 32-channel group computes mean / rstd / scale / shift / running statistics from the totals -- in double, so
-// E[x^2] - E[x]^2 does not cancel in fp32 -- and leaves the accumulators and its ticket counter zeroed for the next call.
-__global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ part, int tiles, int C, double* __restrict__ sum,
-                                                              double* __restrict__ sumsq, unsigned int* __restrict__ counter,
-                                                              float count, float eps, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, float* __restrict__ running_mean,
-                                                              float* __restrict__ running_var, float momentum,
-                                                              float* __restrict__ mean_out, float* __restrict__ rstd_out,
+// reduce_partials_kernel + finalize_kernel in ONE launch (the frozen teacher and the DeepLab forward issue 53-59 of each per pass).
+// No data atomics: block (channel group, slice y) sums its slice of the tile partials in DOUBLE and stores the pair to
+// scratch[y][2][C]; the block that takes the LAST ticket of its 32-channel group adds the gridDim.y slice sums in a fixed order
+// (bit-reproducible statistics) and computes mean / rstd / scale / shift / running statistics in double, so E[x^2] - E[x]^2
+// does not cancel in fp32.  (A first version with double atomics on sum[C] took 25 us per call: same-address f64 atomics from 32
+// blocks serialise memory-side.)  Only the ticket counters need to be zero on entry; they are left zero.
+constexpr int RF_MAX_SLICES = 32;
+__global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ part, int tiles, int C, double* __restrict__ scratch,
+                                                              unsigned int* __restrict__ counter, float count, float eps,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                              float momentum, float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                               float* __restrict__ scale, float* __restrict__ shift) {
     __shared__ double red[8][32][2];
     __shared__ unsigned int ticket;
@@ -450,8 +452,8 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
     if (tl == 0 && c < C) {
 #pragma unroll
         for (int k = 1; k < 8; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }
-        atomicAdd(&sum[c], s1);
-        atomicAdd(&sumsq[c], s2);
+        scratch[((size_t)blockIdx.y * 2) * C + c] = s1;
+        scratch[((size_t)blockIdx.y * 2 + 1) * C + c] = s2;
     }
     __threadfence();
     __syncthreads();
@@ -460,7 +462,11 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
     if (ticket != gridDim.y - 1) return;
     __threadfence();
     if (tl == 0 && c < C) {
-        const double S = atomicAdd(&sum[c], 0.0), Q = atomicAdd(&sumsq[c], 0.0);      // device-coherent reads of the totals
+        double S = 0.0, Q = 0.0;
+        for (unsigned y = 0; y < gridDim.y; ++y) {              // other blocks' stores: read past the (non-coherent) L1 / L2 of this XCD
+            S += __builtin_nontemporal_load(&scratch[((size_t)y * 2) * C + c]);
+            Q += __builtin_nontemporal_load(&scratch[((size_t)y * 2 + 1) * C + c]);
+        }
         const double m = S / (double)count;
         double var = Q / (double)count - m * m;                                         // biased variance
         if (var < 0.0) var = 0.0;
@@ -474,7 +480,6 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
         }
-        sum[c] = 0.0; sumsq[c] = 0.0;
     }
     if (threadIdx.x == 0) counter[blockIdx.x] = 0u;
 }
@@ -550,16 +555,16 @@ int oess_norm_reduce_tile_stats(const float* tile_stats, int tiles, int C, float
     return OESS_OK;
 }
 
-int oess_norm_reduce_finalize_tile_stats(const float* tile_stats, int tiles, int C, double* sum, double* sumsq,
+int oess_norm_reduce_finalize_tile_stats(const float* tile_stats, int tiles, int C, double* scratch,
                                          unsigned int* counters, float count, float eps, const float* gamma, const float* beta,
                                          float* running_mean, float* running_var, float momentum, float* mean, float* rstd,
                                          float* scale, float* shift, oess_stream_t stream) {
-    if (!tile_stats || !sum || !sumsq || !counters || !mean || !rstd || !scale || !shift || tiles <= 0 || C <= 0 || count <= 0.f)
+    if (!tile_stats || !scratch || !counters || !mean || !rstd || !scale || !shift || tiles <= 0 || C <= 0 || count <= 0.f)
         return OESS_EINVAL;
     int gy = (tiles + 63) / 64;                    // >= 8 tiles per tile lane
-    if (gy > 32) gy = 32;
+    if (gy > RF_MAX_SLICES) gy = RF_MAX_SLICES;
     if (gy < 1) gy = 1;
-    hipLaunchKernelGGL(reduce_finalize_kernel, dim3((C + 31) / 32, gy), dim3(256), 0, (hipStream_t)stream, tile_stats, tiles, C, sum, sumsq,
+    hipLaunchKernelGGL(reduce_finalize_kernel, dim3((C + 31) / 32, gy), dim3(256), 0, (hipStream_t)stream, tile_stats, tiles, C, scratch,
                        counters, count, eps, gamma, beta, running_mean, running_var, momentum, mean, rstd, scale, shift);
     OESS_HIP(hipGetLastError());
     return OESS_OK;

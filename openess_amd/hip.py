@@ -636,7 +636,7 @@ _STATS_SCRATCH = {}
 class _StatsScratch:
     def __init__(self, n, device):
         self.buf = torch.zeros((2, n), dtype=torch.float32, device=device)
-        self.buf64 = torch.zeros((2, n), dtype=torch.float64, device=device)       # tile-statistics totals (double) ...
+        self.buf64 = torch.empty((64, n), dtype=torch.float64, device=device)      # tile-statistics slice sums (double) ...
         self.tickets = torch.zeros(((n + 31) // 32,), dtype=torch.int32, device=device)   # ... and their last-block tickets
         self.busy = False
 
@@ -980,7 +980,7 @@ def conv_bn_train_nhwc(x, packed, Cout, R, S, stride, pad, dil, bn, relu=False, 
     st = torch.empty((6, 1, Cout), dtype=torch.float32, device=x.device)
     sc = _stats_scratch(Cout, x.device)
     mom = 0.0 if bn.momentum is None else bn.momentum
-    _lib.check(lib.oess_norm_reduce_finalize_tile_stats(_ptr(part), tiles, Cout, _ptr(sc.buf64[0]), _ptr(sc.buf64[1]), _ptr(sc.tickets),
+    _lib.check(lib.oess_norm_reduce_finalize_tile_stats(_ptr(part), tiles, Cout, _ptr(sc.buf64), _ptr(sc.tickets),
                                                         float(M), float(bn.eps), _ptr(bn.weight.detach()), _ptr(bn.bias.detach()),
                                                         _ptr(bn.running_mean), _ptr(bn.running_var), float(mom), _ptr(st[2]), _ptr(st[3]),
                                                         _ptr(st[4]), _ptr(st[5]), _stream()), "oess_norm_reduce_finalize_tile_stats")

@@ -1,19 +1,25 @@
 # Round-end measurement set on the GPU box (run through gpurun from the repo root); results land in gpurun_out/fin/.
+# Everything under profiles/ is copied from here (tools/collect_profiles.py).
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/fin
 rm -rf $O; mkdir -p $O
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $O/pytest_gpu.txt
-timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
-timeout 600 python bench.py > $O/bench.txt 2>&1
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest_gpu.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
+timeout 900 python bench.py > $O/bench.txt 2>&1
 for wl in frame2voxel_pixel_distill frame2voxel_full frame2recon_full; do
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -o step -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --workload $wl > $O/prof_$wl.txt 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -o step -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-extras --workload $wl > $O/prof_$wl.txt 2>&1
 done
-timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.txt 2>&1
-timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write.txt 2>&1
-python tools/pmc_aggregate.py $O/pmc_fetch $O/pmc_write $O/conv_hbm_traffic.json > $O/pmc_agg.txt 2>&1
-find $O -name "*.csv" -size +20M -delete
+for st in deeplab_fwd maskclip_fwd teacher_fwd; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stage_$st -o p -- python tools/bench_stage.py $st --iters 10 > $O/stage_$st.txt 2>&1
+done
+for r in 1 0; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/vox_raw$r -o p -- python tools/bench_voxelizer.py --raw $r --iters 20 > $O/vox_raw$r.txt 2>&1
+done
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_mfma -o p -- python bench.py --child --steps 1 --warmup 1 > $O/pmc_mfma.txt 2>&1
+python tools/mfma_util.py $O/pmc_mfma $O/mfma_util.json > $O/mfma_util.txt 2>&1 || true
 find $O -name "*_kernel_trace.csv" -delete
-find $O -name "*counter_collection.csv" -delete
+find $O -name "*counter_collection.csv" -size +8M -delete
+find $O -name "*.csv" -size +20M -delete
 du -sh $O
