@@ -211,10 +211,9 @@ int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, 
 int oess_norm_reduce_tile_stats(const float* tile_stats, int tiles, int C, float* sum, float* sumsq, int pre_zeroed,
                                 oess_stream_t stream);
 
-/* oess_norm_reduce_tile_stats + oess_norm_finalize (G = 1) in ONE launch, totals and E[x^2] - E[x]^2 in double and summed in a
- * fixed order (bit-reproducible): the tile partials of a conv epilogue -> mean / rstd / scale / shift (+ BatchNorm running
- * statistics; models/image_model.py:113-114 leaves the frozen teacher in .train()).  `scratch`: caller-owned double[32 * 2 * C],
- * contents irrelevant.  `counters`: caller-owned uint32[(C + 31) / 32] that must be ZERO on entry and is left zero on return. */
+/* oess_norm_reduce_tile_stats + oess_norm_finalize (G = 1) in ONE launch, totals and E[x^2] - E[x]^2 in double: the tile partials of a conv epilogue -> mean / rstd / scale / shift (+ BatchNorm running
+ * statistics; models/image_model.py:113-114 leaves the frozen teacher in .train()).  `scratch`: caller-owned double[2 * C],
+ * `counters`: caller-owned uint32[(C + 31) / 32]; both must be ZERO on entry and are left zero on return (stream-ordered reuse). */
 int oess_norm_reduce_finalize_tile_stats(const float* tile_stats, int tiles, int C, double* scratch,
                                          unsigned int* counters, float count, float eps, const float* gamma, const float* beta,
                                          float* running_mean, float* running_var, float momentum, float* mean, float* rstd,

@@ -425,13 +425,13 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 }
 
 // reduce_partials_kernel + finalize_kernel in ONE launch (the frozen teacher and the DeepLab forward issue 53-59 of each per pass).
-// No data atomics: block (channel group, slice y) sums its slice of the tile partials in DOUBLE and stores the pair to
-// scratch[y][2][C]; the block that takes the LAST ticket of its 32-channel group adds the gridDim.y slice sums in a fixed order
-// (bit-reproducible statistics) and computes mean / rstd / scale / shift / running statistics in double, so E[x^2] - E[x]^2
-// does not cancel in fp32.  (A first version with double atomics on sum[C] took 25 us per call: same-address f64 atomics from 32
-// blocks serialise memory-side.)  Only the ticket counters need to be zero on entry; they are left zero.
-constexpr int RF_MAX_SLICES = 32;
-__global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ part, int tiles, int C, double* __restrict__ scratch,
+// Block (channel group, slice y) sums its slice of the tile partials in DOUBLE and adds the pair to totals[2][C] with RETURNING
+// device-scope atomics (performed at the coherence point once the value is back), then takes a ticket; the block with the last
+// ticket reads the totals back with atomics and computes mean / rstd / scale / shift / running statistics in double, so
+// E[x^2] - E[x]^2 does not cancel in fp32, and leaves totals and tickets zero (atomic exchanges) for the next call.
+// NO __threadfence(): an agent-scope release writes back the whole XCD L2, which right after a convolution holds megabytes of
+// dirty output -- measured 25-31 us per call for two versions that used one, against ~10 us for the two separate kernels.
+__global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ part, int tiles, int C, double* __restrict__ totals,
                                                               unsigned int* __restrict__ counter, float count, float eps,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
@@ -452,21 +452,17 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
     if (tl == 0 && c < C) {
 #pragma unroll
         for (int k = 1; k < 8; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }
-        scratch[((size_t)blockIdx.y * 2) * C + c] = s1;
-        scratch[((size_t)blockIdx.y * 2 + 1) * C + c] = s2;
+        const double o1 = atomicAdd(&totals[c], s1), o2 = atomicAdd(&totals[C + c], s2);
+        asm volatile("" :: "v"(o1), "v"(o2));                    // wait for both atomics to have been performed
     }
-    __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) ticket = atomicAdd(&counter[blockIdx.x], 1u);
     __syncthreads();
     if (ticket != gridDim.y - 1) return;
-    __threadfence();
     if (tl == 0 && c < C) {
-        double S = 0.0, Q = 0.0;
-        for (unsigned y = 0; y < gridDim.y; ++y) {              // other blocks' stores: read past the (non-coherent) L1 / L2 of this XCD
-            S += __builtin_nontemporal_load(&scratch[((size_t)y * 2) * C + c]);
-            Q += __builtin_nontemporal_load(&scratch[((size_t)y * 2 + 1) * C + c]);
-        }
+        // read-and-reset in one memory-side operation each
+        const double S = __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long*>(&totals[c]), 0ull));
+        const double Q = __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long*>(&totals[C + c]), 0ull));
         const double m = S / (double)count;
         double var = Q / (double)count - m * m;                                         // biased variance
         if (var < 0.0) var = 0.0;
@@ -481,7 +477,7 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
         }
     }
-    if (threadIdx.x == 0) counter[blockIdx.x] = 0u;
+    if (threadIdx.x == 0) atomicExch(&counter[blockIdx.x], 0u);
 }
 
 // chunks per group.  Every workgroup ends with 2*C float atomics on the same few cache lines, and those serialise in L2:
@@ -562,7 +558,7 @@ int oess_norm_reduce_finalize_tile_stats(const float* tile_stats, int tiles, int
     if (!tile_stats || !scratch || !counters || !mean || !rstd || !scale || !shift || tiles <= 0 || C <= 0 || count <= 0.f)
         return OESS_EINVAL;
     int gy = (tiles + 63) / 64;                    // >= 8 tiles per tile lane
-    if (gy > RF_MAX_SLICES) gy = RF_MAX_SLICES;
+    if (gy > 32) gy = 32;
     if (gy < 1) gy = 1;
     hipLaunchKernelGGL(reduce_finalize_kernel, dim3((C + 31) / 32, gy), dim3(256), 0, (hipStream_t)stream, tile_stats, tiles, C, scratch,
                        counters, count, eps, gamma, beta, running_mean, running_var, momentum, mean, rstd, scale, shift);

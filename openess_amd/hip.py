@@ -636,7 +636,7 @@ _STATS_SCRATCH = {}
 class _StatsScratch:
     def __init__(self, n, device):
         self.buf = torch.zeros((2, n), dtype=torch.float32, device=device)
-        self.buf64 = torch.empty((64, n), dtype=torch.float64, device=device)      # tile-statistics slice sums (double) ...
+        self.buf64 = torch.zeros((2, n), dtype=torch.float64, device=device)       # tile-statistics totals (double, kept zero) ...
         self.tickets = torch.zeros(((n + 31) // 32,), dtype=torch.int32, device=device)   # ... and their last-block tickets
         self.busy = False
 

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries of tools/final_run.sh from gpurun_out/fin/ into profiles/ (tracked), named per round."""
+import json, os, shutil, subprocess, sys
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src, dst = "gpurun_out/fin", "profiles"
+pairs = {f"prof_frame2voxel_pixel_distill/step_kernel_stats.csv": f"{R}_step_pixel_distill_kernel_stats.csv",
+         f"prof_frame2voxel_full/step_kernel_stats.csv": f"{R}_step_frame2voxel_full_kernel_stats.csv",
+         f"prof_frame2recon_full/step_kernel_stats.csv": f"{R}_step_frame2recon_full_kernel_stats.csv",
+         f"stage_deeplab_fwd/p_kernel_stats.csv": f"{R}_stage_deeplab_fwd_kernel_stats.csv",
+         f"stage_maskclip_fwd/p_kernel_stats.csv": f"{R}_stage_maskclip_fwd_kernel_stats.csv",
+         f"stage_teacher_fwd/p_kernel_stats.csv": f"{R}_stage_teacher_fwd_kernel_stats.csv",
+         f"vox_raw1/p_kernel_stats.csv": f"{R}_voxelizer_raw_kernel_stats.csv",
+         f"vox_raw0/p_kernel_stats.csv": f"{R}_voxelizer_f32_kernel_stats.csv"}
+for a, b in pairs.items():
+    shutil.copyfile(os.path.join(src, a), os.path.join(dst, b))
+line = [l for l in open(os.path.join(src, "bench.txt")).read().split("\n") if l.startswith("{")][-1]
+json.dump(json.loads(line), open(os.path.join(dst, f"{R}_bench_line.json"), "w"), indent=1)
+subprocess.run([sys.executable, "tools/mfma_util.py", os.path.join(src, "pmc_mfma"), os.path.join(dst, f"{R}_mfma_util.json")],
+               check=True, stdout=subprocess.DEVNULL)
+print(sorted(f for f in os.listdir(dst) if f.startswith(R)))

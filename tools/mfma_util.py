@@ -18,9 +18,12 @@ for k, c in sorted(per.items(), key=lambda kv: -kv[1].get("SQ_INSTS_MFMA", 0))[:
     gui = c.get("GRBM_GUI_ACTIVE", 0.0)
     if gui <= 0 or c.get("SQ_INSTS_MFMA", 0) <= 0:
         continue
-    # SQ_VALU_MFMA_BUSY_CYCLES is summed over all SIMDs (256 CUs x 4); GRBM_GUI_ACTIVE counts GPU-active cycles per launch
+    # SQ_VALU_MFMA_BUSY_CYCLES is summed over all 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs (cross-check: a
+    # v_mfma_f32_32x32x16_bf16 occupies the pipe 32 cycles, so busy ~= insts * 32 / 1024 SIMD-cycles per launch)
     out[k] = {"launches": cnt[k], "mfma_insts_per_launch": c["SQ_INSTS_MFMA"] / max(cnt[k], 1),
-              "mfma_busy_frac_of_active_cycles": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024.0)}
+              "active_cycles_per_launch": gui / 8.0 / max(cnt[k], 1),
+              "mfma_busy_frac_of_active_cycles": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui / 8.0 * 1024.0),
+              "mfma_busy_frac_from_inst_count": c["SQ_INSTS_MFMA"] * 32.0 / 1024.0 / (gui / 8.0)}
 print(json.dumps(out, indent=1))
 if len(sys.argv) > 2:
     json.dump(out, open(sys.argv[2], "w"), indent=1)
