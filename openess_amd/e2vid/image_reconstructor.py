@@ -20,10 +20,12 @@ class ImageReconstructor:
         self.last_states_for_each_channel = {'grayscale': None}
         self.event_preprocessor = EventPreprocessor(options)
 
-    def update_reconstruction(self, event_tensor, event_tensor_id=None, stamp=None, channel_slice=None):
+    def update_reconstruction(self, event_tensor, event_tensor_id=None, stamp=None, channel_slice=None, reconstruct=False):
         """event_tensor: fp32 [B, num_bins, H, W] (reference contract), or -- fused form -- the whole
         [B, C_total, H, W] event tensor plus channel_slice=(c0, cs) so that the slice, the normalisation
-        and the NHWC re-layout are one kernel.  Returns (None, states, latent)."""
+        and the NHWC re-layout are one kernel.  Returns (img | None, states, latent): the trainers discard the image
+        (`_, _, latent = update_reconstruction(...)`), so it is only computed with `reconstruct=True` (offline
+        reconstruction, e2vid/run_reconstruction.py), cropped back from the padded size like the reference's CropParameters."""
         with torch.no_grad():
             if channel_slice is None:
                 events = event_tensor.to(self.device).float().contiguous()
@@ -33,6 +35,6 @@ class ImageReconstructor:
             x = self.event_preprocessor.slice_to_nhwc8(events, c0, cs)
             if self.crop.needs_pad:
                 x = self.crop.pad(x.float()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-            _, states, latent = self.model(x, self.last_states_for_each_channel['grayscale'])
+            img, states, latent = self.model(x, self.last_states_for_each_channel['grayscale'], reconstruct=reconstruct)
             self.last_states_for_each_channel['grayscale'] = None if self.no_recurrent else states
-        return None, states, latent
+        return img, states, latent

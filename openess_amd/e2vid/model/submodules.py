@@ -39,19 +39,52 @@ class ConvLayer(nn.Module):
 
 
 class TransposedConvLayer(nn.Module):
-    """e2vid/model/submodules.py:34-62 -- parameter container only: the decoders are dead code for the
-    latents this path consumes (unet.py:163-170)."""
+    """e2vid/model/submodules.py:34-62: ConvTranspose2d(k, stride 2, padding, output_padding 1) -> BN -> relu.  Only the offline
+    reconstruction path runs it (unet.py:165-166; the training path stops at the latents).  A transposed convolution IS the
+    data gradient of the strided convolution with the same weight tensor, so it runs on the same two kernels as autograd's
+    dgrad: zero insertion (oess_zero_insert_nhwc_bf16) + the MFMA conv on the rotated / transposed packing; the eval-mode
+    BatchNorm is folded into that packing and ReLU is fused in the epilogue."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, activation='relu', norm=None):
         super().__init__()
         bias = False if norm == 'BN' else True
         self.transposed_conv2d = nn.ConvTranspose2d(in_channels, out_channels, kernel_size, stride=2, padding=padding,
                                                     output_padding=1, bias=bias)
+        self.activation_name = activation
         self.norm = norm
         if norm == 'BN':
             self.norm_layer = nn.BatchNorm2d(out_channels)
         elif norm == 'IN':
             self.norm_layer = nn.InstanceNorm2d(out_channels, track_running_stats=True)
+        self._cache = {}
+
+    def forward(self, x):
+        if self.norm == 'IN' or self.activation_name not in (None, 'relu'):
+            raise NotImplementedError("only BN / no norm with relu / None are used by the shipped E2VID configurations")
+        t = self.transposed_conv2d
+        if self.norm == 'BN' and self.norm_layer.training:
+            raise RuntimeError("E2VID runs in eval mode on this path")
+        k, pad = t.kernel_size[0], t.padding[0]
+        bn = self.norm_layer if self.norm == 'BN' else None
+        key = (t.weight._version, None if t.bias is None else t.bias._version,
+               None if bn is None else (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version))
+        if self._cache.get('key') != key:
+            with torch.no_grad():
+                w = t.weight.detach().float()                        # [Cin, Cout, k, k] == Conv2d weight of the strided conv it transposes
+                b = None if t.bias is None else t.bias.detach().float()
+                if bn is not None:
+                    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+                    w = w * scale[None, :, None, None]
+                    b0 = torch.zeros_like(scale) if b is None else b
+                    b = (b0 - bn.running_mean.detach().float()) * scale + bn.bias.detach().float()
+                self._cache = {'key': key, 'packed': hip.pack_conv_weight(w.contiguous(), flip=True),
+                               'bias': None if b is None else b.contiguous()}
+        B, Cin, H, W = x.shape
+        Ho, Wo = (H - 1) * 2 - 2 * pad + k + 1, (W - 1) * 2 - 2 * pad + k + 1
+        z = hip.zero_insert(engine.nhwc(x), 2, Ho - (k - 1) + 2 * pad, Wo - (k - 1) + 2 * pad)
+        y = hip.conv2d_nhwc(z, self._cache['packed'], self._cache['bias'], t.out_channels, k, k, 1, (k - 1) - pad, 1,
+                            relu=self.activation_name == 'relu')
+        return engine.from_nhwc(y)
 
 
 class UpsampleConvLayer(nn.Module):
@@ -69,7 +102,7 @@ class UpsampleConvLayer(nn.Module):
 
 
 class ResidualBlock(nn.Module):
-    """e2vid/model/submodules.py:140-172 -- parameter container only (runs after the latents are taken)."""
+    """e2vid/model/submodules.py:140-172.  Runs only on the offline reconstruction path (after the latents are taken)."""
 
     def __init__(self, in_channels, out_channels, stride=1, downsample=None, norm=None):
         super().__init__()
@@ -83,6 +116,22 @@ class ResidualBlock(nn.Module):
             self.bn1 = nn.InstanceNorm2d(out_channels)
             self.bn2 = nn.InstanceNorm2d(out_channels)
         self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=bias)
+        self.downsample = downsample
+        self._pw1, self._pw2 = engine.PackedWeight(), engine.PackedWeight()
+
+    def forward(self, x):
+        """conv-bn-relu-conv-bn + residual + relu (:154-172); eval-mode BatchNorm folded, residual add and ReLU in the conv epilogue."""
+        if self.norm == 'IN' or self.downsample is not None:
+            raise NotImplementedError("E2VID residual blocks use BN / no norm and no downsample")
+        bn1 = self.bn1 if self.norm == 'BN' else None
+        bn2 = self.bn2 if self.norm == 'BN' else None
+        if bn1 is not None and bn1.training:
+            raise RuntimeError("E2VID runs in eval mode on this path")
+        C = self.conv1.out_channels
+        p1 = self._pw1.get(self.conv1.weight, self.conv1.bias, bn1, cin_pad=x.shape[1])
+        y = engine.conv2d_infer(x, p1, C, 3, 1, 1, 1, relu=True)
+        p2 = self._pw2.get(self.conv2.weight, self.conv2.bias, bn2, cin_pad=C)
+        return engine.conv2d_infer(y, p2, C, 3, 1, 1, 1, relu=True, residual=x)
 
 
 class ConvLSTM(nn.Module):

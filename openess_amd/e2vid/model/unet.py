@@ -34,8 +34,10 @@ class UNetRecurrent(nn.Module):
         self.pred = ConvLayer(base_num_channels if skip_type == 'sum' else 2 * base_num_channels, num_output_channels, 1,
                               activation=None, norm=norm)
 
-    def forward(self, x, prev_states):
-        """x: logical [B, 8, H, W] channels_last bf16 (bins zero-padded to 8).  Returns (None, states, latent)."""
+    def forward(self, x, prev_states, reconstruct=False):
+        """x: logical [B, 8, H, W] channels_last bf16 (bins zero-padded to 8).  Returns (img | None, states, latent):
+        the training path stops at the latents; `reconstruct=True` also runs the residual blocks, decoders and the
+        prediction layer (unet.py:160-170) and returns the [B, 1, H, W] fp32 image in [0, 1] (offline reconstruction)."""
         x = self.head(x)
         head = x
         if prev_states is None:
@@ -48,4 +50,18 @@ class UNetRecurrent(nn.Module):
         latent = {1: head}
         for i, b in enumerate(blocks):
             latent[2 ** (i + 1)] = b
-        return None, states, latent
+        img = None
+        if reconstruct:
+            if self.skip_type != 'sum':
+                raise NotImplementedError("E2VID checkpoints use skip_type 'sum'")
+            for resblock in self.resblocks:
+                x = resblock(x)
+            for i, decoder in enumerate(self.decoders):
+                x = decoder(x + blocks[self.num_encoders - i - 1])           # apply_skip_connection = skip_sum
+            import torch
+            from ... import engine
+            p = self.pred
+            pw = p._pw.get(p.conv2d.weight, p.conv2d.bias, p.norm_layer if p.norm == 'BN' else None, cin_pad=x.shape[1])
+            logits = engine.conv2d_infer(x + head, pw, 1, 1, 1, 0, 1, out_f32=True)     # 32 -> 1, fp32 output
+            img = torch.sigmoid(logits.float())
+        return img, states, latent

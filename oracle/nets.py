@@ -64,12 +64,55 @@ class RecurrentConvLayer(nn.Module):
         return state[0], state
 
 
-class UNetRecurrentEncoder(nn.Module):
-    def __init__(self, num_bins=5, num_encoders=3, base=32, norm='BN'):
+class ResidualBlock(nn.Module):
+    """e2vid/model/submodules.py:140-172."""
+
+    def __init__(self, c, norm):
         super().__init__()
-        self.num_encoders = num_encoders
+        self.conv1 = nn.Conv2d(c, c, 3, 1, 1, bias=(norm != 'BN'))
+        self.conv2 = nn.Conv2d(c, c, 3, 1, 1, bias=(norm != 'BN'))
+        self.norm = norm
+        if norm == 'BN':
+            self.bn1, self.bn2 = nn.BatchNorm2d(c), nn.BatchNorm2d(c)
+
+    def forward(self, x):
+        out = self.conv1(x)
+        out = torch.relu(self.bn1(out) if self.norm == 'BN' else out)
+        out = self.conv2(out)
+        out = self.bn2(out) if self.norm == 'BN' else out
+        return torch.relu(out + x)
+
+
+class TransposedConvLayer(nn.Module):
+    """e2vid/model/submodules.py:34-62: ConvTranspose2d(k, stride 2, padding, output_padding 1) -> BN -> relu."""
+
+    def __init__(self, cin, cout, k, padding, norm):
+        super().__init__()
+        self.transposed_conv2d = nn.ConvTranspose2d(cin, cout, k, stride=2, padding=padding, output_padding=1, bias=(norm != 'BN'))
+        self.norm = norm
+        if norm == 'BN':
+            self.norm_layer = nn.BatchNorm2d(cout)
+
+    def forward(self, x):
+        out = self.transposed_conv2d(x)
+        return torch.relu(self.norm_layer(out) if self.norm == 'BN' else out)
+
+
+class UNetRecurrentEncoder(nn.Module):
+    """`full=True` adds the residual blocks, decoders and prediction layer (unet.py:160-170, skip_type 'sum',
+    use_upsample_conv False): the offline reconstruction path.  The training path only needs the latents."""
+
+    def __init__(self, num_bins=5, num_encoders=3, base=32, norm='BN', full=False, num_residual_blocks=2):
+        super().__init__()
+        self.num_encoders, self.full = num_encoders, full
         self.head = ConvLayer(num_bins, base, 5, 1, 2)
         self.encoders = nn.ModuleList([RecurrentConvLayer(base * 2 ** i, base * 2 ** (i + 1), norm) for i in range(num_encoders)])
+        if full:
+            cmax = base * 2 ** num_encoders
+            self.resblocks = nn.ModuleList([ResidualBlock(cmax, norm) for _ in range(num_residual_blocks)])
+            self.decoders = nn.ModuleList([TransposedConvLayer(base * 2 ** (i + 1), base * 2 ** i, 5, 2, norm)
+                                           for i in reversed(range(num_encoders))])
+            self.pred = ConvLayer(base, 1, 1, activation=None, norm=norm)
 
     def forward(self, x, prev_states):
         x = self.head(x)
@@ -84,15 +127,24 @@ class UNetRecurrentEncoder(nn.Module):
         latent = {1: head}
         for i, b in enumerate(blocks):
             latent[2 ** (i + 1)] = b
-        return None, states, latent
+        img = None
+        if self.full:
+            for rb in self.resblocks:
+                x = rb(x)
+            for i, dec in enumerate(self.decoders):
+                x = dec(x + blocks[self.num_encoders - i - 1])               # skip_sum
+            img = torch.sigmoid(self.pred(x + head))
+        return img, states, latent
 
 
 class E2VIDRecurrent(nn.Module):
-    def __init__(self, config):
+    def __init__(self, config, full=False):
         super().__init__()
         self.num_encoders = int(config.get('num_encoders', 4))
+        assert not full or (config.get('skip_type', 'sum') == 'sum' and not config.get('use_upsample_conv', True))
         self.unetrecurrent = UNetRecurrentEncoder(int(config['num_bins']), self.num_encoders,
-                                                  int(config.get('base_num_channels', 32)), config.get('norm'))
+                                                  int(config.get('base_num_channels', 32)), config.get('norm'), full=full,
+                                                  num_residual_blocks=int(config.get('num_residual_blocks', 2)))
 
     def forward(self, x, prev_states):
         return self.unetrecurrent(x, prev_states)

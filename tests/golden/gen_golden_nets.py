@@ -58,7 +58,8 @@ def gen_nets():
     with torch.no_grad():
         for i in range(3):
             x = du.normalize_voxel_grid(torch.from_numpy(ev[:, 5 * i:5 * i + 5].copy()))
-            _, states, latent = m(x, states)
+            img, states, latent = m(x, states)
+    out["e2vid_img"] = img.numpy()                   # full UNetRecurrent forward: resblocks, transposed-conv decoders, pred, sigmoid
     out["e2vid_events"] = ev
     for k, v in latent.items():
         out[f"e2vid_latent{k}"] = v.numpy()

@@ -70,6 +70,41 @@ def test_e2vid_recurrent_latents(g, keys):
     assert torch.equal(latent2[8], latent[8])
 
 
+def test_e2vid_offline_reconstruction_image(g, keys):
+    """the full UNetRecurrent forward (residual blocks, transposed-conv decoders on the dgrad kernels, pred + sigmoid)
+    after 3 recurrent steps vs the reference's own image (golden) and the fp32 oracle."""
+    from openess_amd.e2vid.image_reconstructor import ImageReconstructor
+    from openess_amd.e2vid.model.model import E2VIDRecurrent
+    m = E2VIDRecurrent(E2VID_LIGHTWEIGHT_CONFIG).eval()
+    fill_by_name(m, 11)
+    m.cuda()
+    ev = torch.from_numpy(g["e2vid_events"]).cuda()
+    rec = ImageReconstructor(m, 32, 48, 5, torch.device("cuda"))
+    for i in range(3):
+        img, _, latent = rec.update_reconstruction(ev[:, 5 * i:5 * i + 5], reconstruct=True)
+    assert img.shape == (2, 1, 32, 48) and img.dtype == torch.float32
+    got = img.cpu().numpy()
+    assert np.abs(got - g["e2vid_img"]).max() < 2e-2            # sigmoid output in [0, 1]; bf16 activations through 14 more layers
+    ref = on.E2VIDRecurrent(E2VID_LIGHTWEIGHT_CONFIG, full=True).eval()
+    fill_by_name(ref, 11, keys["e2vid"])
+    st = None
+    with torch.no_grad():
+        for i in range(3):
+            img_ref, st, _ = ref(on.event_preprocess(ev[:, 5 * i:5 * i + 5].cpu()), st)
+    assert np.abs(got - img_ref.numpy()).max() < 2e-2
+    assert cos(got - got.mean(), img_ref.numpy() - img_ref.numpy().mean()) > 0.995
+    # the transposed convolution alone against nn.ConvTranspose2d on the same bf16 operands
+    torch.manual_seed(3)
+    dec = m.unetrecurrent.decoders[0]
+    x = torch.randn(2, 256, 7, 9, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    y = dec(x).float()
+    t, bn = dec.transposed_conv2d, dec.norm_layer
+    yr = torch.nn.functional.conv_transpose2d(x.float(), t.weight.bfloat16().float(), None, 2, 2, 1)
+    yr = torch.relu(torch.nn.functional.batch_norm(yr, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps))
+    assert y.shape == yr.shape == (2, 128, 14, 18)
+    assert relerr(y.cpu().numpy(), yr.cpu().numpy()) < 2e-2
+
+
 def test_semseg_e2vid_forward_backward(g, keys):
     from openess_amd import hip
     from openess_amd.models.style_networks import SemSegE2VID
@@ -392,3 +427,35 @@ def test_pretrain_step_matches_oracle(option, contr):
             # net (measured against the fp32 oracle with bf16 rounding points in test_deeplab_well_conditioned_*); others 2 %
             rel = (1e-1 if option == 'frame2recon' else 5e-2) if k == 'contrastive_nce_loss' else 2e-2
             assert float(losses[k]) == pytest.approx(float(lref[k]), rel=rel), (it, k, float(losses[k]), float(lref[k]))
+
+
+def test_run_reconstruction_cli_end_to_end(tmp_path):
+    """e2vid/run_reconstruction.py mirror: events text file -> fixed-size windows -> HIP voxel grid -> recurrent E2VID with the
+    decoder path -> PNG frames; the frames equal a hand-driven loop over the same windows with the fp32 oracle (image in [0, 255])."""
+    from openess_amd.e2vid import run_reconstruction as rr
+    from oracle import events as oe
+    rng = np.random.default_rng(5)
+    W, H, n = 48, 32, 6000
+    t = np.sort(rng.uniform(0.0, 0.2, n))
+    ev = np.stack([t, rng.integers(0, W, n), rng.integers(0, H, n), rng.integers(0, 2, n)], 1)
+    path = str(tmp_path / "events.txt")
+    with open(path, "w") as f:
+        f.write(f"{W} {H}\n")
+        for r in ev:
+            f.write("%.9f %d %d %d\n" % (r[0], r[1], r[2], r[3]))
+    model = rr.load_model('random')
+    fill_by_name(model, 11)
+    frames = rr.reconstruct(path, model, str(tmp_path / "out"), window_size=2000)
+    assert len(frames) == 3 and frames[0].shape == (H, W) and frames[0].dtype == np.uint8
+    assert sorted(os.listdir(str(tmp_path / "out"))) == ['frame_0000000000.png', 'frame_0000000001.png', 'frame_0000000002.png', 'timestamps.txt']
+    ref = on.E2VIDRecurrent(E2VID_LIGHTWEIGHT_CONFIG, full=True).eval()
+    fill_by_name(ref, 11, sorted(model.state_dict().keys()))
+    st = None
+    ev_read = np.loadtxt(path, skiprows=1)
+    with torch.no_grad():
+        for k in range(3):
+            win = ev_read[k * 2000:(k + 1) * 2000]
+            grid = torch.from_numpy(oe.e2vid_voxel_grid(win.copy(), 5, W, H))[None]
+            img, st, _ = ref(on.event_preprocess(grid), st)
+            want = (img[0, 0].clamp(0, 1) * 255.0).numpy()
+            assert np.abs(frames[k].astype(np.float64) - want).max() <= 6.0, k          # 2e-2 of the [0, 1] image, in grey levels

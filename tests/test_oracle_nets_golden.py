@@ -38,6 +38,21 @@ def test_e2vid_recurrent_latents(g, keys):
         check_compact(g, f"e2vid_latent{k}", v.numpy(), rtol=1e-4, atol=1e-5)
 
 
+def test_e2vid_full_reconstruction_image(g, keys):
+    """Offline reconstruction path: residual blocks, ConvTranspose2d decoders, skip sums, pred + sigmoid
+    (e2vid/model/unet.py:160-170) -- the oracle's image after 3 recurrent steps equals the reference's."""
+    torch.set_num_threads(4)
+    m = on.E2VIDRecurrent(E2VID_LIGHTWEIGHT_CONFIG, full=True).eval()
+    assert sorted(m.state_dict().keys()) == keys["e2vid"]              # every key of the reference module, nothing else
+    fill_by_name(m, 11, keys["e2vid"])
+    ev = torch.from_numpy(g["e2vid_events"])
+    states = None
+    with torch.no_grad():
+        for i in range(3):
+            img, states, _ = m(on.event_preprocess(ev[:, 5 * i:5 * i + 5]), states)
+    np.testing.assert_allclose(img.numpy(), g["e2vid_img"], rtol=1e-4, atol=1e-5)
+
+
 def test_semseg_e2vid_forward_and_grads(g, keys):
     torch.set_num_threads(4)
     net = on.SemSegE2VID(256, 11)
