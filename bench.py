@@ -205,7 +205,8 @@ class Workload:
             self.online_teacher = maskClipFeatureExtractor(text_categories=11).to(device).eval()
         self.option = "frame2recon" if name.startswith("frame2recon") else "frame2voxel"
         self.step = PretrainStep(config_option=self.option, img_size=(H_NET, W_SENSOR), nr_events_data=NWIN, nr_temporal_bins=C,
-                                 if_spatial_contrastive=self.contrastive, superpixel_size=100, device=device)
+                                 if_spatial_contrastive=self.contrastive, superpixel_size=100, device=device,
+                                 online_teacher=self.online_teacher)
         if world > 1:      # identical initial weights on every rank
             broadcast_module_states(self.step.models_dict.values())
         self.reducer = GradAllReduce([p for m in self.step.models_dict.values() for p in m.parameters()], world)
@@ -218,7 +219,7 @@ class Workload:
 
     def train(self, voxels):
         first = self.frame if self.option == "frame2recon" else voxels
-        labels = self.pl if self.online_teacher is None else self.online_teacher(self.frame).argmax(dim=1)
+        labels = self.pl                          # replaced inside the step by the online teacher's argmax when one is set
         for opt in self.step.optimizers_dict.values():
             opt.zero_grad()
         self.reducer.prepare()

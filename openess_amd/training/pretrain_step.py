@@ -21,8 +21,11 @@ class PretrainStep:
     def __init__(self, config_option='frame2voxel', num_classes=11, img_size=(440, 640), nr_events_data=20,
                  nr_temporal_bins=5, if_spatial_contrastive=False, if_dense_clip_supervision=True, superpixel_size=100,
                  lr=5e-4, weight_task_loss=1.0, task_loss=('dice', 'cross_entropy'), output_stride=32, device='cuda',
-                 e2vid_config=None, text_embeddings=None, seed=1205):
+                 e2vid_config=None, text_embeddings=None, seed=1205, online_teacher=None):
         self.config_option = config_option
+        # a frozen MaskCLIP tower as ONLINE teacher: pseudo-labels = argmax of its logits on the frame, computed inside
+        # the step, instead of the offline `pl_*_rgb` PNGs (README.md:295).  None = the reference's behaviour (labels from the batch).
+        self.online_teacher = online_teacher
         self.device = torch.device(device)
         self.nr_events_data, self.bins = nr_events_data, nr_temporal_bins
         self.if_spatial_contrastive = if_spatial_contrastive
@@ -98,6 +101,10 @@ class PretrainStep:
         t_loss = 0.
         self._set_modes()
         S = batch[5] if len(batch) > 5 else None
+        if self.online_teacher is not None:
+            with torch.no_grad():
+                online_pl = self.online_teacher(batch[2] if self.config_option == 'frame2voxel' else batch[0]).argmax(dim=1)
+            batch = (*batch[:3], online_pl, *batch[4:])
         if self.config_option == 'frame2voxel':
             event, frame, pl = batch[0], batch[2], batch[3]
             feat_frame = self._teacher(frame)

@@ -15,7 +15,12 @@ class OpenESSPretrainModel(BaseTrainer):
                 text = torch.load(s.text_embeddings_path, map_location='cpu')
             except (FileNotFoundError, OSError):
                 s.logger.info("text embeddings '%s' not found: random unit-norm embeddings", s.text_embeddings_path)
-        self.step = PretrainStep(config_option=s.config_option, num_classes=s.semseg_num_classes, img_size=tuple(s.img_size_b),
+        online = None
+        if getattr(s, 'pl_sources', '') == 'online_maskclip':          # extension: labels from the frozen tower, in the step
+            from ..models.maskclip_model import maskClipFeatureExtractor
+            kw = {k: getattr(s, k) for k in ('text_embeddings_path', 'visual_projs_path', 'maskclip_checkpoint') if getattr(s, k, None)}
+            online = maskClipFeatureExtractor(text_categories=s.semseg_num_classes, **kw).to(self.device).eval()
+        self.step = PretrainStep(config_option=s.config_option, online_teacher=online, num_classes=s.semseg_num_classes, img_size=tuple(s.img_size_b),
                                  nr_events_data=s.nr_events_data_b, nr_temporal_bins=s.nr_temporal_bins_b,
                                  if_spatial_contrastive=s.if_spatial_contrastive,
                                  if_dense_clip_supervision=s.if_dense_clip_supervision, superpixel_size=s.superpixel_size,

@@ -68,3 +68,29 @@ def test_maskclip_tower_matches_restatement(img_size, hw):
     assert np.abs(out.cpu().numpy() - r).max() < 4e-2 * (r.max() - r.min())
     agree = (out.argmax(1).cpu() == ref.argmax(1)).float().mean().item()
     assert agree >= 0.97, agree
+
+
+def test_online_teacher_labels_in_the_step():
+    """the frozen tower as ONLINE teacher inside PretrainStep -- the step with `online_teacher` equals the step fed
+    with the tower's argmax map as offline pseudo-labels (bit-identical loss), and that map agrees with the oracle tower's."""
+    from openess_amd.training.pretrain_step import PretrainStep
+    from tests.synth import damp_residual, fill_by_name
+    o, m = _pair((32, 48))
+    torch.manual_seed(2)
+    B, H, W, nwin = 2, 64, 96, 2
+    ev = (torch.randn(B, nwin * 5, H, W) * (torch.rand(B, nwin * 5, H, W) > 0.7)).contiguous().cuda()
+    frame = torch.rand(B, 3, H, W)
+    with torch.no_grad():
+        labels = m(frame.cuda()).argmax(1)
+        ref_labels = o(frame).argmax(1)
+    assert (labels.cpu() == ref_labels).float().mean().item() >= 0.97
+    losses = []
+    for teacher, pl in ((m, torch.zeros_like(labels)), (None, labels)):
+        st = PretrainStep(config_option="frame2voxel", img_size=(H, W), nr_events_data=nwin, if_spatial_contrastive=False, lr=1e-4,
+                          online_teacher=teacher)
+        for name, mod in st.models_dict.items():
+            fill_by_name(mod, 100 + len(name))
+            damp_residual(mod)
+        ls, _, _ = st.train_step((ev, None, frame.cuda(), pl, None, None))
+        losses.append(float(ls['dense_clip_loss']))
+    assert losses[0] == pytest.approx(losses[1], rel=1e-6)
