@@ -4,7 +4,7 @@
 //   The reference scatters 8 (tri-linear) or 2 (nearest) read-modify-writes per event into a
 //   C x H x W grid.  Global fp32 atomics across the 8 non-coherent XCD L2s would execute
 //   memory-side, so the splat is made OUTPUT-STATIONARY and free of global atomics:
-//     S  sort     workgroup (segment, slice of 4096 events): the events are loaded ONCE; LDS histogram per
+//     S  sort     workgroup (segment, slice of 2048 events): the events are loaded ONCE; LDS histogram per
 //                 spatial tile, LDS scan, rank by LDS integer atomic into an LDS record buffer, then one
 //                 coalesced block copy of the slice's tile-sorted 16-byte records (region from one global
 //                 atomic) + a row of absolute run starts per tile (plain stores)
@@ -426,17 +426,17 @@ __global__ __launch_bounds__(THREADS) void near_splat_kernel(const float4* __res
 
 // =============================================================================================
 // Tri-linear pipeline: SLICE-LOCAL SORT + multi-run splat (2 kernels).
-//   S  sort   workgroup (segment, slice of 4096 events): load the events ONCE, LDS histogram per tile, LDS
+//   S  sort   workgroup (segment, slice of 2048 events): load the events ONCE, LDS histogram per tile, LDS
 //             exclusive scan, rank by LDS integer atomic into an LDS record buffer, then ONE coalesced block
 //             copy of the slice's records (sorted by tile) to a region obtained with one global atomic; the
 //             per-slice table row {start[tile], ..., end, max |value|} is stored with plain stores.
 //   D  splat  workgroup (segment, tile): gathers its run from every slice of the segment (run starts one per
 //             lane, wave scan, ds_bpermute search), accumulates in LDS and writes every voxel once.
 // =============================================================================================
-constexpr int SORT_THREADS = 512;
-constexpr int SSL = SORT_THREADS * EPT;  // 4096 events per sort slice (one batch of EPT per thread)
-constexpr int LCAP = 4608;               // records staged in LDS (36 / 72 KB); a slice needs 4096 * ~1.08 on real data,
-                                         // up to 4 * 4096 on adversarial input (overflow goes straight to HBM)
+constexpr int SORT_THREADS = 256;        // 4 sort workgroups per CU (36 KB staging each); 512 threads / 4096-event slices: 1.5-3 % slower
+constexpr int SSL = SORT_THREADS * EPT;  // 2048 events per sort slice (one batch of EPT per thread)
+constexpr int LCAP = 2304;               // records staged in LDS (36 KB); a slice needs 2048 * ~1.08 on real data,
+                                         // up to 4 * 2048 on adversarial input (overflow goes straight to HBM)
 constexpr int FAST_LDS_BYTES = 20 * 1024;   // 32-bit accumulator tile: 8 splat workgroups per CU
 
 __device__ __forceinline__ int block_incl_scan_256(int v, int* wsum) {
