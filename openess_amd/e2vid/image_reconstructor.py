@@ -20,7 +20,7 @@ class ImageReconstructor:
         self.last_states_for_each_channel = {'grayscale': None}
         self.event_preprocessor = EventPreprocessor(options)
 
-    def update_reconstruction(self, event_tensor, event_tensor_id=None, stamp=None, channel_slice=None, reconstruct=False):
+    def update_reconstruction(self, event_tensor, event_tensor_id=None, stamp=None, channel_slice=None, reconstruct=False, wavefront=None):
         """event_tensor: fp32 [B, num_bins, H, W] (reference contract), or -- fused form -- the whole
         [B, C_total, H, W] event tensor plus channel_slice=(c0, cs) so that the slice, the normalisation
         and the NHWC re-layout are one kernel.  Returns (img | None, states, latent): the trainers discard the image
@@ -32,9 +32,13 @@ class ImageReconstructor:
                 c0, cs = 0, events.shape[1]
             else:
                 events, (c0, cs) = event_tensor, channel_slice
-            x = self.event_preprocessor.slice_to_nhwc8(events, c0, cs)
-            if self.crop.needs_pad:
-                x = self.crop.pad(x.float()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-            img, states, latent = self.model(x, self.last_states_for_each_channel['grayscale'], reconstruct=reconstruct)
+            import contextlib
+            first = torch.cuda.stream(wavefront.streams[0]) if wavefront is not None else contextlib.nullcontext()
+            with first:                               # EventPreprocessor + re-layout belong to level 0's stream
+                x = self.event_preprocessor.slice_to_nhwc8(events, c0, cs)
+                if self.crop.needs_pad:
+                    x = self.crop.pad(x.float()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            kw = {} if wavefront is None else {'wavefront': wavefront}
+            img, states, latent = self.model(x, self.last_states_for_each_channel['grayscale'], reconstruct=reconstruct, **kw)
             self.last_states_for_each_channel['grayscale'] = None if self.no_recurrent else states
         return img, states, latent

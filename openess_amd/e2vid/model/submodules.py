@@ -209,9 +209,13 @@ class RecurrentConvLayer(nn.Module):
         return {'xh': [engine.zeros_cl(B, 2 * Co, Ho, Wo, x.device), engine.zeros_cl(B, 2 * Co, Ho, Wo, x.device)], 'cur': 0,
                 'cell': torch.empty((B, Ho, Wo, Co), dtype=torch.float32, device=x.device), 'fresh': True}
 
-    def forward(self, x, prev_state):
+    def run_conv(self, x, prev_state):
         state = prev_state if prev_state is not None else self.new_state(x)
         Co = self.conv.conv2d.out_channels
         self.conv(x, out=state['xh'][state['cur']][:, :Co])         # x -> first half of the current cat(x, h) buffer
+        return state
+
+    def forward(self, x, prev_state):
+        state = self.run_conv(x, prev_state)
         h = self.recurrent_block.step(state)
         return h, state

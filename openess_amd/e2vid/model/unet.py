@@ -34,19 +34,36 @@ class UNetRecurrent(nn.Module):
         self.pred = ConvLayer(base_num_channels if skip_type == 'sum' else 2 * base_num_channels, num_output_channels, 1,
                               activation=None, norm=norm)
 
-    def forward(self, x, prev_states, reconstruct=False):
+    def forward(self, x, prev_states, reconstruct=False, wavefront=None):
         """x: logical [B, 8, H, W] channels_last bf16 (bins zero-padded to 8).  Returns (img | None, states, latent):
         the training path stops at the latents; `reconstruct=True` also runs the residual blocks, decoders and the
-        prediction layer (unet.py:160-170) and returns the [B, 1, H, W] fp32 image in [0, 1] (offline reconstruction)."""
-        x = self.head(x)
-        head = x
+        prediction layer (unet.py:160-170) and returns the [B, 1, H, W] fp32 image in [0, 1] (offline reconstruction).
+        `wavefront` (e2vid/wavefront.py): run level l on its own HIP stream, ordered by events; same kernels, same results."""
         if prev_states is None:
             prev_states = [None] * self.num_encoders
         blocks, states = [], []
-        for i, encoder in enumerate(self.encoders):
-            x, state = encoder(x, prev_states[i])
-            blocks.append(x)
-            states.append(state)
+        if wavefront is not None and not reconstruct:
+            import torch
+            with torch.cuda.stream(wavefront.streams[0]):
+                x = self.head(x)
+            head = x
+            for i, encoder in enumerate(self.encoders):
+                with torch.cuda.stream(wavefront.streams[i]):
+                    wavefront.before_conv(i)
+                    state = encoder.run_conv(x, prev_states[i])
+                    wavefront.after_conv(i)
+                    wavefront.before_lstm(i)
+                    x = encoder.recurrent_block.step(state)
+                    wavefront.after_lstm(i)
+                blocks.append(x)
+                states.append(state)
+        else:
+            x = self.head(x)
+            head = x
+            for i, encoder in enumerate(self.encoders):
+                x, state = encoder(x, prev_states[i])
+                blocks.append(x)
+                states.append(state)
         latent = {1: head}
         for i, b in enumerate(blocks):
             latent[2 ** (i + 1)] = b

@@ -21,7 +21,7 @@ class PretrainStep:
     def __init__(self, config_option='frame2voxel', num_classes=11, img_size=(440, 640), nr_events_data=20,
                  nr_temporal_bins=5, if_spatial_contrastive=False, if_dense_clip_supervision=True, superpixel_size=100,
                  lr=5e-4, weight_task_loss=1.0, task_loss=('dice', 'cross_entropy'), output_stride=32, device='cuda',
-                 e2vid_config=None, text_embeddings=None, seed=1205, online_teacher=None):
+                 e2vid_config=None, text_embeddings=None, seed=1205, online_teacher=None, wavefront=False):
         self.config_option = config_option
         # a frozen MaskCLIP tower as ONLINE teacher: pseudo-labels = argmax of its logits on the frame, computed inside
         # the step, instead of the offline `pl_*_rgb` PNGs (README.md:295).  None = the reference's behaviour (labels from the batch).
@@ -61,6 +61,12 @@ class PretrainStep:
         if config_option == 'frame2voxel':
             self.reconstructor = ImageReconstructor(self.front_end_sensor_b, self.input_height, self.input_width,
                                                     nr_temporal_bins, self.device)
+            # wavefront schedule of the 20 recurrent sub-windows over one HIP stream per ConvLSTM level (e2vid/wavefront.py);
+            # `self.wavefront = None` switches back to the single-stream order at any time (same results)
+            self.wavefront = None
+            if wavefront and self.device.type == 'cuda':
+                from ..e2vid.wavefront import EncoderWavefront
+                self.wavefront = EncoderWavefront(self.device, self.front_end_sensor_b.num_encoders)
         self.task_loss = TaskLoss(losses=list(task_loss), gamma=2.0, num_classes=num_classes, ignore_index=255)
         self.nce_loss = NCELoss(temperature=0.07)
         # createOptimizerDict (pretrain_trainer.py:225-259)
@@ -107,11 +113,16 @@ class PretrainStep:
             batch = (*batch[:3], online_pl, *batch[4:])
         if self.config_option == 'frame2voxel':
             event, frame, pl = batch[0], batch[2], batch[3]
+            wf = getattr(self, 'wavefront', None)
+            if wf is not None:
+                wf.begin()              # the level streams start here: the recurrent encoder also overlaps the teacher forward below
             feat_frame = self._teacher(frame)
             self.reconstructor.last_states_for_each_channel = {'grayscale': None}
             for i in range(self.nr_events_data):
                 _, _, latent_real = self.reconstructor.update_reconstruction(
-                    event, channel_slice=(i * self.bins, self.bins))
+                    event, channel_slice=(i * self.bins, self.bins), wavefront=wf)
+            if wf is not None:
+                wf.end()
             content = {k: v.detach() for k, v in latent_real.items()}          # trainTaskStepPretrain (:550-562)
             pred, feat_voxel = self.task_backend(content)
             loss_dense = self.task_loss(pred[1], pl) * self.weight_task_loss

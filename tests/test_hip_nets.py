@@ -461,3 +461,51 @@ def test_run_reconstruction_cli_end_to_end(tmp_path):
             img, st, _ = ref(on.event_preprocess(grid), st)
             want = (img[0, 0].clamp(0, 1) * 255.0).numpy()
             assert np.abs(frames[k].astype(np.float64) - want).max() <= 6.0, k          # 2e-2 of the [0, 1] image, in grey levels
+
+
+def test_wavefront_schedule_equals_single_stream_order():
+    """e2vid/wavefront.py: one HIP stream per ConvLSTM level, ordered by events, vs the single-stream order: same kernels on the
+    same buffers -> the latents of 7 recurrent sub-windows agree (EventPreprocessor's fp64 atomics are the only order-dependent
+    arithmetic), and a whole PretrainStep gives the same losses."""
+    from openess_amd.e2vid.image_reconstructor import ImageReconstructor
+    from openess_amd.e2vid.model.model import E2VIDRecurrent
+    from openess_amd.e2vid.wavefront import EncoderWavefront
+    from openess_amd.training.pretrain_step import PretrainStep
+    torch.manual_seed(1)
+    m = E2VIDRecurrent(E2VID_LIGHTWEIGHT_CONFIG).eval()
+    fill_by_name(m, 11)
+    m.cuda()
+    B, H, W, nwin = 2, 64, 96, 7
+    ev = (torch.randn(B, nwin * 5, H, W) * (torch.rand(B, nwin * 5, H, W) > 0.7)).contiguous().cuda()
+    outs = []
+    for use in (False, True, True):
+        rec = ImageReconstructor(m, H, W, 5, torch.device("cuda"))
+        wf = EncoderWavefront("cuda", 3) if use else None
+        if wf:
+            wf.begin()
+        for i in range(nwin):
+            _, _, latent = rec.update_reconstruction(ev, channel_slice=(5 * i, 5), wavefront=wf)
+        if wf:
+            wf.end()
+        torch.cuda.synchronize()
+        outs.append({k: v.float().clone() for k, v in latent.items()})
+    for k in (1, 2, 4, 8):
+        for o in outs[1:]:
+            assert (o[k] == outs[0][k]).float().mean().item() > 0.9999, k
+            assert torch.allclose(o[k], outs[0][k], atol=2e-2, rtol=2e-2), k
+    losses = []
+    for use in (False, True):
+        torch.manual_seed(3)
+        st = PretrainStep(config_option="frame2voxel", img_size=(H, W), nr_events_data=nwin, if_spatial_contrastive=True,
+                          superpixel_size=25, lr=1e-4, wavefront=use)
+        for name, mod in st.models_dict.items():
+            fill_by_name(mod, 100 + len(name))
+            damp_residual(mod)
+        frame = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(9)).cuda()
+        pl = torch.randint(0, 11, (B, H, W), generator=torch.Generator().manual_seed(9)).cuda()
+        sp = torch.randint(0, 25, (B, H // 8, W // 8), generator=torch.Generator().manual_seed(9)).repeat_interleave(8, 1).repeat_interleave(8, 2).cuda()
+        for _ in range(2):
+            ls, _, _ = st.train_step((ev, None, frame, pl, sp, B * 25))
+        losses.append({k: float(v) for k, v in ls.items()})
+    for k in losses[0]:
+        assert losses[1][k] == pytest.approx(losses[0][k], rel=2e-3), (k, losses)
