@@ -192,7 +192,7 @@ def pmc_traffic(timeout_s=420):
 
 # ------------------------------------------------------------------------------------------------ the step
 class Workload:
-    def __init__(self, name, rank, world, device, inputs, wavefront=True):
+    def __init__(self, name, rank, world, device, inputs, wavefront=False):
         from openess_amd.training.ddp import GradAllReduce, broadcast_module_states
         from openess_amd.training.pretrain_step import PretrainStep
         self.name, self.device, self.world = name, device, world
@@ -401,7 +401,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC child passes (roofline.traffic = null)")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only: no stages / configs / ingest blocks")
-    ap.add_argument("--no-wavefront", action="store_true", help="single-stream recurrent encoder in the timed region as well")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)        # profiled child of pmc_traffic(): steps only
     a = ap.parse_args()
 
@@ -417,21 +416,14 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     inputs = make_inputs(rank, device)
-    wl = Workload(a.workload, rank, world, device, inputs, wavefront=not (a.no_wavefront or a.child))
+    wl = Workload(a.workload, rank, world, device, inputs)
     if a.child:
         wl.timed(a.steps, a.warmup)
         return
-    # headline: the timed region runs the recurrent encoder as a wavefront over one HIP stream per ConvLSTM level (and under the
-    # teacher forward).  Overlapping kernels time-share the CUs, which stretches every per-launch duration, so the `roofline`
-    # object is measured right after it in a second, single-stream region of the same step (same kernels, same results).
-    dt, loss, _ = wl.timed(a.steps, a.warmup)
-    overlapped = getattr(wl.step, 'wavefront', None) is not None
-    n_roof = max(10, a.steps // 5)
-    wl.step.wavefront = None
-    dt_roof, _, conv_stats = wl.timed(n_roof, 1, conv_timing=True)
+    dt, loss, conv_stats = wl.timed(a.steps, a.warmup, conv_timing=True)
     if rank == 0 and os.environ.get("OESS_CONV_BREAKDOWN") and conv_stats:
         for k, (n, tm, fl) in sorted(conv_stats["by_shape"].items(), key=lambda kv: -kv[1][1]):
-            print(f"# conv HxWxCin->Cout k,s,d {k}: {n // n_roof:3d}/step {tm / n_roof:7.3f} ms/step {fl / tm / 1e9:7.1f} TF/s", file=sys.stderr)
+            print(f"# conv HxWxCin->Cout k,s,d {k}: {n // a.steps:3d}/step {tm / a.steps:7.3f} ms/step {fl / tm / 1e9:7.1f} TF/s", file=sys.stderr)
     extras = not a.no_extras
     out = None
     if rank == 0:
@@ -440,19 +432,13 @@ def main():
         roof = None
         if conv_stats and conv_stats["ms"] > 0:
             ach = conv_stats["flops"] / (conv_stats["ms"] * 1e-3) / 1e12
-            conv_stats["launches"] = conv_stats["launches"] * a.steps // n_roof      # per-step figures below divide by a.steps
-            conv_stats["flops"] *= a.steps / n_roof
-            conv_stats["ms"] *= a.steps / n_roof
             roof = {"bound": "mfma", "kernel": "conv3x3_halo_kernel<{0|1}> (3x3 stride-1, row-halo reuse; <1> = fused ConvLSTM epilogue) + conv_fwd_dma_kernel<{128|64},128,2> + short-K conv_fwd_dma32_kernel<128,..,3>: implicit-GEMM bf16 MFMA with LDS-DMA operands, every forward / data-gradient launch with Cout > 64; conv FLOPs only",
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                     "launches_per_step": conv_stats["launches"] // a.steps,
                     "avg_launch_us": round(conv_stats["ms"] * 1e3 / max(conv_stats["launches"], 1), 2),
                     "algorithmic_gflop_per_launch": round(conv_stats["flops"] / max(conv_stats["launches"], 1) / 1e9, 2),
-                    "share_of_step_time": round(conv_stats["ms"] / (dt_roof * 1e3), 3),
-                    "measured_over": f"{n_roof} single-stream steps after the timed region ({round(dt_roof / n_roof * 1e3, 3)} ms per step); "
-                                     + ("the timed region itself overlaps the three recurrent levels and the teacher on HIP streams"
-                                        if overlapped else "the timed region is single-stream too")}
+                    "share_of_step_time": round(conv_stats["ms"] / (dt * 1e3), 3)}
         out = {"metric": "event-frames/sec fwd+bwd @640x480 B=8", "value": round(value, 2), "unit": "event-frames/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
@@ -478,8 +464,8 @@ def main():
         del wl
         torch.cuda.empty_cache()
         cfgs = {}
-        for name in ("frame2voxel_full", "frame2recon_full"):
-            w2 = Workload(name, rank, world, device, inputs, wavefront=not a.no_wavefront)
+        for name in ("frame2voxel_full", "frame2recon_full", "frame2voxel_pixel_distill+wavefront"):
+            w2 = Workload(name.split("+")[0], rank, world, device, inputs, wavefront=name.endswith("+wavefront"))
             n2 = max(10, a.steps // 4)
             dt2, loss2, _ = w2.timed(n2, 3)
             cfgs[name] = {"value": round(world * B * n2 / dt2, 2), "unit": "event-frames/s", "ms_per_step": round(dt2 / n2 * 1e3, 3),
@@ -489,6 +475,9 @@ def main():
         if rank == 0:
             cfgs["frame2voxel_full"]["what"] = "BASELINE configs[2]: configs[1] + superpixel scatter-mean + InfoNCE (differentiable teacher head)"
             cfgs["frame2recon_full"]["what"] = "frame2recon pre-training: DeepLabv3/ASPP student + teacher + superpixel InfoNCE + Dice/CE"
+            cfgs["frame2voxel_pixel_distill+wavefront"]["what"] = ("the headline workload with the recurrent encoder scheduled as a wavefront over one "
+                                                                   "HIP stream per ConvLSTM level, overlapping the teacher forward (e2vid/wavefront.py; "
+                                                                   "opt-in: overlapped launches would blur the per-launch roofline timing)")
             out["configs"] = cfgs
     if rank == 0:
         if world == 1 and not a.no_pmc and out["roofline"] is not None:
