@@ -504,12 +504,14 @@ __global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const i
     for (int off = 32; off > 0; off >>= 1) vm = fmaxf(vm, __shfl_xor(vm, off, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(&wsum[16], __float_as_int(vm));        // non-negative floats order like ints
     // phase A: histogram, shifted by one so that the inclusive scan below yields exclusive starts
+    unsigned long long tl[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
+        tl[k] = 0ull;
         if (!ok[k]) continue;
         int tiles[4];
         const int nt = tri_tiles(rec[k].x, rec[k].y, g, tiles);
-        for (int j = 0; j < nt; ++j) atomicAdd(&cur[tiles[j] + 1], 1);
+        for (int j = 0; j < nt; ++j) { atomicAdd(&cur[tiles[j] + 1], 1); tl[k] |= (unsigned long long)(tiles[j] + 1) << (14 * j); }
     }
     __syncthreads();
     const int vmax_bits = wsum[16];
@@ -533,10 +535,10 @@ __global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const i
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
         if (!ok[k]) continue;
-        int tiles[4];
-        const int nt = tri_tiles(rec[k].x, rec[k].y, g, tiles);
-        for (int j = 0; j < nt; ++j) {
-            const int pos = atomicAdd(&cur[tiles[j]], 1);
+        for (int j = 0; j < 4; ++j) {
+            const int tj = (int)((tl[k] >> (14 * j)) & 0x3fff) - 1;
+            if (tj < 0) break;
+            const int pos = atomicAdd(&cur[tj], 1);
             if (pos < LCAP) buf[pos] = packed[k]; else if (base + (unsigned int)pos < cap) region[pos] = packed[k];
         }
     }
