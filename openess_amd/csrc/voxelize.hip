@@ -39,10 +39,19 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include "oess.h"
 #include "oess_common.h"
 
 namespace {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// Streaming store: the voxel grid (0.9 GB per batch) and the sorted records are written once and never re-read by the
+// writing kernel; non-temporal stores keep them from allocating in L2 (tools/probes/wg_floor_probe: the grid's tiled write
+// pattern runs at 161 us with them, 196 us without).
+__device__ __forceinline__ void store_stream(float4* p, const float4 v) {
+    __builtin_nontemporal_store(f32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_t*>(p));
+}
 
 constexpr int TW = 64;            // tile width (pixels) = one wave of lanes
 constexpr int THREADS = 256;
@@ -102,18 +111,27 @@ struct SrcF32 {                         // VoxelGrid.convert's own arguments
     }
     using Rec = float4;                 // {x, y, t_norm, value}
     static __device__ Rec sentinel() { return make_float4(0.f, 0.f, 2.0e9f, 0.f); }         // t_norm sentinel: no valid bin
-    __device__ Rec pack(int64_t, const TriRec& r, const Seg&) const { return make_float4(r.x, r.y, r.tn, r.v); }
+    __device__ Rec pack(const TriRec& r) const { return make_float4(r.x, r.y, r.tn, r.v); }
     __device__ TriRec unpack(const Rec& q) const { TriRec r; r.x = q.x; r.y = q.y; r.tn = q.z; r.v = q.w; return r; }
-    __device__ float2 load_xy(int64_t i, const Seg&) const { return make_float2(x[i], y[i]); }
-    __device__ TriRec load(int64_t i, const Seg& sg, int C) const {
+    // `at(base)`: the same source with its columns advanced to event `base`; load() then takes a 32-bit offset, so the
+    // address of every column is a uniform base + a lane offset (one VGPR) instead of a 64-bit pointer per column per event.
+    __device__ SrcF32 at(int64_t base) const { SrcF32 q = *this; q.x += base; q.y += base; q.p += base; q.t += base; return q; }
+    // The load is split in three so that the sort kernel can issue the column loads of all its events, then the dependent
+    // gathers, and only then compute: fetch (column loads), coords (SrcRaw: the rectify-map gather), finish (arithmetic).
+    struct Ev { float x, y, t, p; };
+    __device__ Ev fetch(unsigned int i) const { Ev v; v.x = x[i]; v.y = y[i]; v.t = t[i]; v.p = p[i]; return v; }
+    __device__ float2 coords(const Ev& v, const Seg&) const { return make_float2(v.x, v.y); }
+    template <bool UNIT_DENOM>
+    __device__ TriRec finish(const Ev& v, float2 xy, const Seg& sg, int C) const {
         TriRec r;
-        r.x = x[i]; r.y = y[i];
+        r.x = xy.x; r.y = xy.y;
         // representations.py:25  (C-1)*(t-t[0]) / (t[-1]-t[0])   float32, left to right
-        const float num = __fmul_rn((float)(C - 1), __fsub_rn(t[i], sg.t0));
-        r.tn = (sg.denom == 1.0f) ? num : num / sg.denom;         // x/1 == x exactly: skip the IEEE divide
-        r.v = __fsub_rn(__fmul_rn(2.0f, p[i]), 1.0f);             // representations.py:31
+        const float num = __fmul_rn((float)(C - 1), __fsub_rn(v.t, sg.t0));
+        r.tn = UNIT_DENOM ? num : num / sg.denom;                 // x/1 == x exactly: skip the IEEE divide
+        r.v = __fsub_rn(__fmul_rn(2.0f, v.p), 1.0f);              // representations.py:31
         return r;
     }
+    __device__ bool unit_denom(const Seg& sg) const { return sg.denom == 1.0f; }
 };
 
 struct SrcRaw {                         // raw DSEC columns + rectify map (sequence_ov.py:154-157,204-210)
@@ -134,48 +152,51 @@ struct SrcRaw {                         // raw DSEC columns + rectify map (seque
     //                                     {x | y << 12 | p << 24, t_norm} record + a second map gather in the splat was measured
     //                                     slower (the pipeline is bound by cache-line REQUESTS, not bytes: 17 M more gathers)
     static __device__ Rec sentinel() { return make_float4(0.f, 0.f, 2.0e9f, 0.f); }
-    __device__ Rec pack(int64_t, const TriRec& r, const Seg&) const { return make_float4(r.x, r.y, r.tn, r.v); }
+    __device__ Rec pack(const TriRec& r) const { return make_float4(r.x, r.y, r.tn, r.v); }
     __device__ TriRec unpack(const Rec& q) const { TriRec r; r.x = q.x; r.y = q.y; r.tn = q.z; r.v = q.w; return r; }
-    __device__ float2 load_xy(int64_t i, const Seg& sg) const {
-        int xi = x[i], yi = y[i];
-        if (xi >= W) xi = W - 1;                                   // reference asserts x.max() < width
-        if (yi >= H) yi = H - 1;
-        return *reinterpret_cast<const float2*>(sg.map + ((size_t)yi * W + xi) * 2);
+    __device__ SrcRaw at(int64_t base) const { SrcRaw q = *this; q.x += base; q.y += base; q.t += base; q.p += base; return q; }
+    struct Ev { int x, y; int64_t t; int p; };
+    __device__ Ev fetch(unsigned int i) const { Ev v; v.x = x[i]; v.y = y[i]; v.t = t[i]; v.p = p[i]; return v; }
+    __device__ float2 coords(const Ev& v, const Seg& sg) const {
+        const int xi = v.x >= W ? W - 1 : v.x;                     // reference asserts x.max() < width
+        const int yi = v.y >= H ? H - 1 : v.y;
+        return *reinterpret_cast<const float2*>(sg.map + (unsigned int)(yi * W + xi) * 2u);
     }
-    __device__ TriRec load(int64_t i, const Seg& sg, int C) const {
+    template <bool UNIT_DENOM>
+    __device__ TriRec finish(const Ev& v, float2 xy, const Seg& sg, int C) const {
         TriRec r;
-        const float2 m = load_xy(i, sg);
-        r.x = m.x; r.y = m.y;
-        const int64_t d = t[i] - sg.t0;
-        // int64 -> float64 -> float32 is a single rounding of an exact integer; for |d| < 2^31 the
-        // native int32 -> float32 conversion gives the identical result
-        const float df = (d == (int64_t)(int)d) ? (float)(int)d : (float)(double)d;
+        r.x = xy.x; r.y = xy.y;
+        const int64_t d = v.t - sg.t0;
+        // int64 -> float64 -> float32 is a single rounding of an exact integer; for |d| < 2^31 the native
+        // int32 -> float32 conversion gives the identical result.  Wave-uniform choice: windows are far shorter than 2^31 us.
+        float df = (float)(int)d;
+        if (__any(d != (int64_t)(int)d)) df = (float)(double)d;
         const float tt = df / sg.dlast;
         const float num = __fmul_rn((float)(C - 1), __fsub_rn(tt, sg.tn0));
-        r.tn = (sg.denom == 1.0f) ? num : num / sg.denom;
-        r.v = __fsub_rn(__fmul_rn(2.0f, (float)p[i]), 1.0f);
+        r.tn = UNIT_DENOM ? num : num / sg.denom;
+        r.v = __fsub_rn(__fmul_rn(2.0f, (float)v.p), 1.0f);
         return r;
     }
+    __device__ bool unit_denom(const Seg& sg) const { return sg.denom == 1.0f; }
 };
 
-// Tiles touched by a tri-linear event.  Returns the number of tiles (0..4) in tiles[].
-// Membership is purely spatial (count and scatter must agree without reading t in the count pass);
-// the splat applies the time-bin masks.
-__device__ __forceinline__ int tri_tiles(float x, float y, const Geom& g, int tiles[4]) {
-    if (x != x || y != y) return 0;
+// Tiles touched by a tri-linear event, as straight-line code: the event's pixel pair (x0, x0+1) x (y0, y0+1) meets at most
+// 2 x 2 tiles, tile(a, b) = t00 + a * tilesX + b.  Returns (t00 + tilesX + 1) << 4 | mask with mask bit (2a + b) set when
+// tile (a, b) holds a valid corner; the second column / row only counts when it is a different tile from the first.
+// Membership is purely spatial; the splat applies the time-bin masks.  NaN coordinates clamp to -8: no tile.
+__device__ __forceinline__ unsigned int tri_tiles(float x, float y, const Geom& g) {
     // clamp before the int conversion so that huge coordinates stay "far outside" instead of UB
-    float fx = fminf(fmaxf(x, -8.0f), (float)g.W + 8.0f);
-    float fy = fminf(fmaxf(y, -8.0f), (float)g.H + 8.0f);
-    int x0 = (int)fx, y0 = (int)fy;                 // C-style truncation (representations.py:27-28)
-    int cx[2], cy[2], ncx = 0, ncy = 0;
-    if (x0 >= 0 && x0 < g.W) cx[ncx++] = x0 >> 6;
-    if (x0 + 1 >= 0 && x0 + 1 < g.W) { int c = (x0 + 1) >> 6; if (ncx == 0 || cx[0] != c) cx[ncx++] = c; }
-    if (y0 >= 0 && y0 < g.Hout) cy[ncy++] = y0 >> g.lgTH;
-    if (y0 + 1 >= 0 && y0 + 1 < g.Hout) { int c = (y0 + 1) >> g.lgTH; if (ncy == 0 || cy[0] != c) cy[ncy++] = c; }
-    int n = 0;
-    for (int a = 0; a < ncy; ++a)
-        for (int b = 0; b < ncx; ++b) tiles[n++] = cy[a] * g.tilesX + cx[b];
-    return n;
+    const float fx = fminf(fmaxf(x, -8.0f), (float)g.W + 8.0f);
+    const float fy = fminf(fmaxf(y, -8.0f), (float)g.H + 8.0f);
+    const int x0 = (int)fx, y0 = (int)fy;           // C-style truncation (representations.py:27-28)
+    const int cxa = x0 >> 6, cxb = (x0 + 1) >> 6, cya = y0 >> g.lgTH, cyb = (y0 + 1) >> g.lgTH;
+    const bool vxa = (unsigned int)x0 < (unsigned int)g.W;
+    const bool vxb = (unsigned int)(x0 + 1) < (unsigned int)g.W && (!vxa || cxb != cxa);
+    const bool vya = (unsigned int)y0 < (unsigned int)g.Hout;
+    const bool vyb = (unsigned int)(y0 + 1) < (unsigned int)g.Hout && (!vya || cyb != cya);
+    const unsigned int mask = (unsigned int)(vya && vxa) | (unsigned int)(vya && vxb) << 1 | (unsigned int)(vyb && vxa) << 2 |
+                              (unsigned int)(vyb && vxb) << 3;
+    return (unsigned int)(cya * g.tilesX + cxa + g.tilesX + 1) << 4 | mask;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -486,32 +507,45 @@ __global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const i
     int64_t sl_end = sl_beg + SSL;
     if (sl_end > n) sl_end = n;
     const typename Src::Seg sg = src.seg(s, b, e);
-    TriRec rec[EPT];
+    const Src here = src.at(b + sl_beg);                 // columns at the slice's first event: 32-bit lane offsets from here on
+    const unsigned int n_here = (unsigned int)(sl_end - sl_beg);
     Rec packed[EPT];
-    bool ok[EPT];
+    unsigned int tl[EPT];                                // tri_tiles code of the event; 0 = no tile (or past the slice's end)
     float vm = 0.f;
+    // the only read of the events: EPT independent column loads per lane, all issued before the first use, then the
+    // dependent gathers likewise (the kernel lives on memory-level parallelism; a loop that loads and computes per event
+    // measured 10 % slower)
+    typename Src::Ev ev[EPT];
+    float2 xy[EPT];
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) {                      // the only read of the events: EPT independent loads per lane
-        const int64_t i = sl_beg + k * SORT_THREADS + threadIdx.x;
-        ok[k] = i < sl_end;
-        const int64_t ii = b + (ok[k] ? i : sl_end - 1);
-        rec[k] = src.load(ii, sg, g.C);
-        packed[k] = src.pack(ii, rec[k], sg);
-        const float av = fabsf(rec[k].v);
-        if (ok[k]) vm = (av != av) ? __int_as_float(0x7f800000) : fmaxf(vm, av);     // NaN value: force the 64-bit path
-    }
+    for (int k = 0; k < EPT; ++k) ev[k] = here.fetch(min(k * SORT_THREADS + threadIdx.x, n_here - 1));
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) xy[k] = here.coords(ev[k], sg);
+    auto load_all = [&](auto unit_c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const bool ok = k * SORT_THREADS + threadIdx.x < n_here;
+            const TriRec r = here.template finish<decltype(unit_c)::value>(ev[k], xy[k], sg, g.C);
+            packed[k] = here.pack(r);
+            float av = fabsf(r.v);
+            av = (av != av) ? __int_as_float(0x7f800000) : av;                        // NaN value: force the 64-bit path
+            vm = fmaxf(vm, ok ? av : 0.f);
+            tl[k] = ok ? tri_tiles(r.x, r.y, g) : 0u;
+        }
+    };
+    if (here.unit_denom(sg)) load_all(std::true_type{}); else load_all(std::false_type{});     // block-uniform
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) vm = fmaxf(vm, __shfl_xor(vm, off, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(&wsum[16], __float_as_int(vm));        // non-negative floats order like ints
     // phase A: histogram, shifted by one so that the inclusive scan below yields exclusive starts
-    unsigned long long tl[EPT];
+    const int tx1 = g.tilesX + 1;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-        tl[k] = 0ull;
-        if (!ok[k]) continue;
-        int tiles[4];
-        const int nt = tri_tiles(rec[k].x, rec[k].y, g, tiles);
-        for (int j = 0; j < nt; ++j) { atomicAdd(&cur[tiles[j] + 1], 1); tl[k] |= (unsigned long long)(tiles[j] + 1) << (14 * j); }
+        int* c = &cur[(int)(tl[k] >> 4) - tx1 + 1];      // counter of tile (0, 0) + 1
+        if (tl[k] & 1u) atomicAdd(c, 1);
+        if (tl[k] & 2u) atomicAdd(c + 1, 1);
+        if (tl[k] & 4u) atomicAdd(c + g.tilesX, 1);
+        if (tl[k] & 8u) atomicAdd(c + g.tilesX + 1, 1);
     }
     __syncthreads();
     const int vmax_bits = wsum[16];
@@ -532,24 +566,51 @@ __global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const i
     __syncthreads();                                     // column stored before the cursors start moving
     Rec* region = recs + base;
     // phase B: rank inside the tile by LDS integer atomic, stage in LDS
+    auto place = [&](int* c, const Rec& q) __attribute__((always_inline)) {
+        const int pos = atomicAdd(c, 1);
+        if (pos < LCAP) buf[pos] = q; else if (base + (unsigned int)pos < cap) region[pos] = q;
+    };
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-        if (!ok[k]) continue;
-        for (int j = 0; j < 4; ++j) {
-            const int tj = (int)((tl[k] >> (14 * j)) & 0x3fff) - 1;
-            if (tj < 0) break;
-            const int pos = atomicAdd(&cur[tj], 1);
-            if (pos < LCAP) buf[pos] = packed[k]; else if (base + (unsigned int)pos < cap) region[pos] = packed[k];
-        }
+        int* c = &cur[(int)(tl[k] >> 4) - tx1];
+        if (tl[k] & 1u) place(c, packed[k]);
+        if (tl[k] & 2u) place(c + 1, packed[k]);
+        if (tl[k] & 4u) place(c + g.tilesX, packed[k]);
+        if (tl[k] & 8u) place(c + g.tilesX + 1, packed[k]);
     }
     __syncthreads();
     const int staged = total < LCAP ? total : LCAP;
     for (int i = threadIdx.x; i < staged; i += SORT_THREADS)
-        if (base + (unsigned int)i < cap) region[i] = buf[i];                      // whole, exclusively owned lines
+        if (base + (unsigned int)i < cap) store_stream(&region[i], buf[i]);        // whole, exclusively owned lines
+}
+
+// Wave64 inclusive scan / max on the DPP network (row_shr 1,2,4,8 inside the 16-lane rows, then row_bcast:15 and :31 across
+// them): six VALU instructions each and no LDS traffic, where __shfl_up costs a ds_bpermute per step.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_or_zero(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ int wave_incl_scan_add(int v) {
+    v += dpp_or_zero<0x111, 0xf>(v);
+    v += dpp_or_zero<0x112, 0xf>(v);
+    v += dpp_or_zero<0x114, 0xf>(v);
+    v += dpp_or_zero<0x118, 0xf>(v);
+    v += dpp_or_zero<0x142, 0xa>(v);
+    v += dpp_or_zero<0x143, 0xc>(v);
+    return v;
+}
+// max over the wave of non-negative floats (0 is the identity), returned wave-uniform
+__device__ __forceinline__ float wave_max_nonneg(float f) {
+    auto step = [](float a, int b) { return fmaxf(a, __int_as_float(b)); };
+    f = step(f, dpp_or_zero<0x111, 0xf>(__float_as_int(f)));
+    f = step(f, dpp_or_zero<0x112, 0xf>(__float_as_int(f)));
+    f = step(f, dpp_or_zero<0x114, 0xf>(__float_as_int(f)));
+    f = step(f, dpp_or_zero<0x118, 0xf>(__float_as_int(f)));
+    f = step(f, dpp_or_zero<0x142, 0xa>(__float_as_int(f)));
+    f = step(f, dpp_or_zero<0x143, 0xc>(__float_as_int(f)));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), 63));
 }
 
 constexpr int RUN_CHUNK = 64;            // slices whose runs are gathered per splat iteration: one per lane, kept in
-                                         // registers (wave scan + ds_bpermute search): no LDS beyond the accumulators
+                                         // registers: no LDS beyond the accumulators
 
 // rows [row_lo, row_lo + rows) of tile (tx, .) -> out, every voxel once, float4 per lane
 template <typename ACC>
@@ -562,17 +623,30 @@ __device__ __forceinline__ void write_rows(const ACC* acc, float inv_scale, floa
         if (sizeof(ACC) == 8) return from_fix((long long)a);
         return __fmul_rn((float)(int)a, inv_scale);
     };
-    if ((g.W & 3) == 0) {
-        const int q_per_row = TW / 4;
-        const int total = g.C * rows * q_per_row;
+    constexpr int Q = TW / 4, RPI = THREADS / Q;      // float4s per tile row, tile rows covered per iteration (16)
+    if ((g.W & 3) == 0 && rows <= RPI) {
+        // the common shape: a lane keeps its (row, column) and walks the channels with constant strides
+        const int q = threadIdx.x & (Q - 1), rc0 = threadIdx.x / Q;
+        const int rr = rc0 & (rows - 1), cstep = RPI >> lgr;
+        const int xx = x_base + q * 4, yy = row_lo + rr;
+        if (xx < g.W && yy < g.Hout) {
+            int c = rc0 >> lgr;
+            const ACC* a = &acc[(c * rows + rr) * TW + q * 4];
+            float* o = &out[((size_t)s * g.C + c) * plane + (size_t)yy * g.W + xx];
+            const size_t ostep = (size_t)cstep * plane;
+            for (; c < g.C; c += cstep, a += RPI * TW, o += ostep)
+                store_stream(reinterpret_cast<float4*>(o), make_float4(cvt(a[0]), cvt(a[1]), cvt(a[2]), cvt(a[3])));
+        }
+    } else if ((g.W & 3) == 0) {
+        const int total = g.C * rows * Q;
         for (int i = threadIdx.x; i < total; i += THREADS) {
-            const int q = i & (q_per_row - 1), rc = i >> 4;          // q_per_row == 16
+            const int q = i & (Q - 1), rc = i / Q;
             const int rr = rc & (rows - 1), c = rc >> lgr;
             const int xx = x_base + q * 4, yy = row_lo + rr;
             if (xx < g.W && yy < g.Hout) {
                 const ACC* a = &acc[(c * rows + rr) * TW + q * 4];
-                *reinterpret_cast<float4*>(&out[((size_t)s * g.C + c) * plane + (size_t)yy * g.W + xx]) =
-                    make_float4(cvt(a[0]), cvt(a[1]), cvt(a[2]), cvt(a[3]));
+                store_stream(reinterpret_cast<float4*>(&out[((size_t)s * g.C + c) * plane + (size_t)yy * g.W + xx]),
+                             make_float4(cvt(a[0]), cvt(a[1]), cvt(a[2]), cvt(a[3])));
             }
         }
     } else {
@@ -586,161 +660,211 @@ __device__ __forceinline__ void write_rows(const ACC* acc, float inv_scale, floa
     }
 }
 
-// One (segment, tile) item per workgroup.  A persistent grid (8 workgroups per CU walking the items, next item's table rows
-// prefetched) was built and measured SLOWER (329 vs 262 us): the hardware dispatcher balances the uneven items better than a
-// static loop, and the launch of 192 k waves is not what the 72 us floor of the empty kernel consists of.
+// One record into the LDS tile: the eight corners as straight-line code.  Validity is one unsigned compare per axis end
+// (tw_eff / rows_eff already hold the image border), the six axis weights are computed once, and the power-of-two scale of
+// the 32-bit accumulators is folded into the value up front (scaling by 2^sh commutes with every rounding of the product
+// chain; where it does not - an intermediate below 2^-126 - both orders round to the integer 0).
+// representations.py:39  value * (1-|xlim-x|) * (1-|ylim-y|) * (1-|tlim-t_norm|), float32, in that order.
+template <bool FAST, bool COUNT>
+__device__ __forceinline__ void splat_record(const TriRec r, const Geom& g, int x_lo, unsigned int tw_eff, int row_lo,
+                                             unsigned int rows_eff, int rows, float scale, int* acc32) {
+    const float x = r.x, y = r.y, tn = r.tn;
+    const float fx = fminf(fmaxf(x, -8.0f), (float)g.W + 8.0f);
+    const float fy = fminf(fmaxf(y, -8.0f), (float)g.H + 8.0f);
+    // NaN/inf time: Tensor.int() gives INT_MIN on the CPU -> every corner masked
+    const int x0 = (int)fx, y0 = (int)fy, t0 = (fabsf(tn) < 1.0e9f) ? (int)tn : 0x40000000;
+    const int lx = x0 - x_lo, ly = y0 - row_lo;
+    const bool vx0 = (unsigned int)lx < tw_eff, vx1 = (unsigned int)(lx + 1) < tw_eff;
+    const bool vy0 = (unsigned int)ly < rows_eff, vy1 = (unsigned int)(ly + 1) < rows_eff;
+    const bool vt0 = (unsigned int)t0 < (unsigned int)g.C, vt1 = (unsigned int)(t0 + 1) < (unsigned int)g.C;
+    const float val = FAST ? __fmul_rn(r.v, scale) : r.v;
+    const float wx0 = __fmul_rn(val, __fsub_rn(1.0f, fabsf(__fsub_rn((float)x0, x))));
+    const float wx1 = __fmul_rn(val, __fsub_rn(1.0f, fabsf(__fsub_rn((float)(x0 + 1), x))));
+    const float by0 = __fsub_rn(1.0f, fabsf(__fsub_rn((float)y0, y)));
+    const float by1 = __fsub_rn(1.0f, fabsf(__fsub_rn((float)(y0 + 1), y)));
+    const float ct0 = __fsub_rn(1.0f, fabsf(__fsub_rn((float)t0, tn)));
+    const float ct1 = __fsub_rn(1.0f, fabsf(__fsub_rn((float)(t0 + 1), tn)));
+    const int base = (t0 * rows + ly) * TW + lx;
+    const int tstep = rows * TW;
+    auto add = [&](bool m, int off, float wxy, float ct) {
+        if (!m) return;
+        if (FAST) {
+            const int wi = COUNT ? (int)scale : __float2int_rn(__fmul_rn(wxy, ct));
+            atomicAdd(&acc32[base + off], wi);                                                   // ds_add_u32
+        } else {
+            lds_add(reinterpret_cast<long long*>(acc32) + (base + off), to_fix(COUNT ? 1.0f : __fmul_rn(wxy, ct)));
+        }
+    };
+    const float w00 = __fmul_rn(wx0, by0), w01 = __fmul_rn(wx0, by1), w10 = __fmul_rn(wx1, by0), w11 = __fmul_rn(wx1, by1);
+    add(vx0 && vy0 && vt0, 0, w00, ct0);
+    add(vx0 && vy0 && vt1, tstep, w00, ct1);
+    add(vx0 && vy1 && vt0, TW, w01, ct0);
+    add(vx0 && vy1 && vt1, TW + tstep, w01, ct1);
+    add(vx1 && vy0 && vt0, 1, w10, ct0);
+    add(vx1 && vy0 && vt1, 1 + tstep, w10, ct1);
+    add(vx1 && vy1 && vt0, TW + 1, w11, ct0);
+    add(vx1 && vy1 && vt1, TW + 1 + tstep, w11, ct1);
+}
+
+// One (segment, tile) item per workgroup, grid (tilesX, tilesY, segments).  A persistent grid (8 workgroups per CU walking
+// the items, next item's table rows prefetched) was built and measured SLOWER (329 vs 262 us): the hardware dispatcher
+// balances the uneven items better than a static loop.
+//
+// The kernel is VALU-issue bound (r02 PMC: SQ_INSTS_VALU x 4 cycles / 1024 SIMDs = its whole duration), so the code below
+// is arranged for instruction count: straight-line corners (splat_record), run lookup by LDS marks instead of a per-lane
+// binary search, constant-stride write-out, no integer divisions.
 template <typename Src>
 __global__ __launch_bounds__(THREADS) void tri_splat_kernel(Src src, const typename Src::Rec* __restrict__ recs,
                                                             const int* __restrict__ table, Geom g, int nSl, int count_mode,
-                                                            unsigned int cap, float* __restrict__ out) {
+                                                            unsigned int cap, int s_base, float* __restrict__ out) {
     using Rec = typename Src::Rec;
     extern __shared__ __attribute__((aligned(16))) int acc32[];          // [C][TH][TW] ints == [C][TH/2][TW] long longs
-    long long* acc64 = reinterpret_cast<long long*>(acc32);
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nT = g.nTiles;
-    // chunk-0 run-table entries of an item, one slice per lane
-    auto load_rows = [&](int item, int& cnt, unsigned int& beg, float& vm) {
-        cnt = 0; beg = 0; vm = 0.f;
-        if (lane < nSl) {
-            const int s = item / nT, tile = item - s * nT;
-            const int* trow = table + ((size_t)s * (nT + 2) + tile) * nSl;
-            const int st = trow[lane], en = trow[nSl + lane];
-            cnt = en - st;
-            beg = (unsigned int)(((size_t)s * nSl + lane) * RSTRIDE) + (unsigned int)st;
-            vm = __int_as_float(table[((size_t)s * (nT + 2) + nT + 1) * nSl + lane]);
-        }
-    };
-    {
-        const int item = blockIdx.x;                                     // = segment * nTiles + tile
-        const int s = item / nT, tile = item - s * nT;
-        const int ty = tile / g.tilesX, tx = tile - ty * g.tilesX;
-        const int x_lo = tx * TW, y_lo = ty * g.TH;
-        int cnt0; unsigned int beg0; float vmax;
-        load_rows(item, cnt0, beg0, vmax);
-        // ---- accumulator choice: every voxel sum of this tile is bounded by (records of the tile) x max |value|
-        int total_all = cnt0;
-        for (int c0 = RUN_CHUNK; c0 < nSl; c0 += RUN_CHUNK) {             // segments longer than 64 slices (rare): on demand
-            if (c0 + lane < nSl) {
-                const int* trow = table + ((size_t)s * (nT + 2) + tile) * nSl;
-                total_all += trow[nSl + c0 + lane] - trow[c0 + lane];
-                vmax = fmaxf(vmax, __int_as_float(table[((size_t)s * (nT + 2) + nT + 1) * nSl + c0 + lane]));
-            }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            total_all += __shfl_xor(total_all, off, 64);
-            vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
-        }
-        if (count_mode) vmax = 1.0f;
-        const float boundf = (float)total_all * vmax + 1.0f;             // +inf for a NaN / inf value: 64-bit path
-        int sh = 0;
-        if (boundf < 1024.0f) {
-            const int bnd = (int)boundf;                                 // >= 1
-            const int lg = (bnd <= 1) ? 0 : 32 - __clz(bnd - 1);         // ceil(log2(bnd))
-            sh = 30 - (lg < 1 ? 1 : lg);
-            if (sh > 24) sh = 24;
-        }
-        const bool fast = sh >= 20;                                      // wave- and block-uniform
-        const float scale = __int_as_float((127 + sh) << 23), inv_scale = __int_as_float((127 - sh) << 23);
+    const int s = s_base + blockIdx.z, tx = blockIdx.x, ty = blockIdx.y;
+    const int tile = ty * g.tilesX + tx;
+    const int x_lo = tx * TW, y_lo = ty * g.TH;
+    const int* trow = table + ((size_t)s * (nT + 2) + tile) * nSl;       // run starts of this tile, one per slice; ends follow
+    const int* vrow = table + ((size_t)s * (nT + 2) + nT + 1) * nSl;     // max |value| of each slice
 
-        auto run_pass = [&](const int row_lo, const int rows) {
-            const int lds_n = g.C * rows * TW;
-            auto splat = [&](const Rec q) {
-                const TriRec r = src.unpack(q);
-                const float x = r.x, y = r.y, tn = r.tn, val = r.v;
-                const float fx = fminf(fmaxf(x, -8.0f), (float)g.W + 8.0f);
-                const float fy = fminf(fmaxf(y, -8.0f), (float)g.H + 8.0f);
-                // NaN/inf time: Tensor.int() gives INT_MIN on the CPU -> every corner masked
-                const int x0 = (int)fx, y0 = (int)fy, t0 = (fabsf(tn) < 1.0e9f) ? (int)tn : 0x40000000;
+    // chunk 0 of the run table: one slice per lane
+    int cnt0 = 0; unsigned int beg0 = 0; float vmax = 0.f;
+    if (lane < nSl) {
+        const int st = trow[lane], en = trow[nSl + lane];
+        cnt0 = en - st;
+        beg0 = (unsigned int)(((size_t)s * nSl + lane) * RSTRIDE) + (unsigned int)st;
+        vmax = __int_as_float(vrow[lane]);
+    }
+    const int incl0 = wave_incl_scan_add(cnt0);
+    const int total0 = __builtin_amdgcn_readlane(incl0, 63);               // SGPR: the loops below are wave-uniform
+    // ---- accumulator choice: every voxel sum of this tile is bounded by (records of the tile) x max |value|
+    int total_all = total0;
+    if (nSl > RUN_CHUNK) {                                               // segments longer than 64 slices (rare)
+        int extra = 0;
+        for (int c0 = RUN_CHUNK; c0 < nSl; c0 += RUN_CHUNK)
+            if (c0 + lane < nSl) {
+                extra += trow[nSl + c0 + lane] - trow[c0 + lane];
+                vmax = fmaxf(vmax, __int_as_float(vrow[c0 + lane]));
+            }
 #pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    const int xl = x0 + dx;
-                    const int lx = xl - x_lo;
-                    if (xl < 0 || xl >= g.W || lx < 0 || lx >= TW) continue;
-                    // representations.py:39  value * (1-|xlim-x|) * (1-|ylim-y|) * (1-|tlim-t_norm|), float32
-                    const float wx = __fmul_rn(val, __fsub_rn(1.0f, fabsf(__fsub_rn((float)xl, x))));
-#pragma unroll
-                    for (int dy = 0; dy < 2; ++dy) {
-                        const int yl = y0 + dy;
-                        const int ly = yl - row_lo;
-                        if (yl < 0 || yl >= g.Hout || ly < 0 || ly >= rows) continue;
-                        const float wxy = __fmul_rn(wx, __fsub_rn(1.0f, fabsf(__fsub_rn((float)yl, y))));
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) {
-                            const int tl = t0 + dt;
-                            if (tl < 0 || tl >= g.C) continue;
-                            float w = __fmul_rn(wxy, __fsub_rn(1.0f, fabsf(__fsub_rn((float)tl, tn))));
-                            if (count_mode) w = 1.0f;
-                            const int idx = (tl * rows + ly) * TW + lx;
-                            if (fast) atomicAdd(&acc32[idx], __float2int_rn(__fmul_rn(w, scale)));      // ds_add_u32
-                            else lds_add(&acc64[idx], to_fix(w));                                       // ds_add_u64
-                        }
-                    }
+        for (int off = 32; off > 0; off >>= 1) extra += __shfl_xor(extra, off, 64);
+        total_all += __builtin_amdgcn_readfirstlane(extra);
+    }
+    vmax = wave_max_nonneg(vmax);
+    if (count_mode) vmax = 1.0f;
+    const float boundf = (float)total_all * vmax + 1.0f;                 // +inf for a NaN / inf value: 64-bit path
+    int sh = 0;
+    if (boundf < 1024.0f) {
+        const int bnd = (int)boundf;                                     // >= 1
+        const int lg = (bnd <= 1) ? 0 : 32 - __clz(bnd - 1);             // ceil(log2(bnd))
+        sh = 30 - (lg < 1 ? 1 : lg);
+        if (sh > 24) sh = 24;
+    }
+    const bool fast = sh >= 20;                                          // wave- and block-uniform
+    const float scale = __int_as_float((127 + sh) << 23), inv_scale = __int_as_float((127 - sh) << 23);
+    const unsigned int tw_eff = (unsigned int)min(TW, g.W - x_lo);
+
+    auto run_pass = [&](auto fast_c, auto count_c, const int row_lo, const int rows) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fast_c)::value, COUNT = decltype(count_c)::value;
+        const int lds_n = g.C * rows * TW * (FAST ? 1 : 2);              // in ints
+        const unsigned int rows_eff = (unsigned int)max(0, min(rows, g.Hout - row_lo));
+        auto splat = [&](const Rec q) __attribute__((always_inline)) {
+            splat_record<FAST, COUNT>(src.unpack(q), g, x_lo, tw_eff, row_lo, rows_eff, rows, scale, acc32);
+        };
+        for (int c0 = 0; c0 < nSl; c0 += RUN_CHUNK) {
+            const int nc = (nSl - c0 < RUN_CHUNK) ? nSl - c0 : RUN_CHUNK;
+            int cnt = cnt0, incl = incl0, total = total0;
+            unsigned int beg = beg0;
+            if (c0 > 0) {
+                cnt = 0; beg = 0;
+                if (lane < nc) {
+                    const int st = trow[c0 + lane], en = trow[nSl + c0 + lane];
+                    cnt = en - st;
+                    beg = (unsigned int)(((size_t)s * nSl + c0 + lane) * RSTRIDE) + (unsigned int)st;
                 }
+                incl = wave_incl_scan_add(cnt);
+                total = __builtin_amdgcn_readlane(incl, 63);
+            }
+            const int excl = incl - cnt;
+            // record j of the concatenated runs, general form: per-lane binary search over the run starts (ds_bpermute).
+            // All lanes take part in the shuffles (fixed trip count, j clamped); only the load is predicated.
+            auto fetch_search = [&](int j) __attribute__((always_inline)) -> Rec {
+                const bool valid = j < total;
+                const int jj = valid ? j : 0;
+                int lo = 0, hi = nc;                                       // largest run index with excl[idx] <= jj
+#pragma unroll
+                for (int step = 0; step < 6; ++step) {
+                    const int mid = (lo + hi) >> 1;
+                    const int v = __shfl(excl, mid, 64);
+                    if (hi - lo > 1) { if (v <= jj) lo = mid; else hi = mid; }
+                }
+                const unsigned int ri = (unsigned int)__shfl((int)beg, lo, 64) + (unsigned int)(jj - __shfl(excl, lo, 64));
+                return (valid && ri < cap) ? recs[ri] : Src::sentinel();
             };
-            for (int c0 = 0; c0 < nSl; c0 += RUN_CHUNK) {
-                const int nc = (nSl - c0 < RUN_CHUNK) ? nSl - c0 : RUN_CHUNK;
-                int cnt = cnt0;
-                unsigned int beg = beg0;
-                if (c0 > 0) {
-                    cnt = 0; beg = 0;
-                    if (lane < nc) {
-                        const int* trow = table + ((size_t)s * (nT + 2) + tile) * nSl;
-                        const int st = trow[c0 + lane], en = trow[nSl + c0 + lane];
-                        cnt = en - st;
-                        beg = (unsigned int)(((size_t)s * nSl + c0 + lane) * RSTRIDE) + (unsigned int)st;
+            Rec pre[PRE];
+            if (c0 == 0) {
+                // The first PRE x THREADS records (all of them, for all but the densest tiles) are located without a search
+                // while the accumulator LDS is still free.  The non-empty runs are compacted to the low lanes (one bijective
+                // ds_permute), so their starts are strictly increasing; a wave whose 64 lanes want records j0 .. j0+63 lets
+                // every run starting inside (j0, j0+64) mark its start in a 64-entry LDS row, and lane L's run is
+                //   (runs starting at or before j0) - 1 + (marks at positions <= L).
+                // The row of wave w lies in words the same wave zero-fills afterwards: no barrier is involved.
+                const unsigned long long ne = __ballot(cnt > 0);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(ne >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)ne, 0u));
+                const int nne = __popcll(ne);
+                const int dst = (cnt > 0) ? rank : nne + (lane - rank);
+                int c_excl = __builtin_amdgcn_ds_permute(dst << 2, excl);
+                const int c_off = __builtin_amdgcn_ds_permute(dst << 2, (int)beg - excl);     // record index = c_off[run] + j
+                if (lane >= nne) c_excl = 0x7fffffff;
+                int* mark = acc32 + wave * 128;                            // words [128 w, 128 w + 64)
+#pragma unroll
+                for (int k = 0; k < PRE; ++k) {                            // in flight under the LDS zero fill
+                    pre[k] = Src::sentinel();
+                    if (k * THREADS < total) {
+                        const int j0 = k * THREADS + wave * 64;
+                        const int d = c_excl - j0;
+                        const int below = __popcll(__ballot(d <= 0));
+                        mark[lane] = 0;
+                        __builtin_amdgcn_wave_barrier();
+                        if ((unsigned int)(d - 1) < 63u) mark[d] = 1;
+                        __builtin_amdgcn_wave_barrier();
+                        const int flag = mark[lane];
+                        __builtin_amdgcn_wave_barrier();
+                        const unsigned long long m = __ballot(flag != 0);
+                        const int run = below - 1 + flag +
+                            (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+                        const int j = j0 + lane;
+                        const unsigned int ri = (unsigned int)__shfl(c_off, run, 64) + (unsigned int)j;
+                        if (j < total && ri < cap) pre[k] = recs[ri];
                     }
                 }
-                int incl = cnt;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int y = __shfl_up(incl, off, 64);
-                    if (lane >= off) incl += y;
-                }
-                const int excl = incl - cnt;
-                const int total = __shfl(incl, 63, 64);
-                // record j of the concatenated runs: per-lane binary search over the run starts held one per lane (ds_bpermute).
-                // All lanes take part in the shuffles (fixed trip count, j clamped); only the load is predicated.
-                auto fetch = [&](int j) -> Rec {
-                    const bool valid = j < total;
-                    const int jj = valid ? j : 0;
-                    int lo = 0, hi = nc;                                   // largest run index with excl[idx] <= jj
-#pragma unroll
-                    for (int step = 0; step < 6; ++step) {
-                        const int mid = (lo + hi) >> 1;
-                        const int v = __shfl(excl, mid, 64);
-                        if (hi - lo > 1) { if (v <= jj) lo = mid; else hi = mid; }
-                    }
-                    const unsigned int ri = (unsigned int)__shfl((int)beg, lo, 64) + (unsigned int)(jj - __shfl(excl, lo, 64));
-                    return (valid && ri < cap) ? recs[ri] : Src::sentinel();
-                };
-                Rec pre[PRE];
-#pragma unroll
-                for (int k = 0; k < PRE; ++k)                              // in flight under the LDS zero fill
-                    pre[k] = (k * THREADS < total) ? fetch(k * THREADS + (int)threadIdx.x) : Src::sentinel();
-                if (c0 == 0) {
-                    if (fast) { for (int i = threadIdx.x; i < lds_n; i += THREADS) acc32[i] = 0; }
-                    else { for (int i = threadIdx.x; i < lds_n; i += THREADS) acc64[i] = 0; }
-                    __syncthreads();
-                }
+                for (int i = threadIdx.x * 2; i < lds_n; i += THREADS * 2) *reinterpret_cast<int2*>(&acc32[i]) = make_int2(0, 0);
+                __syncthreads();
+            } else {
 #pragma unroll
                 for (int k = 0; k < PRE; ++k)
-                    if (k * THREADS < total) splat(pre[k]);
-                for (int j0 = PRE * THREADS; j0 < total; j0 += THREADS) splat(fetch(j0 + (int)threadIdx.x));
+                    pre[k] = (k * THREADS < total) ? fetch_search(k * THREADS + (int)threadIdx.x) : Src::sentinel();
             }
-            __syncthreads();
-            if (fast) write_rows<int>(acc32, inv_scale, out, g, s, tx, row_lo, rows);
-            else write_rows<long long>(acc64, 0.f, out, g, s, tx, row_lo, rows);
-            __syncthreads();                                            // the accumulators are re-zeroed by the next pass
-        };
-        if (fast) {
-            run_pass(y_lo, g.TH);
-        } else {                                                        // dense tile: two half-height passes, same LDS bytes
-            const int half = g.TH >> 1;
-            run_pass(y_lo, half);
-            run_pass(y_lo + half, half);
+#pragma unroll
+            for (int k = 0; k < PRE; ++k)
+                if (k * THREADS < total) splat(pre[k]);
+            for (int j0 = PRE * THREADS; j0 < total; j0 += THREADS) splat(fetch_search(j0 + (int)threadIdx.x));
         }
-    }
+        __syncthreads();
+        if (FAST) write_rows<int>(acc32, inv_scale, out, g, s, tx, row_lo, rows);
+        else write_rows<long long>(reinterpret_cast<const long long*>(acc32), 0.f, out, g, s, tx, row_lo, rows);
+        __syncthreads();                                            // the accumulators are re-zeroed by the next pass
+    };
+    auto run_tile = [&](auto count_c) __attribute__((always_inline)) {
+        if (fast) {
+            run_pass(std::true_type{}, count_c, y_lo, g.TH);
+        } else {                                                    // dense tile: two half-height passes, same LDS bytes
+            const int half = g.TH >> 1;
+            run_pass(std::false_type{}, count_c, y_lo, half);
+            run_pass(std::false_type{}, count_c, y_lo + half, half);
+        }
+    };
+    if (count_mode) run_tile(std::true_type{}); else run_tile(std::false_type{});
 }
 
 // Event histogram (a4): tiny; direct global atomics on a zeroed 2 x H x W image per segment.
@@ -834,10 +958,12 @@ int run_tri(Src src, const int64_t* seg_off, int n_seg, int64_t max_seg_len, int
     hipLaunchKernelGGL((tri_sort_kernel<Src>), dim3(nSl, n_seg), dim3(SORT_THREADS), sort_lds, st, src_c, seg_off, g, nSl, table,
                        recs, cap);
     OESS_HIP(hipFuncSetAttribute((const void*)&tri_splat_kernel<Src>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)splat_lds));
-    const long long n_items = (long long)g.nTiles * n_seg;
-    if (n_items > 0x7fffffffll) return OESS_EINVAL;
-    hipLaunchKernelGGL((tri_splat_kernel<Src>), dim3((unsigned)n_items), dim3(THREADS), splat_lds, st, src_c, (const Rec*)recs,
-                       (const int*)table, g, nSl, count_mode, cap, out);
+    if (splat_lds < 2048) return OESS_EINVAL;             // the run lookup borrows the first 512 accumulator words
+    for (int s0 = 0; s0 < n_seg; s0 += 65535) {           // grid.z limit
+        const int ns = n_seg - s0 < 65535 ? n_seg - s0 : 65535;
+        hipLaunchKernelGGL((tri_splat_kernel<Src>), dim3(g.tilesX, g.tilesY, ns), dim3(THREADS), splat_lds, st, src_c,
+                           (const Rec*)recs, (const int*)table, g, nSl, count_mode, cap, s0, out);
+    }
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }
