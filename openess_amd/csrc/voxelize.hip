@@ -455,7 +455,8 @@ __global__ __launch_bounds__(THREADS) void near_splat_kernel(const float4* __res
 //             lane, wave scan, ds_bpermute search), accumulates in LDS and writes every voxel once.
 // =============================================================================================
 constexpr int SORT_THREADS = 256;        // 4 sort workgroups per CU (36 KB staging each); 512 threads / 4096-event slices: 1.5-3 % slower
-constexpr int SSL = SORT_THREADS * EPT;  // 2048 events per sort slice (one batch of EPT per thread)
+constexpr int SSL = 2048;                 // events per sort slice
+constexpr int SEPT = SSL / SORT_THREADS; // events per thread
 constexpr int LCAP = 2304;               // records staged in LDS (36 KB); a slice needs 2048 * ~1.08 on real data,
                                          // up to 4 * 2048 on adversarial input (overflow goes straight to HBM)
 constexpr int FAST_LDS_BYTES = 20 * 1024;   // 32-bit accumulator tile: 8 splat workgroups per CU
@@ -481,7 +482,7 @@ __device__ __forceinline__ int block_incl_scan_256(int v, int* wsum) {
 // (i = nTiles: end of the last run), i = nTiles + 1: float bits of max |value| over the slice's events.  A splat workgroup
 // reads rows `tile` and `tile + 1`: two contiguous rows of nSl ints.  Record region of (segment, slice) =
 // [(segment * nSl + slice) * RSTRIDE, + RSTRIDE): fixed, no allocator (the workspace holds 4 records per event anyway).
-constexpr int RSTRIDE = 4 * SORT_THREADS * EPT;      // worst case: every event of the slice in 4 tiles
+constexpr int RSTRIDE = 4 * SSL;      // worst case: every event of the slice in 4 tiles
 template <typename Src>
 __global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const int64_t* __restrict__ seg_off, Geom g, int nSl,
                                                            int* __restrict__ table,
@@ -509,21 +510,21 @@ __global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const i
     const typename Src::Seg sg = src.seg(s, b, e);
     const Src here = src.at(b + sl_beg);                 // columns at the slice's first event: 32-bit lane offsets from here on
     const unsigned int n_here = (unsigned int)(sl_end - sl_beg);
-    Rec packed[EPT];
-    unsigned int tl[EPT];                                // tri_tiles code of the event; 0 = no tile (or past the slice's end)
+    Rec packed[SEPT];
+    unsigned int tl[SEPT];                                // tri_tiles code of the event; 0 = no tile (or past the slice's end)
     float vm = 0.f;
-    // the only read of the events: EPT independent column loads per lane, all issued before the first use, then the
+    // the only read of the events: SEPT independent column loads per lane, all issued before the first use, then the
     // dependent gathers likewise (the kernel lives on memory-level parallelism; a loop that loads and computes per event
     // measured 10 % slower)
-    typename Src::Ev ev[EPT];
-    float2 xy[EPT];
+    typename Src::Ev ev[SEPT];
+    float2 xy[SEPT];
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) ev[k] = here.fetch(min(k * SORT_THREADS + threadIdx.x, n_here - 1));
+    for (int k = 0; k < SEPT; ++k) ev[k] = here.fetch(min(k * SORT_THREADS + threadIdx.x, n_here - 1));
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) xy[k] = here.coords(ev[k], sg);
+    for (int k = 0; k < SEPT; ++k) xy[k] = here.coords(ev[k], sg);
     auto load_all = [&](auto unit_c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < EPT; ++k) {
+        for (int k = 0; k < SEPT; ++k) {
             const bool ok = k * SORT_THREADS + threadIdx.x < n_here;
             const TriRec r = here.template finish<decltype(unit_c)::value>(ev[k], xy[k], sg, g.C);
             packed[k] = here.pack(r);
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const i
     // phase A: histogram, shifted by one so that the inclusive scan below yields exclusive starts
     const int tx1 = g.tilesX + 1;
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) {
+    for (int k = 0; k < SEPT; ++k) {
         int* c = &cur[(int)(tl[k] >> 4) - tx1 + 1];      // counter of tile (0, 0) + 1
         if (tl[k] & 1u) atomicAdd(c, 1);
         if (tl[k] & 2u) atomicAdd(c + 1, 1);
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const i
         if (pos < LCAP) buf[pos] = q; else if (base + (unsigned int)pos < cap) region[pos] = q;
     };
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) {
+    for (int k = 0; k < SEPT; ++k) {
         int* c = &cur[(int)(tl[k] >> 4) - tx1];
         if (tl[k] & 1u) place(c, packed[k]);
         if (tl[k] & 2u) place(c + 1, packed[k]);
