@@ -72,7 +72,9 @@ def test_maskclip_tower_matches_restatement(img_size, hw):
 
 def test_online_teacher_labels_in_the_step():
     """the frozen tower as ONLINE teacher inside PretrainStep -- the step with `online_teacher` equals the step fed
-    with the tower's argmax map as offline pseudo-labels (bit-identical loss), and that map agrees with the oracle tower's."""
+    with the tower's argmax map as offline pseudo-labels, and that map agrees with the oracle tower's.  The two steps run the same
+    kernels on the same labels; what differs from run to run is the arrival order of the fp32 atomics in the normalisation
+    statistics and the loss reduction (observed 0 - 2.5e-6 relative between two runs of the SAME step), hence rel 2e-5."""
     from openess_amd.training.pretrain_step import PretrainStep
     from tests.synth import damp_residual, fill_by_name
     o, m = _pair((32, 48))
@@ -93,4 +95,4 @@ def test_online_teacher_labels_in_the_step():
             damp_residual(mod)
         ls, _, _ = st.train_step((ev, None, frame.cuda(), pl, None, None))
         losses.append(float(ls['dense_clip_loss']))
-    assert losses[0] == pytest.approx(losses[1], rel=1e-6)
+    assert losses[0] == pytest.approx(losses[1], rel=2e-5)
