@@ -461,6 +461,11 @@ constexpr int LCAP = 2304;               // records staged in LDS (36 KB); a sli
                                          // up to 4 * 2048 on adversarial input (overflow goes straight to HBM)
 constexpr int FAST_LDS_BYTES = 20 * 1024;   // 32-bit accumulator tile: 8 splat workgroups per CU
 
+// Barrier for LDS-only hand-offs: waits for this wave's LDS operations, not for its global loads and stores.  __syncthreads()
+// carries a workgroup-scope release, which on gfx9 means s_waitcnt vmcnt(0): it would drain the table / record stores of the
+// sort kernel (and any prefetched columns) at every phase boundary.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ int block_incl_scan_256(int v, int* wsum) {
     // inclusive scan over all threads of the block (<= 16 waves); wsum: 16 ints of LDS
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -471,10 +476,10 @@ __device__ __forceinline__ int block_incl_scan_256(int v, int* wsum) {
         if (lane >= off) x += y;
     }
     if (lane == 63) wsum[wave] = x;
-    __syncthreads();
+    lds_barrier();
     int add = 0;
     for (int w = 0; w < wave; ++w) add += wsum[w];
-    __syncthreads();
+    lds_barrier();
     return x + add;
 }
 
@@ -504,7 +509,7 @@ __global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const i
         for (int i = threadIdx.x; i < nT + 2; i += SORT_THREADS) tab[(size_t)i * nSl] = 0;
         return;
     }
-    __syncthreads();
+    lds_barrier();
     int64_t sl_end = sl_beg + SSL;
     if (sl_end > n) sl_end = n;
     const typename Src::Seg sg = src.seg(s, b, e);
@@ -548,7 +553,7 @@ __global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const i
         if (tl[k] & 4u) atomicAdd(c + g.tilesX, 1);
         if (tl[k] & 8u) atomicAdd(c + g.tilesX + 1, 1);
     }
-    __syncthreads();
+    lds_barrier();
     const int vmax_bits = wsum[16];
     {   // inclusive scan of cur[0 .. nT] in place
         const int per = (nT + 1 + SORT_THREADS - 1) / SORT_THREADS;
@@ -559,12 +564,12 @@ __global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const i
         int run = incl - sum;
         for (int i = lo; i < lo + per && i <= nT; ++i) { run += cur[i]; cur[i] = run; }
     }
-    __syncthreads();
+    lds_barrier();
     const int total = cur[nT];
     const unsigned int base = (unsigned int)(((size_t)s * nSl + slice) * RSTRIDE);
     for (int i = threadIdx.x; i <= nT; i += SORT_THREADS) tab[(size_t)i * nSl] = cur[i];                  // starts inside the region
     if (threadIdx.x == 0) tab[(size_t)(nT + 1) * nSl] = vmax_bits;
-    __syncthreads();                                     // column stored before the cursors start moving
+    lds_barrier();                                     // column stored before the cursors start moving
     Rec* region = recs + base;
     // phase B: rank inside the tile by LDS integer atomic, stage in LDS
     auto place = [&](int* c, const Rec& q) __attribute__((always_inline)) {
@@ -579,7 +584,7 @@ __global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const i
         if (tl[k] & 4u) place(c + g.tilesX, packed[k]);
         if (tl[k] & 8u) place(c + g.tilesX + 1, packed[k]);
     }
-    __syncthreads();
+    lds_barrier();
     const int staged = total < LCAP ? total : LCAP;
     for (int i = threadIdx.x; i < staged; i += SORT_THREADS)
         if (base + (unsigned int)i < cap) store_stream(&region[i], buf[i]);        // whole, exclusively owned lines
@@ -707,7 +712,7 @@ __device__ __forceinline__ void splat_record(const TriRec r, const Geom& g, int 
     add(vx1 && vy1 && vt1, TW + 1 + tstep, w11, ct1);
 }
 
-// One (segment, tile) item per workgroup, grid (tilesX, tilesY, segments).  A persistent grid (8 workgroups per CU walking
+// One (segment, tile) item per workgroup.  A persistent grid (8 workgroups per CU walking
 // the items, next item's table rows prefetched) was built and measured SLOWER (329 vs 262 us): the hardware dispatcher
 // balances the uneven items better than a static loop.
 //
@@ -717,13 +722,18 @@ __device__ __forceinline__ void splat_record(const TriRec r, const Geom& g, int 
 template <typename Src>
 __global__ __launch_bounds__(THREADS) void tri_splat_kernel(Src src, const typename Src::Rec* __restrict__ recs,
                                                             const int* __restrict__ table, Geom g, int nSl, int count_mode,
-                                                            unsigned int cap, int s_base, float* __restrict__ out) {
+                                                            unsigned int cap, int n_items, float* __restrict__ out) {
     using Rec = typename Src::Rec;
     extern __shared__ __attribute__((aligned(16))) int acc32[];          // [C][TH][TW] ints == [C][TH/2][TW] long longs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nT = g.nTiles;
-    const int s = s_base + blockIdx.z, tx = blockIdx.x, ty = blockIdx.y;
-    const int tile = ty * g.tilesX + tx;
+    // XCD-aware item order: workgroup L runs on XCD L % 8; giving every XCD one contiguous eighth of the (segment, tile) items
+    // puts the neighbouring tiles of a slice - whose runs share their boundary cache lines - on the same L2, one after the other
+    const int per_xcd = (n_items + 7) >> 3;
+    const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (item >= n_items) return;
+    const int s = item / nT, tile = item - s * nT;
+    const int ty = tile / g.tilesX, tx = tile - ty * g.tilesX;
     const int x_lo = tx * TW, y_lo = ty * g.TH;
     const int* trow = table + ((size_t)s * (nT + 2) + tile) * nSl;       // run starts of this tile, one per slice; ends follow
     const int* vrow = table + ((size_t)s * (nT + 2) + nT + 1) * nSl;     // max |value| of each slice
@@ -840,7 +850,7 @@ __global__ __launch_bounds__(THREADS) void tri_splat_kernel(Src src, const typen
                     }
                 }
                 for (int i = threadIdx.x * 2; i < lds_n; i += THREADS * 2) *reinterpret_cast<int2*>(&acc32[i]) = make_int2(0, 0);
-                __syncthreads();
+                lds_barrier();                             // LDS only: the record loads stay in flight
             } else {
 #pragma unroll
                 for (int k = 0; k < PRE; ++k)
@@ -851,10 +861,11 @@ __global__ __launch_bounds__(THREADS) void tri_splat_kernel(Src src, const typen
                 if (k * THREADS < total) splat(pre[k]);
             for (int j0 = PRE * THREADS; j0 < total; j0 += THREADS) splat(fetch_search(j0 + (int)threadIdx.x));
         }
-        __syncthreads();
+        lds_barrier();
         if (FAST) write_rows<int>(acc32, inv_scale, out, g, s, tx, row_lo, rows);
         else write_rows<long long>(reinterpret_cast<const long long*>(acc32), 0.f, out, g, s, tx, row_lo, rows);
-        __syncthreads();                                            // the accumulators are re-zeroed by the next pass
+        lds_barrier();     // the accumulators are re-zeroed by the next pass; the grid stores are NOT waited for (a
+                           // __syncthreads() here held the workgroup's LDS and wave slots until they were acknowledged)
     };
     auto run_tile = [&](auto count_c) __attribute__((always_inline)) {
         if (fast) {
@@ -960,11 +971,10 @@ int run_tri(Src src, const int64_t* seg_off, int n_seg, int64_t max_seg_len, int
                        recs, cap);
     OESS_HIP(hipFuncSetAttribute((const void*)&tri_splat_kernel<Src>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)splat_lds));
     if (splat_lds < 2048) return OESS_EINVAL;             // the run lookup borrows the first 512 accumulator words
-    for (int s0 = 0; s0 < n_seg; s0 += 65535) {           // grid.z limit
-        const int ns = n_seg - s0 < 65535 ? n_seg - s0 : 65535;
-        hipLaunchKernelGGL((tri_splat_kernel<Src>), dim3(g.tilesX, g.tilesY, ns), dim3(THREADS), splat_lds, st, src_c,
-                           (const Rec*)recs, (const int*)table, g, nSl, count_mode, cap, s0, out);
-    }
+    const long long n_items = (long long)g.nTiles * n_seg;
+    if (n_items > 0x7ffffff0ll) return OESS_EINVAL;
+    hipLaunchKernelGGL((tri_splat_kernel<Src>), dim3((unsigned)(((n_items + 7) >> 3) << 3)), dim3(THREADS), splat_lds, st, src_c,
+                       (const Rec*)recs, (const int*)table, g, nSl, count_mode, cap, (int)n_items, out);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }
