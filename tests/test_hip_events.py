@@ -79,6 +79,46 @@ def test_trilinear_segments_crop_and_edges():
     assert not out[C:2 * C].any() and not out[2 * C:3 * C].any() and not out[4 * C:5 * C].any()
 
 
+def test_trilinear_dense_tiles_long_segments_and_two_bins():
+    """The splat's less-travelled paths against the oracle: (a) tiles far denser than the 32-bit accumulator bound (64-bit
+    fixed point in two half-height passes, more than 768 records per tile -> the per-lane run search), with large |value|;
+    (b) a segment longer than 64 sort slices (> 131 072 events: run table walked in 64-slice chunks); (c) C = 2 (32-row
+    tiles: the strided write-out) and C = 11.  The float64 sums are the yardstick for the dense case: the oracle's own
+    sequential fp32 accumulation carries an error that grows with the count, the fixed-point sum does not."""
+    from openess_amd import hip
+    rng = np.random.default_rng(11)
+
+    def one(C, H, W, lens, xr, yr, pvals, atol, rtol):
+        N = sum(lens)
+        x = rng.uniform(xr[0], xr[1], N).astype(np.float32)
+        y = rng.uniform(yr[0], yr[1], N).astype(np.float32)
+        p = rng.choice(np.asarray(pvals, np.float32), N)
+        t = np.empty(N, np.float32)
+        off = np.concatenate([[0], np.cumsum(lens)])
+        for i, n in enumerate(lens):
+            tt = np.sort(rng.uniform(0, 1, n)).astype(np.float32)
+            tt[0], tt[-1] = 0, 1
+            t[off[i]:off[i + 1]] = tt
+        for cm in (True, False):
+            out = hip.voxelize_trilinear(dev(x), dev(y), dev(p), dev(t), seg(*lens), C, H, W, count_mode=cm).cpu().numpy()
+            for i, n in enumerate(lens):
+                s, e = off[i], off[i + 1]
+                ref = oe.voxelgrid_trilinear(x[s:e], y[s:e], p[s:e], t[s:e], C, H, W, count_mode=cm)
+                got = out[i * C:(i + 1) * C]
+                if cm:
+                    assert np.array_equal(got, ref), (C, H, W, i)
+                else:
+                    np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol)
+
+    # (a) 6 000 and 900 events inside a 40 x 12 pixel patch (one or two tiles), values 2p-1 in {-1, 1, 199, -201}
+    one(5, 64, 128, [6000, 900], (30.0, 70.0), (10.0, 22.0), [0.0, 1.0, 100.0, -100.0], atol=2e-2, rtol=2e-5)
+    # (b) 150 000 events in one segment (74 slices) + a short one, small image so that the oracle stays quick
+    one(5, 48, 128, [150000, 3000], (-1.0, 128.5), (-1.0, 48.5), [0.0, 1.0], atol=3e-4, rtol=2e-5)
+    # (c) two bins (32-row tiles) and eleven bins (4-row tiles)
+    one(2, 70, 128, [5000, 1], (-2.0, 129.0), (-2.0, 71.0), [0.0, 1.0], atol=ATOL, rtol=0)
+    one(11, 40, 192, [5000], (-2.0, 193.0), (-2.0, 41.0), [0.0, 1.0], atol=ATOL, rtol=0)
+
+
 def test_dsec_raw_matches_oracle_full_sensor():
     """Raw uint16/int64/uint8 columns + rectify map, DSEC sensor size, 2 samples x 3 sub-windows."""
     from openess_amd import hip
