@@ -145,6 +145,32 @@ def test_dsec_raw_matches_oracle_full_sensor():
                 np.testing.assert_allclose(got, ref, rtol=0, atol=ATOL)
 
 
+def test_dsec_raw_time_span_beyond_int32():
+    """Raw path with a window longer than 2^31 us (the int64 -> float64 -> float32 conversion of t - t[0]; shorter windows take
+    the int32 conversion, identical by construction) and with unsorted / repeated timestamps inside the window."""
+    from openess_amd import hip
+    C, H, W, crop, nwin, n_per = 5, 96, 128, 8, 2, 5000
+    rng = np.random.default_rng(17)
+    rmap = synth.rectify_map(H, W)
+    x = rng.integers(0, W, nwin * n_per).astype(np.uint16)
+    y = rng.integers(0, H, nwin * n_per).astype(np.uint16)
+    p = rng.integers(0, 2, nwin * n_per).astype(np.uint8)
+    t = np.sort(rng.integers(0, 3 * 2 ** 31, nwin * n_per)).astype(np.int64) + 7_000_000_000_000
+    t[n_per + 10:n_per + 20] = t[n_per + 10]                       # repeated stamps
+    t[n_per + 30], t[n_per + 31] = t[n_per + 31], t[n_per + 30]    # a swapped pair (not sorted)
+    maps = dev(rmap[None])
+    seg_map = torch.zeros(nwin, dtype=torch.int32).cuda()
+    so = seg(*([n_per] * nwin))
+    for cm in (True, False):
+        out = hip.voxelize_dsec_raw(dev(x), dev(y), dev(t), dev(p), maps, seg_map, so, C, H, W, crop_rows=crop,
+                                    count_mode=cm).cpu().numpy()
+        ref = oe.dsec_event_tensor(x, y, t, p, rmap, nwin, C, H, W, crop, count_mode=cm)
+        if cm:
+            assert np.array_equal(out, ref)
+        else:
+            np.testing.assert_allclose(out, ref, rtol=0, atol=ATOL)
+
+
 def test_trilinear_full_batch_properties():
     """BASELINE size (8 samples x 20 sub-windows x 100k events, 640x480): size-independent properties."""
     from openess_amd import hip
