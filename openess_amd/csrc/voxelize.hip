@@ -543,15 +543,19 @@ __global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const i
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) vm = fmaxf(vm, __shfl_xor(vm, off, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(&wsum[16], __float_as_int(vm));        // non-negative floats order like ints
-    // phase A: histogram, shifted by one so that the inclusive scan below yields exclusive starts
+    // phase A: count AND rank in one pass of returning LDS atomics (counter of tile t at cur[t + 1], so that the inclusive
+    // scan below yields exclusive starts); the rank of a record inside its tile stays in registers, two 16-bit ranks per VGPR
     const int tx1 = g.tilesX + 1;
+    unsigned int rk[SEPT][2];
 #pragma unroll
     for (int k = 0; k < SEPT; ++k) {
         int* c = &cur[(int)(tl[k] >> 4) - tx1 + 1];      // counter of tile (0, 0) + 1
-        if (tl[k] & 1u) atomicAdd(c, 1);
-        if (tl[k] & 2u) atomicAdd(c + 1, 1);
-        if (tl[k] & 4u) atomicAdd(c + g.tilesX, 1);
-        if (tl[k] & 8u) atomicAdd(c + g.tilesX + 1, 1);
+        unsigned int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        if (tl[k] & 1u) r0 = (unsigned int)atomicAdd(c, 1);
+        if (tl[k] & 2u) r1 = (unsigned int)atomicAdd(c + 1, 1);
+        if (tl[k] & 4u) r2 = (unsigned int)atomicAdd(c + g.tilesX, 1);
+        if (tl[k] & 8u) r3 = (unsigned int)atomicAdd(c + g.tilesX + 1, 1);
+        rk[k][0] = r0 | r1 << 16; rk[k][1] = r2 | r3 << 16;            // a slice holds at most 4 x 2048 records
     }
     lds_barrier();
     const int vmax_bits = wsum[16];
@@ -569,20 +573,19 @@ __global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const i
     const unsigned int base = (unsigned int)(((size_t)s * nSl + slice) * RSTRIDE);
     for (int i = threadIdx.x; i <= nT; i += SORT_THREADS) tab[(size_t)i * nSl] = cur[i];                  // starts inside the region
     if (threadIdx.x == 0) tab[(size_t)(nT + 1) * nSl] = vmax_bits;
-    lds_barrier();                                     // column stored before the cursors start moving
     Rec* region = recs + base;
-    // phase B: rank inside the tile by LDS integer atomic, stage in LDS
-    auto place = [&](int* c, const Rec& q) __attribute__((always_inline)) {
-        const int pos = atomicAdd(c, 1);
+    // phase B: position = start of the tile + rank; stage in LDS (the counters are only read from here on)
+    auto place = [&](const int* c, unsigned int rank, const Rec& q) __attribute__((always_inline)) {
+        const int pos = *c + (int)rank;
         if (pos < LCAP) buf[pos] = q; else if (base + (unsigned int)pos < cap) region[pos] = q;
     };
 #pragma unroll
     for (int k = 0; k < SEPT; ++k) {
-        int* c = &cur[(int)(tl[k] >> 4) - tx1];
-        if (tl[k] & 1u) place(c, packed[k]);
-        if (tl[k] & 2u) place(c + 1, packed[k]);
-        if (tl[k] & 4u) place(c + g.tilesX, packed[k]);
-        if (tl[k] & 8u) place(c + g.tilesX + 1, packed[k]);
+        const int* c = &cur[(int)(tl[k] >> 4) - tx1];
+        if (tl[k] & 1u) place(c, rk[k][0] & 0xffffu, packed[k]);
+        if (tl[k] & 2u) place(c + 1, rk[k][0] >> 16, packed[k]);
+        if (tl[k] & 4u) place(c + g.tilesX, rk[k][1] & 0xffffu, packed[k]);
+        if (tl[k] & 8u) place(c + g.tilesX + 1, rk[k][1] >> 16, packed[k]);
     }
     lds_barrier();
     const int staged = total < LCAP ? total : LCAP;
