@@ -635,6 +635,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_dma_kernel(ConvArgs a) {
         if constexpr (MT == 4 && NT == 4)                                                                        \
             asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(FA_[0]), "+v"(FA_[1]), "+v"(FA_[2]), "+v"(FA_[3]),       \
                          "+v"(FB_[0]), "+v"(FB_[1]), "+v"(FB_[2]), "+v"(FB_[3]) : "n"(N_) : "memory");           \
+        else if constexpr (MT == 2 && NT == 4)                                                                   \
+            asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(FA_[0]), "+v"(FA_[1]), "+v"(FB_[0]), "+v"(FB_[1]), "+v"(FB_[2]), "+v"(FB_[3]) : "n"(N_) : "memory"); \
         else if constexpr (MT == 2 && NT == 2)                                                                   \
             asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(FA_[0]), "+v"(FA_[1]), "+v"(FB_[0]), "+v"(FB_[1]) : "n"(N_) : "memory"); \
         else if constexpr (MT == 1 && NT == 2)                                                                   \
@@ -1329,6 +1331,7 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
                              (const void*)&conv_fwd_dma_kernel<64, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<64, 128, 2, true>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 2, false, 1>, (const void*)&conv_fwd_dma_kernel<128, 128, 2, true, 1>,
                              (const void*)&conv3x3_halo_kernel<0>, (const void*)&conv3x3_halo_kernel<1>,
+                             (const void*)&conv_fwd_dma_kernel<256, 256, 2, true>,
                              (const void*)&conv_fwd_dma32_kernel<128, true, 0, 3>};
         for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attrs_set = true;
@@ -1397,6 +1400,23 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
         else hipLaunchKernelGGL((conv_fwd_dma_kernel<128, 128, 2, false, 1>), grid, block, lds, st, a);
         OESS_HIP(hipGetLastError());
         return OESS_OK;
+    }
+    // (3b) large plain-GEMM layers (1x1, Cin % 64 == 0, Cout % 256 == 0, K >= 256): 256 x 256 tiles on ONE 8-wave workgroup per
+    //      CU, wave tile 64 x 128 (24 fragment reads per 32 MFMAs instead of 16 per 16, half the L2 -> LDS bytes per FLOP).
+    //      Same template as rule (6).  Measured against the 128 x 128 tiling on the teacher's layers at M = 140 800:
+    //      512->2048 556 -> 451 us, 1024->2048 831 -> 680, 2048->512 396 -> 362, 256->1024 179 -> 169; ViT fc1 (M = 8 968,
+    //      432 tiles) 65.8 -> 62.5.  Below ~1.5 rounds of 256 tiles the coarser quantisation loses (324 tiles: 51.7 -> 59.5 us).
+    if (!lstm && bn == 128 && fastk && (Cout % 256) == 0 && a.Kpad >= 256 && R == 1 && S == 1 && stride == 1) {
+        const long long t256 = (long long)((a.M + 255) / 256) * (Cout / 256);
+        if (t256 >= 400) {
+            a.tiles_m = (a.M + 255) / 256; a.tiles_n = Cout / 256;
+            size_t lds = (size_t)2 * 512 * 128;                                          // 2 stages x (256 + 256) rows x 128 B
+            const size_t epi256 = (size_t)256 * (256 + 8) * 2 + (size_t)4 * 256 * 2 * 4 + 256;   // output image + BatchNorm partials
+            if (lds < epi256) lds = epi256;
+            hipLaunchKernelGGL((conv_fwd_dma_kernel<256, 256, 2, true>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, st, a);
+            OESS_HIP(hipGetLastError());
+            return OESS_OK;
+        }
     }
     // (4) short reductions (K <= 256, the 1x1 bottleneck convs): a workgroup lives ~6 us of which the K loop is a fraction, so
     //     residency matters more than the main loop: BK = 32 slabs in a 3-deep ring = 48 KB -> 3 workgroups per CU

@@ -34,6 +34,7 @@ CASES = [
     (2, 28, 40, 2048, 256, 3, 1, 12, 12),  # ASPP rate 12: every tap lands inside the 28x40 map for interior pixels
     (2, 28, 40, 2048, 256, 3, 1, 18, 18),  # ASPP rate 18 (models/deeplabv3.py:137-142, else-branch rates 6/12/18)
     (1, 14, 20, 2048, 256, 3, 1, 12, 12),  # 224x320 input: rate 12 still has in-range off-centre taps
+    (2, 220, 320, 512, 1024, 1, 1, 0, 1),  # large 1x1 (teacher layer class): 550 x 4 tiles of 256 x 256
 ]
 
 
@@ -135,6 +136,31 @@ def test_conv_wgrad_matches_autograd(case):
         xp = torch.cat([x, torch.zeros(B, H, W, 8, device="cuda", dtype=torch.bfloat16)], -1)
         dw2 = hip.conv2d_wgrad(xp, gy.permute(0, 2, 3, 1).contiguous(), Cout, Cin, R, R, stride, pad, dil)
         assert float((dw2 - ref).abs().max() / ref.abs().max()) < 2e-3
+
+
+def test_conv_256_tile_kernel_stats_residual_and_ragged_rows():
+    """The 256 x 256-tile path of large 1x1 layers: BatchNorm partial sums (a 256-row tile fills stats row 2t and zeroes row
+    2t + 1, so the per-128-row table sums to the column sums whichever kernel ran), residual + ReLU epilogue, and a pixel count
+    that is not a multiple of 256."""
+    from openess_amd import hip
+    torch.manual_seed(9)
+    B, H, W, Cin, Cout = 2, 219, 321, 256, 512          # M = 140 598 = 549 x 256 + 54
+    x = torch.randn(B, H, W, Cin, device="cuda").bfloat16()
+    w = torch.randn(Cout, Cin, 1, 1, device="cuda") / np.sqrt(Cin)
+    packed = hip.pack_conv_weight(w)
+    ref = ref_conv(x, w, None, 1, 0, 1).reshape(-1, Cout)
+    tiles = (B * H * W + 127) // 128
+    part = torch.full((tiles, 2, Cout), float("nan"), device="cuda")
+    y = hip.conv2d_nhwc(x, packed, None, Cout, 1, 1, 1, 0, 1, tile_stats=part)
+    assert torch.isfinite(part).all()
+    np.testing.assert_allclose(part[:, 0].double().sum(0).cpu().numpy(), ref.double().sum(0).cpu().numpy(), rtol=2e-3, atol=2.0)
+    np.testing.assert_allclose(part[:, 1].double().sum(0).cpu().numpy(), (ref.double() ** 2).sum(0).cpu().numpy(), rtol=2e-3)
+    np.testing.assert_allclose(y.float().reshape(-1, Cout).cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=1e-2)
+    res = torch.randn(B, H, W, Cout, device="cuda").bfloat16()
+    bias = torch.randn(Cout, device="cuda")
+    y2 = hip.conv2d_nhwc(x, packed, bias, Cout, 1, 1, 1, 0, 1, relu=True, residual=res)
+    ref2 = (ref + bias + res.float().reshape(-1, Cout)).clamp_min(0)
+    np.testing.assert_allclose(y2.float().reshape(-1, Cout).cpu().numpy(), ref2.cpu().numpy(), rtol=1e-2, atol=2e-2)
 
 
 @pytest.mark.gpu
