@@ -4,22 +4,24 @@
 //   The reference scatters 8 (tri-linear) or 2 (nearest) read-modify-writes per event into a
 //   C x H x W grid.  Global fp32 atomics across the 8 non-coherent XCD L2s would execute
 //   memory-side, so the splat is made OUTPUT-STATIONARY and free of global atomics:
-//     S  sort     workgroup (segment, slice of 2048 events): the events are loaded ONCE; LDS histogram per
-//                 spatial tile, LDS scan, rank by LDS integer atomic into an LDS record buffer, then one
-//                 coalesced block copy of the slice's tile-sorted 16-byte records (region from one global
-//                 atomic) + a row of absolute run starts per tile (plain stores)
-//     D  splat    workgroup (segment, tile): gathers its run from every slice of the segment (run starts
-//                 one per lane, wave scan, ds_bpermute search), records -> LDS accumulators, then every
-//                 output voxel is written ONCE, coalesced (float4 per lane); no pre-zeroing pass.
+//     S  sort     workgroup (segment, slice of 2048 events): the events are loaded ONCE (all column loads of a lane issued
+//                 before the first use, then the rectify gathers); count + rank in one pass of returning LDS atomics, LDS
+//                 scan, records staged in LDS, then one coalesced non-temporal block copy of the slice's tile-sorted
+//                 16-byte records into the slice's FIXED region + a column of the transposed run table (plain stores)
+//     D  splat    workgroup (segment, tile), XCD-aware item order: gathers its run from every slice of the segment (run
+//                 starts one per lane, DPP wave scan, run lookup by LDS marks), records -> LDS accumulators, then every
+//                 output voxel is written ONCE, coalesced (float4 per lane, non-temporal); no pre-zeroing pass.
 //   (The nearest-xy path still uses the first pipeline: count -> two scans -> scatter -> splat.  For the tri-linear
 //   path it was measured slower -- 0.578 / 0.780 ms (fp32 SoA / raw+rectify) against 0.513 / 0.583 ms -- because it
 //   reads the events twice and scatters records into ~450-byte cursor ranges whose boundary lines are shared between
 //   workgroups on different XCDs, and has been removed.)
-//   Both kernels are bound by the NUMBER of cache-line requests, not by bytes (ablation, B=8 x 2 M events: the splat's
-//   per-wave reads of 25 strided table rows cost 81 us of 322, a second rectify-map gather in the splat 30 us, the
-//   same-address global allocation atomic of 3906 sort workgroups serialises memory-side).  Hence: 16-byte records that
-//   carry the rectified coordinates, a TRANSPOSED run table (a tile's 25 run starts are one contiguous row) and fixed
-//   record regions per slice instead of an allocator.
+//   What bounds the two kernels was measured with PMC counters and phase ablations: the splat was
+//   VALU-issue bound (803 instructions per wave for ~1.5 records per lane) until its corners became straight-line code and
+//   its run lookup a mark row; it now sits on its 0.9 GB write (floor 150-160 us) plus the latency of the record fetch.
+//   The sort lives on memory-level parallelism (16 waves per CU behind a 36 KB staging buffer).  Design choices that
+//   came out of the ablations: 16-byte records that carry the rectified coordinates (a second rectify-map gather in the
+//   splat costs more than the bytes it saves), a TRANSPOSED run table (a tile's run starts are one contiguous row) and
+//   fixed record regions per slice instead of an allocator.
 //   An event whose 2x2 pixel footprint straddles a tile edge is binned into each tile it touches
 //   (<= 4); each tile only accumulates the corners it owns.
 //
@@ -447,12 +449,12 @@ __global__ __launch_bounds__(THREADS) void near_splat_kernel(const float4* __res
 
 // =============================================================================================
 // Tri-linear pipeline: SLICE-LOCAL SORT + multi-run splat (2 kernels).
-//   S  sort   workgroup (segment, slice of 2048 events): load the events ONCE, LDS histogram per tile, LDS
-//             exclusive scan, rank by LDS integer atomic into an LDS record buffer, then ONE coalesced block
-//             copy of the slice's records (sorted by tile) to a region obtained with one global atomic; the
-//             per-slice table row {start[tile], ..., end, max |value|} is stored with plain stores.
+//   S  sort   workgroup (segment, slice of 2048 events): load the events ONCE, count + rank per tile with returning
+//             LDS atomics, LDS scan, records into an LDS buffer, then ONE coalesced block copy of the slice's records
+//             (sorted by tile) to the slice's fixed region; the per-slice table column {start[tile], ..., end,
+//             max |value|} is stored with plain stores.
 //   D  splat  workgroup (segment, tile): gathers its run from every slice of the segment (run starts one per
-//             lane, wave scan, ds_bpermute search), accumulates in LDS and writes every voxel once.
+//             lane, wave scan, mark-row lookup), accumulates in LDS and writes every voxel once.
 // =============================================================================================
 constexpr int SORT_THREADS = 256;        // 4 sort workgroups per CU (36 KB staging each); 512 threads / 4096-event slices: 1.5-3 % slower
 constexpr int SSL = 2048;                 // events per sort slice
