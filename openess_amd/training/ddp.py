@@ -43,8 +43,15 @@ class _Bucket:
 
 
 class GradAllReduce:
-    def __init__(self, params, world_size=None, bucket_bytes=25 << 20, overlap=True):
+    def __init__(self, params, world_size=None, bucket_bytes=25 << 20, overlap=True, force_buckets=False):
+        """overlap=True launches a bucket's all-reduce from the autograd hook as soon as every parameter of the bucket has
+        received its gradient ONCE: valid for one backward() per step (what every trainer of this path does).  With several
+        backward() calls / gradient accumulation per step pass overlap=False (buckets then go at finish()); a second
+        accumulation into a bucket whose collective is already in flight raises instead of racing with it.
+        force_buckets=True keeps the whole bucket / hook / collective machinery at world size 1 (a 1-rank process group:
+        exercises the RCCL call path on a single GPU)."""
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.active = self.world > 1 or (force_buckets and dist.is_initialized())
         seen, self.params = set(), []
         for p in params:
             if p.requires_grad and id(p) not in seen:
@@ -54,7 +61,7 @@ class GradAllReduce:
         self.buckets, self._where, self._hooks = [], {}, []
         self._avg = None
         self._armed = False
-        if self.world == 1:
+        if not self.active:
             return
         for p in self.params:
             if p.dtype != torch.float32:
@@ -77,7 +84,7 @@ class GradAllReduce:
     def prepare(self):
         """Call after `optimizer.zero_grad()`: zero the bucket buffers (one memset each) and point every trainable
         parameter's .grad at its slice, so that backward accumulates into the message buffers."""
-        if self.world == 1:
+        if not self.active:
             return
         for b in self.buckets:
             b.flat.zero_()
@@ -102,14 +109,21 @@ class GradAllReduce:
         if p.grad is not b.views[pi]:                 # someone re-assigned .grad (zero_grad after prepare): fold it back in
             b.views[pi].copy_(p.grad)
             p.grad = b.views[pi]
-        if id(p) not in self._touched:
-            self._touched.add(id(p))
-            b.pending -= 1
-            if b.pending == 0 and self.overlap and not b.launched:
-                self._launch(b)
+        if id(p) in self._touched:
+            if b.launched:
+                # the in-place `grad +=` that just ran on the compute stream raced with the bucket's in-flight all-reduce on the
+                # communicator's stream: the reduced values are undefined.  Fail loudly.
+                raise RuntimeError("GradAllReduce(overlap=True): a parameter received a second gradient accumulation after its "
+                                   "bucket's all-reduce was launched (several backward() calls / gradient accumulation in one step); "
+                                   "construct the reducer with overlap=False for that pattern")
+            return
+        self._touched.add(id(p))
+        b.pending -= 1
+        if b.pending == 0 and self.overlap and not b.launched:
+            self._launch(b)
 
     def finish(self):
-        if self.world == 1:
+        if not self.active:
             return
         if not self._armed:                           # prepare() was not called this step: gather whatever .grad holds now
             self._gather_unprepared()
@@ -140,6 +154,13 @@ class GradAllReduce:
                     v.copy_(p.grad)
                     p.grad = v
                 self._touched.add(id(p))
+
+    def close(self):
+        """Detach from the parameters (hooks removed, .grad views released): needed before a second reducer takes the same
+        parameters."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks, self._armed = [], False
 
     def exposed_bytes(self):
         return sum(b.flat.numel() * 4 for b in self.buckets)

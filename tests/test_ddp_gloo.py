@@ -88,3 +88,49 @@ def test_two_rank_step_equals_single_process_step():
     opt.step()
     for p, w in zip(net.parameters(), a["w1"]):
         assert torch.allclose(p.detach(), w, atol=1e-6)
+
+
+def _accum_worker(rank, world, port, out):
+    """Two backward() calls per step: overlap=True must refuse (the second in-place `grad +=` races with the in-flight
+    collective), overlap=False must give the mean over ranks of the ACCUMULATED gradient."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from openess_amd.training.ddp import GradAllReduce
+    torch.manual_seed(3)
+    net = torch.nn.Linear(4, 3)
+    torch.manual_seed(50 + rank)
+    xa, xb = torch.randn(5, 4), torch.randn(5, 4)
+    red = GradAllReduce(net.parameters(), world, bucket_bytes=1 << 20, overlap=True)
+    net.zero_grad()
+    red.prepare()
+    net(xa).sum().backward()
+    raised = False
+    try:
+        net(xb).sum().backward()
+    except RuntimeError as e:
+        raised = "second gradient accumulation" in str(e)
+    for b in red.buckets:                                  # drain what the first backward launched
+        if b.handle is not None:
+            b.handle.wait()
+    red.close()
+    red2 = GradAllReduce(net.parameters(), world, bucket_bytes=1 << 20, overlap=False)
+    net.zero_grad()
+    red2.prepare()
+    net(xa).sum().backward()
+    net(xb).sum().backward()
+    red2()
+    out[rank] = {"raised": raised, "grad": [p.grad.clone() for p in net.parameters()],
+                 "local": [xa.sum(0) + xb.sum(0), torch.full((3,), 10.0)]}
+    dist.destroy_process_group()
+
+
+def test_second_accumulation_is_refused_with_overlap_and_correct_without():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_accum_worker, args=(world, port, out), nprocs=world, join=True)
+    a, b = out[0], out[1]
+    assert a["raised"] and b["raised"]
+    want_w = ((a["local"][0] + b["local"][0]) / 2)[None].expand(3, 4)
+    assert torch.allclose(a["grad"][0], want_w, atol=1e-5) and torch.allclose(b["grad"][0], want_w, atol=1e-5)
+    assert torch.allclose(a["grad"][1], a["local"][1], atol=1e-6)

@@ -1,0 +1,145 @@
+"""The RCCL call path itself (`backend="nccl"` is RCCL on ROCm) on the hardware that is available:
+  * world size 1 on one GPU: `GradAllReduce(force_buckets=True)` runs prepare -> post-accumulate hooks -> async
+    `all_reduce(ReduceOp.AVG)` on the communicator's stream under backward -> finish / wait (stream ordering against the
+    compute stream) on the REAL `PretrainStep`; AVG over one rank is the identity, so gradients, None-grad parameters and the
+    AdamW result must equal the un-reduced step's bit for bit;
+  * world size 2 over two GPUs (skipped on a 1-GPU box): the reduced gradient equals flatten / all_reduce / unflatten of the
+    local gradients, including a never-used parameter."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+B, H, W, NWIN = 2, 64, 96, 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _batch(seed=11, dev="cuda"):
+    g = torch.Generator().manual_seed(seed)
+    ev = (torch.randn(B, NWIN * 5, H, W, generator=g) * (torch.rand(B, NWIN * 5, H, W, generator=g) > 0.7)).contiguous()
+    frame = torch.rand(B, 3, H, W, generator=g)
+    pl = torch.randint(0, 11, (B, H, W), generator=g)
+    sp = torch.randint(0, 25, (B, H // 8, W // 8), generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)
+    S = int((sp + torch.arange(B)[:, None, None] * 25).max()) + 1
+    return (ev.to(dev), None, frame.to(dev), pl.to(dev), sp.to(dev), S)
+
+
+def _build(seed=1205):
+    from openess_amd.training.pretrain_step import PretrainStep
+    from tests.synth import damp_residual
+    st = PretrainStep(config_option="frame2voxel", img_size=(H, W), nr_events_data=NWIN, if_spatial_contrastive=True,
+                      superpixel_size=25, lr=1e-4, seed=seed)
+    for m in st.models_dict.values():
+        damp_residual(m)
+    return st
+
+
+def _trainable(st):
+    return [(f"{k}.{n}", p) for k, m in st.models_dict.items() for n, p in m.named_parameters() if p.requires_grad]
+
+
+def _one_step(st, red, batch):
+    for opt in st.optimizers_dict.values():
+        opt.zero_grad()
+    if red is not None:
+        red.prepare()
+    t_loss, _, _ = st.task_train_step(batch)
+    t_loss.backward()
+    early = 0 if red is None else sum(b.launched for b in red.buckets)
+    if red is not None:
+        red()
+    grads = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in _trainable(st)}
+    for opt in st.optimizers_dict.values():
+        opt.step()
+    return grads, early, float(t_loss)
+
+
+def _world1_worker(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from openess_amd.training.ddp import GradAllReduce, broadcast_module_states
+    st = _build()
+    broadcast_module_states(st.models_dict.values())          # 1-rank broadcast: RCCL call path of the weight sync
+    red = GradAllReduce([p for _, p in _trainable(st)], bucket_bytes=4 << 20, force_buckets=True)
+    assert red.active and len(red.buckets) >= 2
+    batch = _batch()
+    g1, early, loss1 = _one_step(st, red, batch)
+    assert red._avg is True                                   # ReduceOp.AVG, the RCCL branch
+    g2, _, loss2 = _one_step(st, red, batch)                  # a second step reuses the buckets (prepare re-zeroes them)
+    w = {n: p.detach().float().cpu() for n, p in _trainable(st)}
+    ref = _build()
+    r1, _, rl1 = _one_step(ref, None, batch)
+    r2, _, rl2 = _one_step(ref, None, batch)
+    wr = {n: p.detach().float().cpu() for n, p in _trainable(ref)}
+    bad = []
+    for n in g1:
+        for a, b in ((g1[n], r1[n]), (g2[n], r2[n])):
+            if (a is None) != (b is None) or (a is not None and not torch.equal(a.cpu(), b.cpu())):
+                bad.append(n)
+    out[0] = {"early": early, "bad": sorted(set(bad)), "n_buckets": len(red.buckets), "loss": (loss1, loss2, rl1, rl2),
+              "w_equal": all(torch.equal(w[n], wr[n]) for n in w)}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_world1_bucketed_reducer_on_the_real_step():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_world1_worker, args=(_free_port(), out), nprocs=1, join=True)
+    r = out[0]
+    assert r["n_buckets"] >= 2 and r["early"] >= 1            # at least one all-reduce was launched from a hook, under backward
+    assert r["bad"] == [], r["bad"][:5]                       # AVG over one rank: bit-identical gradients (incl. None ones)
+    assert r["loss"][0] == r["loss"][2] and r["loss"][1] == r["loss"][3]
+    assert r["w_equal"]
+
+
+def _world2_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    from openess_amd.training.ddp import GradAllReduce, broadcast_module_states
+    dev = torch.device("cuda", rank)
+    torch.manual_seed(100 + rank)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 16, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(16, 8, 1)).to(dev)
+    unused = torch.nn.Linear(8, 8).to(dev)
+    broadcast_module_states([net, unused])
+    params = list(net.parameters()) + list(unused.parameters())
+    red = GradAllReduce(params, world, bucket_bytes=256)
+    torch.manual_seed(7 + rank)
+    x = torch.randn(4, 3, 16, 16, device=dev)
+    net.zero_grad(); unused.zero_grad()
+    red.prepare()
+    net(x).square().mean().backward()
+    red()
+    got = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad()
+    net(x).square().mean().backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    dist.all_reduce(flat)
+    flat /= world
+    off, ok = 0, True
+    for g, p in zip(got, net.parameters()):
+        ok = ok and torch.allclose(g.reshape(-1), flat[off:off + p.numel()], rtol=1e-6, atol=1e-8)
+        off += p.numel()
+    out[rank] = {"ok": ok, "unused_none": all(p.grad is None for p in unused.parameters())}
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (xGMI peers)")
+def test_rccl_world2_equals_flatten_allreduce_unflatten():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_world2_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out[0]["ok"] and out[1]["ok"] and out[0]["unused_none"] and out[1]["unused_none"]
