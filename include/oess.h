@@ -207,13 +207,12 @@ int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, 
                          long long out_pix_stride, float* tile_stats, oess_stream_t stream);
 /* tile_stats (nullable): [ceil(M/128)][2][Cout] fp32, per-128-row-tile column sums and sums of squares of the fp32
  * result (BatchNorm batch statistics straight from the accumulators; bias-free, no activation/residual).
- * oess_norm_reduce_tile_stats folds them into sum[C] / sumsq[C] for oess_norm_finalize. */
-int oess_norm_reduce_tile_stats(const float* tile_stats, int tiles, int C, float* sum, float* sumsq, int pre_zeroed,
-                                oess_stream_t stream);
+ * oess_norm_reduce_finalize_tile_stats turns them into mean / rstd / scale / shift. */
 
-/* oess_norm_reduce_tile_stats + oess_norm_finalize (G = 1) in ONE launch, totals and E[x^2] - E[x]^2 in double: the tile partials of a conv epilogue -> mean / rstd / scale / shift (+ BatchNorm running
- * statistics; models/image_model.py:113-114 leaves the frozen teacher in .train()).  `scratch`: caller-owned double[2 * C],
- * `counters`: caller-owned uint32[(C + 31) / 32]; both must be ZERO on entry and are left zero on return (stream-ordered reuse). */
+/* Reduce + finalize (G = 1) in ONE launch, sums and E[x^2] - E[x]^2 in double, slices added in a FIXED order (bit-repeatable):
+ * the tile partials of a conv epilogue -> mean / rstd / scale / shift (+ BatchNorm running statistics;
+ * models/image_model.py:113-114 leaves the frozen teacher in .train()).  `scratch`: caller-owned double[32 * 2 * C] (any
+ * content), `counters`: caller-owned uint32[(C + 31) / 32], ZERO on entry and left zero on return (stream-ordered reuse). */
 int oess_norm_reduce_finalize_tile_stats(const float* tile_stats, int tiles, int C, double* scratch,
                                          unsigned int* counters, float count, float eps, const float* gamma, const float* beta,
                                          float* running_mean, float* running_var, float momentum, float* mean, float* rstd,
@@ -255,14 +254,19 @@ int oess_event_slice_to_nhwc8_bf16(const float* in, int B, int Ctot, int c0, int
  * (style_networks.py:148-160) and nn.Upsample(x4, bilinear, align_corners=True) + F.normalize
  * (image_model.py:121-143).  G groups of pixels_per_group pixels: G = 1 BatchNorm, G = B InstanceNorm.
  * ------------------------------------------------------------------------------------------ */
+/* Statistics are DETERMINISTIC: every workgroup writes its partial sums to `partials` (caller workspace of
+ * oess_norm_partials_bytes(G, pixels_per_group, C, backward) bytes; backward = 1 for the two *_bwd entry points) and a second
+ * kernel adds the rows in a fixed order in double -- no floating-point atomics anywhere on the training path. */
+size_t oess_norm_partials_bytes(int G, long long pixels_per_group, int C, int backward);
+/* sum[G x C] = sum of x, sumsq[G x C] = sum of x^2 (overwritten; also the bias gradient: sum of dY over pixels) */
 int oess_norm_stats_nhwc_bf16(const void* x, long long x_pix_stride, int G, long long pixels_per_group, int C,
-                              float* sum, float* sumsq, int pre_zeroed, oess_stream_t stream);
-/* sum / sumsq are ACCUMULATED into; pre_zeroed = 0 makes the call zero them first.  With pre_zeroed = 1 and
- * oess_norm_finalize(..., rezero = 1) a caller keeps one persistent zero scratch and never issues a memset
- * (the finalize kernel clears what it has read). */
-int oess_norm_finalize(float* sum, float* sumsq, int rezero, int G, int C, float count, float eps, const float* gamma,
-                       const float* beta, float* running_mean, float* running_var, float momentum, float* mean,
-                       float* rstd, float* scale, float* shift, oess_stream_t stream);
+                              float* sum, float* sumsq, float* partials, size_t partials_bytes, oess_stream_t stream);
+/* statistics + mean / rstd / scale = gamma*rstd / shift = beta - mean*scale per (group, channel), E[x^2] - E[x]^2 in double;
+ * G == 1 and running_mean != NULL: nn.BatchNorm2d's running-statistics update (unbiased variance).  gamma / beta nullable. */
+int oess_norm_stats_finalize_nhwc_bf16(const void* x, long long x_pix_stride, int G, long long pixels_per_group, int C, float eps,
+                                       const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                       float momentum, float* mean, float* rstd, float* scale, float* shift, float* partials,
+                                       size_t partials_bytes, oess_stream_t stream);
 /* out = act(x*scale + shift [+ residual]) */
 int oess_norm_apply_nhwc_bf16(const void* x, long long x_pix_stride, const float* scale, const float* shift,
                               const void* residual, long long res_pix_stride, int relu, int G, long long pixels_per_group,
@@ -270,17 +274,19 @@ int oess_norm_apply_nhwc_bf16(const void* x, long long x_pix_stride, const float
 /* affine-free InstanceNorm (+ReLU) backward; s1/s2 are [G x C] scratch */
 int oess_instnorm_bwd_nhwc_bf16(const void* x, long long x_pix_stride, const void* dy, long long dy_pix_stride,
                                 const float* mean, const float* rstd, int relu, int G, long long pixels_per_group, int C,
-                                float* s1, float* s2, void* dx, long long dx_pix_stride, oess_stream_t stream);
+                                float* s1, float* s2, void* dx, long long dx_pix_stride, float* partials, size_t partials_bytes,
+                                oess_stream_t stream);
 /* nn.BatchNorm2d TRAIN-mode backward fused with the ReLU mask and the residual branch of a Bottleneck
  * (models/_resnet.py:96-114: out = relu(bn3(conv3) + identity)):  g = dy * (y_out > 0 if relu);  d(residual) = g;
  * dbeta[C] = sum g;  dgamma[C] = sum g * xhat;  dx = gamma * rstd * (g - dbeta/N - xhat * dgamma/N).
  * x = the BatchNorm input, y_out = the stored forward output (needed when relu != 0), mean / rstd = the batch statistics
- * of the forward (oess_norm_finalize).  dresidual nullable.  Replaces MIOpenBatchNormBwdSpatial* + the ATen ReLU / add
+ * of the forward (oess_norm_stats_finalize_nhwc_bf16).  dresidual nullable.  Replaces MIOpenBatchNormBwdSpatial* + the ATen ReLU / add
  * backward kernels on the trainable DeepLabv3 path. */
 int oess_batchnorm_bwd_nhwc_bf16(const void* x, long long x_pix_stride, const void* dy, long long dy_pix_stride, const void* y_out,
                                  long long y_pix_stride, const float* mean, const float* rstd, const float* gamma, int relu,
                                  long long pixels, int C, float* dbeta, float* dgamma, void* dx, long long dx_pix_stride,
-                                 void* dresidual, long long dres_pix_stride, oess_stream_t stream);
+                                 void* dresidual, long long dres_pix_stride, float* partials, size_t partials_bytes,
+                                 oess_stream_t stream);
 int oess_upsample_nearest2x_nhwc_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int C, void* out,
                                       long long out_pix_stride, oess_stream_t stream);
 /* z[b, s*y, s*x, :] = in[b, y, x, :], zero elsewhere on an Hz x Wz grid: turns the data gradient of a stride-s convolution

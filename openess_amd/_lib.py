@@ -58,7 +58,7 @@ SIGNATURES = {
     "oess_l2norm_nhwc_bwd": (c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_i64, c_int, c_int, c_f, c_vp, c_ll, c_vp]),
     "oess_zero_insert_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_ll, c_vp]),
     "oess_batchnorm_bwd_nhwc_bf16": (c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_vp, c_int, c_ll, c_int, c_vp, c_vp,
-                                             c_vp, c_ll, c_vp, c_ll, c_vp]),
+                                             c_vp, c_ll, c_vp, c_ll, c_vp, c_sz, c_vp]),
     "oess_layernorm_bf16": (c_int, [c_vp, c_ll, c_i64, c_int, c_vp, c_vp, c_f, c_vp, c_ll, c_vp]),
     "oess_attention_d64_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_f, c_vp, c_ll, c_vp]),
     "oess_nce_loss_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_f, c_vp, c_vp, c_sz, c_vp, c_vp]),
@@ -66,12 +66,13 @@ SIGNATURES = {
     "oess_adamw_multi_f32": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_d, c_d, c_d, c_d, c_d, c_d, c_d, c_vp]),
     "oess_masked_stats_slice_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp]),
     "oess_event_slice_to_nhwc8_bf16": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_ll, c_vp, c_int, c_vp, c_vp]),
-    "oess_norm_stats_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_ll, c_int, c_vp, c_vp, c_int, c_vp]),
-    "oess_norm_finalize": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_vp,
-                                   c_vp]),
+    "oess_norm_partials_bytes": (c_sz, [c_int, c_ll, c_int, c_int]),
+    "oess_norm_stats_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_ll, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "oess_norm_stats_finalize_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_ll, c_int, c_f, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp,
+                                                   c_vp, c_vp, c_vp, c_sz, c_vp]),
     "oess_norm_apply_nhwc_bf16": (c_int, [c_vp, c_ll, c_vp, c_vp, c_vp, c_ll, c_int, c_int, c_ll, c_int, c_vp, c_ll, c_vp]),
     "oess_instnorm_bwd_nhwc_bf16": (c_int, [c_vp, c_ll, c_vp, c_ll, c_vp, c_vp, c_int, c_int, c_ll, c_int, c_vp, c_vp, c_vp,
-                                            c_ll, c_vp]),
+                                            c_ll, c_vp, c_sz, c_vp]),
     "oess_upsample_nearest2x_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp, c_ll, c_vp]),
     "oess_downsample_sum2x_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp, c_ll, c_vp]),
     "oess_bilinear_l2norm_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_ll, c_vp]),
@@ -81,7 +82,6 @@ SIGNATURES = {
     "oess_conv2d_pack_weight": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
     "oess_conv2d_fwd_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                      c_int, c_int, c_int, c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp]),
-    "oess_norm_reduce_tile_stats": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
     "oess_norm_reduce_finalize_tile_stats": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_f,
                                                      c_vp, c_vp, c_vp, c_vp, c_vp]),
 }

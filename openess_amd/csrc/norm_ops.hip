@@ -19,7 +19,9 @@ constexpr int THREADS = 256;
 union Pack8 { uint4 q; uint16_t h[8]; };
 
 // ---------------------------------------------------------------------------------------------
-// statistics: sum[g][c], sumsq[g][c] over the pixels of group g.  grid = (chunks, G).
+// statistics: per-workgroup partial sums part[chunk][2][G*C] over the chunk's pixels of group g.  grid = (chunks, G).
+// NO atomics: every workgroup owns its row of the partials buffer and partials_reduce_kernel adds the rows in a fixed order
+// in double, so the statistics (and everything downstream of them) are bit-repeatable from run to run.
 // thread layout: cl = C/8 channel-lanes per pixel (power of two not required), rows = THREADS/cl pixels in flight.
 // MODE 0: plain sums of x.   MODE 1 (InstanceNorm backward): s1 = sum g, s2 = sum g*xhat with
 //         xhat = (x-mean)*rstd, g = dy * (relu ? xhat > 0 : 1).
@@ -28,9 +30,8 @@ template <int MODE>
 __global__ __launch_bounds__(THREADS) void stats_kernel(const uint16_t* __restrict__ x, int64_t xps,
                                                         const uint16_t* __restrict__ dy, int64_t dps,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                        int relu, int64_t ppg, int C, float* __restrict__ o1,
-                                                        float* __restrict__ o2, const uint16_t* __restrict__ yout = nullptr,
-                                                        int64_t yps = 0) {
+                                                        int relu, int64_t ppg, int C, float* __restrict__ part,
+                                                        const uint16_t* __restrict__ yout = nullptr, int64_t yps = 0) {
     extern __shared__ float red[];                 // [rows][C][2]
     const int cl = C >> 3;
     const int rows = THREADS / cl;
@@ -110,37 +111,65 @@ __global__ __launch_bounds__(THREADS) void stats_kernel(const uint16_t* __restri
         }
     }
     __syncthreads();
+    const int64_t GC = (int64_t)gridDim.y * C;
     for (int c = threadIdx.x; c < C; c += THREADS) {
         float s1 = 0.f, s2 = 0.f;
         for (int r = 0; r < rows; ++r) { s1 += red[(r * C + c) * 2]; s2 += red[(r * C + c) * 2 + 1]; }
-        atomicAdd(&o1[(int64_t)g * C + c], s1);
-        atomicAdd(&o2[(int64_t)g * C + c], s2);
+        part[((int64_t)blockIdx.x * 2 + 0) * GC + (int64_t)g * C + c] = s1;
+        part[((int64_t)blockIdx.x * 2 + 1) * GC + (int64_t)g * C + c] = s2;
     }
 }
 
-// mean / rstd / (scale, shift) per (group, channel); optional BatchNorm running-stat update (G == 1).
-__global__ void finalize_kernel(float* __restrict__ sum, float* __restrict__ sumsq, int rezero, int G, int C, float count,
-                                float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
-                                float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ scale,
-                                float* __restrict__ shift) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G * C) return;
-    const int c = i % C;
-    const float m = sum[i] / count;
-    float var = sumsq[i] / count - m * m;        // biased variance (normalisation uses it in BN and IN)
-    if (rezero) { sum[i] = 0.f; sumsq[i] = 0.f; }  // self-cleaning accumulators: the caller keeps them zero between uses
-    if (var < 0.f) var = 0.f;
-    const float r = rsqrtf(var + eps);
-    mean_out[i] = m; rstd_out[i] = r;
+// mean / rstd / (scale, shift) of one (group, channel) from its double totals; optional BatchNorm running-stat update.
+__device__ __forceinline__ void finalize_one(double S, double Q, int i, int c, bool bn_running, float count, float eps,
+                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                             float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                             float* __restrict__ scale, float* __restrict__ shift) {
+    const double m = S / (double)count;
+    double var = Q / (double)count - m * m;          // biased variance (normalisation uses it in BN and IN); no fp32 cancellation
+    if (var < 0.0) var = 0.0;
+    const float r = (float)(1.0 / sqrt(var + (double)eps));
+    mean_out[i] = (float)m; rstd_out[i] = r;
     const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
     scale[i] = ga * r;
-    shift[i] = be - m * ga * r;
-    if (running_mean && G == 1) {                // nn.BatchNorm2d: running_var uses the UNBIASED estimate
-        const float unb = count > 1.f ? var * count / (count - 1.f) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+    shift[i] = be - (float)m * ga * r;
+    if (bn_running) {                                // nn.BatchNorm2d: running_var uses the UNBIASED estimate
+        const float unb = count > 1.f ? (float)(var * (double)count / ((double)count - 1.0)) : (float)var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
     }
+}
+
+// Fixed-order reduction of stats_kernel's partials part[chunks][2][N] (N = G*C) in double.  block = 32 columns x 8 chunk lanes;
+// lane tl adds chunks tl, tl+8, ... in order, the 8 lane sums are added 0..7: the result does not depend on scheduling.
+// FIN = false: o1[N] = sum, o2[N] = second sum (backward: d(beta), d(gamma) / the InstanceNorm sums).
+// FIN = true : mean / rstd / scale / shift (+ running statistics when G == 1), E[x^2] - E[x]^2 in double.
+template <bool FIN>
+__global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __restrict__ part, int chunks, int G, int C,
+                                                              float* __restrict__ o1, float* __restrict__ o2, float count, float eps,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                              float momentum, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                              float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double red[8][32][2];
+    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    const int64_t N = (int64_t)G * C;
+    const int64_t i = (int64_t)blockIdx.x * 32 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (i < N)
+        for (int t = tl; t < chunks; t += 8) {
+            s1 += (double)part[((int64_t)t * 2) * N + i];
+            s2 += (double)part[((int64_t)t * 2 + 1) * N + i];
+        }
+    red[tl][cl][0] = s1; red[tl][cl][1] = s2;
+    __syncthreads();
+    if (tl != 0 || i >= N) return;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }
+    if (!FIN) { o1[i] = (float)s1; o2[i] = (float)s2; return; }
+    finalize_one(s1, s2, (int)i, (int)(i % C), running_mean != nullptr && G == 1, count, eps, gamma, beta, running_mean, running_var,
+                 momentum, mean_out, rstd_out, scale, shift);
 }
 
 // Thread layout of both apply kernels: lane_c = channel chunk (8 channels) is FIXED per thread, rows = THREADS / (C/8)
@@ -401,37 +430,16 @@ __global__ __launch_bounds__(THREADS) void bilinear_l2_vec_kernel(const uint16_t
     }
 }
 
-// reduce the conv epilogue's per-tile partials [tiles][2][C] -> sum[C], sumsq[C]   (sum / sumsq pre-zeroed)
-// block = 32 channels x 8 tile lanes; grid.y slices the tile range; one atomic per (block, channel).
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int tiles, int C,
-                                                              float* __restrict__ sum, float* __restrict__ sumsq) {
-    __shared__ float red[8][32][2];
-    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
-    float s1 = 0.f, s2 = 0.f;
-    if (c < C)
-        for (int t = blockIdx.y * 8 + tl; t < tiles; t += gridDim.y * 8) {
-            s1 += part[((size_t)t * 2) * C + c];
-            s2 += part[((size_t)t * 2 + 1) * C + c];
-        }
-    red[tl][cl][0] = s1; red[tl][cl][1] = s2;
-    __syncthreads();
-    if (tl == 0 && c < C) {
-#pragma unroll
-        for (int k = 1; k < 8; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }
-        atomicAdd(&sum[c], s1);
-        atomicAdd(&sumsq[c], s2);
-    }
-}
-
-// reduce_partials_kernel + finalize_kernel in ONE launch (the frozen teacher and the DeepLab forward issue 53-59 of each per pass).
-// Block (channel group, slice y) sums its slice of the tile partials in DOUBLE and adds the pair to totals[2][C] with RETURNING
-// device-scope atomics (performed at the coherence point once the value is back), then takes a ticket; the block with the last
-// ticket reads the totals back with atomics and computes mean / rstd / scale / shift / running statistics in double, so
-// E[x^2] - E[x]^2 does not cancel in fp32, and leaves totals and tickets zero (atomic exchanges) for the next call.
+// Reduce + finalize the conv epilogue's per-tile partials [tiles][2][C] in ONE launch (the frozen teacher and the DeepLab forward
+// issue 53-59 of these per pass).  Block (channel group x, slice y) sums its slice of the tiles in DOUBLE; with one slice
+// (tiles <= 64) it finalizes directly.  With several slices it parks its pair of sums in scratch[y][2][C] with RETURNING
+// device-scope exchanges (performed at the coherence point once the value is back) and takes a ticket; the block with the
+// last ticket reads all slices back (agent-scope atomic loads) and adds them IN SLICE ORDER, so the statistics do not depend
+// on which block finished first (bit-repeatable; round 2 added the slices with double atomics in arrival order), then computes
+// mean / rstd / scale / shift / running statistics in double and leaves the ticket zero for the next call.
 // NO __threadfence(): an agent-scope release writes back the whole XCD L2, which right after a convolution holds megabytes of
-// dirty output -- measured 25-31 us per call for two versions that used one, against ~10 us for the two separate kernels.
-__global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ part, int tiles, int C, double* __restrict__ totals,
+// dirty output -- measured 25-31 us per call for two versions that used one, against ~10 us for two separate kernels.
+__global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ part, int tiles, int C, double* __restrict__ scratch,
                                                               unsigned int* __restrict__ counter, float count, float eps,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
@@ -452,32 +460,39 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
     if (tl == 0 && c < C) {
 #pragma unroll
         for (int k = 1; k < 8; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }
-        const double o1 = atomicAdd(&totals[c], s1), o2 = atomicAdd(&totals[C + c], s2);
-        asm volatile("" :: "v"(o1), "v"(o2));                    // wait for both atomics to have been performed
     }
-    __syncthreads();
-    if (threadIdx.x == 0) ticket = atomicAdd(&counter[blockIdx.x], 1u);
-    __syncthreads();
-    if (ticket != gridDim.y - 1) return;
-    if (tl == 0 && c < C) {
-        // read-and-reset in one memory-side operation each
-        const double S = __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long*>(&totals[c]), 0ull));
-        const double Q = __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long*>(&totals[C + c]), 0ull));
-        const double m = S / (double)count;
-        double var = Q / (double)count - m * m;                                         // biased variance
-        if (var < 0.0) var = 0.0;
-        const float r = (float)(1.0 / sqrt(var + (double)eps));
-        mean_out[c] = (float)m; rstd_out[c] = r;
-        const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
-        scale[c] = ga * r;
-        shift[c] = be - (float)m * ga * r;
-        if (running_mean) {                                                             // nn.BatchNorm2d: unbiased running_var
-            const float unb = count > 1.f ? (float)(var * (double)count / ((double)count - 1.0)) : (float)var;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    if (gridDim.y > 1) {
+        if (tl == 0 && c < C) {
+            unsigned long long* slot = reinterpret_cast<unsigned long long*>(scratch) + ((size_t)blockIdx.y * 2) * C + c;
+            const unsigned long long r1 = atomicExch(slot, (unsigned long long)__double_as_longlong(s1));
+            const unsigned long long r2 = atomicExch(slot + C, (unsigned long long)__double_as_longlong(s2));
+            asm volatile("" :: "v"(r1), "v"(r2));                // wait for both exchanges to have been performed
         }
+        __syncthreads();
+        if (threadIdx.x == 0) ticket = atomicAdd(&counter[blockIdx.x], 1u);
+        __syncthreads();
+        if (ticket != gridDim.y - 1) return;
+        // last block of this channel group: all 256 threads fetch (slice tl, tl+8, ...), then a fixed-order sum
+        double p1 = 0.0, p2 = 0.0;
+        if (c < C)
+            for (int y = tl; y < (int)gridDim.y; y += 8) {
+                const double* slot = scratch + ((size_t)y * 2) * C + c;
+                p1 += __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                p2 += __hip_atomic_load(slot + C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        __syncthreads();                                         // red[] of the first phase has been consumed by tl == 0 above
+        red[tl][cl][0] = p1; red[tl][cl][1] = p2;
+        __syncthreads();
+        if (tl == 0 && c < C) {
+            s1 = p1; s2 = p2;
+#pragma unroll
+            for (int k = 1; k < 8; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }
+        }
+        if (threadIdx.x == 0) atomicExch(&counter[blockIdx.x], 0u);
     }
-    if (threadIdx.x == 0) atomicExch(&counter[blockIdx.x], 0u);
+    if (tl == 0 && c < C)
+        finalize_one(s1, s2, c, c, running_mean != nullptr, count, eps, gamma, beta, running_mean, running_var, momentum, mean_out,
+                     rstd_out, scale, shift);
 }
 
 // chunks per group.  Every workgroup ends with 2*C float atomics on the same few cache lines, and those serialise in L2:
@@ -511,42 +526,58 @@ int grid_for(int64_t work) {
 
 }  // namespace
 
-// zero two fp32 accumulators; one memset when they are adjacent (the wrappers allocate them as one tensor)
-static hipError_t zero_pair(float* a, float* b, size_t n, hipStream_t st) {
-    if (b == a + n) return hipMemsetAsync(a, 0, 2 * n * sizeof(float), st);
-    hipError_t e = hipMemsetAsync(a, 0, n * sizeof(float), st);
-    if (e != hipSuccess) return e;
-    return hipMemsetAsync(b, 0, n * sizeof(float), st);
+// launch stats_kernel<MODE> into the partials buffer; returns the number of chunk rows written (0 on a bad workspace)
+template <int MODE>
+static int launch_stats(hipStream_t st, const void* x, long long xps, const void* dy, long long dps, const float* mean,
+                        const float* rstd, int relu, int G, long long ppg, int C, float* partials, size_t partials_bytes,
+                        const void* yout = nullptr, long long yps = 0) {
+    const int cl = C >> 3;
+    if (cl > THREADS) return 0;
+    const int rows = THREADS / cl;
+    const size_t lds = (size_t)rows * C * 2 * sizeof(float);
+    const unsigned chunks = stats_chunks(ppg, G, MODE == 0 ? 256 : 512);
+    if (!partials || partials_bytes < (size_t)chunks * 2 * G * C * sizeof(float)) return 0;
+    hipLaunchKernelGGL(stats_kernel<MODE>, dim3(chunks, (unsigned)G), dim3(THREADS), lds, st, (const uint16_t*)x, (int64_t)xps,
+                       (const uint16_t*)dy, (int64_t)dps, mean, rstd, relu, (int64_t)ppg, C, partials, (const uint16_t*)yout,
+                       (int64_t)yps);
+    return (int)chunks;
 }
 
 extern "C" {
 
+size_t oess_norm_partials_bytes(int G, long long pixels_per_group, int C, int backward) {
+    if (G <= 0 || pixels_per_group <= 0 || C <= 0) return 0;
+    return (size_t)stats_chunks(pixels_per_group, G, backward ? 512 : 256) * 2 * (size_t)G * C * sizeof(float);
+}
+
 int oess_norm_stats_nhwc_bf16(const void* x, long long x_pix_stride, int G, long long pixels_per_group, int C,
-                              float* sum, float* sumsq, int pre_zeroed, oess_stream_t stream) {
+                              float* sum, float* sumsq, float* partials, size_t partials_bytes, oess_stream_t stream) {
     if (!x || !sum || !sumsq || G <= 0 || pixels_per_group <= 0 || C <= 0 || (C & 7) || C > 2048 || (x_pix_stride & 7))
         return OESS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (!pre_zeroed) OESS_HIP(zero_pair(sum, sumsq, (size_t)G * C, st));
-    const int cl = C >> 3;
-    if (cl > THREADS) return OESS_EINVAL;
-    const int rows = THREADS / cl;
-    const size_t lds = (size_t)rows * C * 2 * sizeof(float);
-    dim3 grid(stats_chunks(pixels_per_group, G), (unsigned)G);
-    hipLaunchKernelGGL(stats_kernel<0>, grid, dim3(THREADS), lds, st, (const uint16_t*)x, (int64_t)x_pix_stride, nullptr,
-                       (int64_t)0, nullptr, nullptr, 0, (int64_t)pixels_per_group, C, sum, sumsq);
+    const int chunks = launch_stats<0>(st, x, x_pix_stride, nullptr, 0, nullptr, nullptr, 0, G, pixels_per_group, C, partials,
+                                       partials_bytes);
+    if (!chunks) return OESS_EINVAL;
+    hipLaunchKernelGGL(partials_reduce_kernel<false>, dim3((unsigned)(((int64_t)G * C + 31) / 32)), dim3(256), 0, st, partials, chunks, G,
+                       C, sum, sumsq, 1.f, 0.f, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }
 
-int oess_norm_reduce_tile_stats(const float* tile_stats, int tiles, int C, float* sum, float* sumsq, int pre_zeroed,
-                                oess_stream_t stream) {
-    if (!tile_stats || !sum || !sumsq || tiles <= 0 || C <= 0) return OESS_EINVAL;
+int oess_norm_stats_finalize_nhwc_bf16(const void* x, long long x_pix_stride, int G, long long pixels_per_group, int C, float eps,
+                                       const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                       float momentum, float* mean, float* rstd, float* scale, float* shift, float* partials,
+                                       size_t partials_bytes, oess_stream_t stream) {
+    if (!x || !mean || !rstd || !scale || !shift || G <= 0 || pixels_per_group <= 0 || C <= 0 || (C & 7) || C > 2048 ||
+        (x_pix_stride & 7))
+        return OESS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (!pre_zeroed) OESS_HIP(zero_pair(sum, sumsq, (size_t)C, st));
-    int gy = (tiles + 63) / 64;                    // >= 8 tiles per tile lane
-    if (gy > 32) gy = 32;
-    if (gy < 1) gy = 1;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 31) / 32, gy), dim3(256), 0, st, tile_stats, tiles, C, sum, sumsq);
+    const int chunks = launch_stats<0>(st, x, x_pix_stride, nullptr, 0, nullptr, nullptr, 0, G, pixels_per_group, C, partials,
+                                       partials_bytes);
+    if (!chunks) return OESS_EINVAL;
+    hipLaunchKernelGGL(partials_reduce_kernel<true>, dim3((unsigned)(((int64_t)G * C + 31) / 32)), dim3(256), 0, st, partials, chunks, G,
+                       C, nullptr, nullptr, (float)pixels_per_group, eps, gamma, beta, running_mean, running_var, momentum, mean, rstd,
+                       scale, shift);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }
@@ -562,16 +593,6 @@ int oess_norm_reduce_finalize_tile_stats(const float* tile_stats, int tiles, int
     if (gy < 1) gy = 1;
     hipLaunchKernelGGL(reduce_finalize_kernel, dim3((C + 31) / 32, gy), dim3(256), 0, (hipStream_t)stream, tile_stats, tiles, C, scratch,
                        counters, count, eps, gamma, beta, running_mean, running_var, momentum, mean, rstd, scale, shift);
-    OESS_HIP(hipGetLastError());
-    return OESS_OK;
-}
-
-int oess_norm_finalize(float* sum, float* sumsq, int rezero, int G, int C, float count, float eps, const float* gamma,
-                       const float* beta, float* running_mean, float* running_var, float momentum, float* mean,
-                       float* rstd, float* scale, float* shift, oess_stream_t stream) {
-    if (!sum || !sumsq || !mean || !rstd || !scale || !shift || G <= 0 || C <= 0 || count <= 0.f) return OESS_EINVAL;
-    hipLaunchKernelGGL(finalize_kernel, dim3((G * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sum, sumsq, rezero, G, C, count,
-                       eps, gamma, beta, running_mean, running_var, momentum, mean, rstd, scale, shift);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }
@@ -592,19 +613,17 @@ int oess_norm_apply_nhwc_bf16(const void* x, long long x_pix_stride, const float
 
 int oess_instnorm_bwd_nhwc_bf16(const void* x, long long x_pix_stride, const void* dy, long long dy_pix_stride,
                                 const float* mean, const float* rstd, int relu, int G, long long pixels_per_group, int C,
-                                float* s1, float* s2, void* dx, long long dx_pix_stride, oess_stream_t stream) {
+                                float* s1, float* s2, void* dx, long long dx_pix_stride, float* partials, size_t partials_bytes,
+                                oess_stream_t stream) {
     if (!x || !dy || !mean || !rstd || !s1 || !s2 || !dx || G <= 0 || pixels_per_group <= 0 || C <= 0 || (C & 7) ||
         C > 2048 || (x_pix_stride & 7) || (dy_pix_stride & 7) || (dx_pix_stride & 7))
         return OESS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    OESS_HIP(zero_pair(s1, s2, (size_t)G * C, st));
-    const int cl = C >> 3;
-    if (cl > THREADS) return OESS_EINVAL;
-    const int rows = THREADS / cl;
-    const size_t lds = (size_t)rows * C * 2 * sizeof(float);
-    dim3 grid(stats_chunks(pixels_per_group, G, 512), (unsigned)G);
-    hipLaunchKernelGGL(stats_kernel<1>, grid, dim3(THREADS), lds, st, (const uint16_t*)x, (int64_t)x_pix_stride,
-                       (const uint16_t*)dy, (int64_t)dy_pix_stride, mean, rstd, relu, (int64_t)pixels_per_group, C, s1, s2);
+    const int chunks = launch_stats<1>(st, x, x_pix_stride, dy, dy_pix_stride, mean, rstd, relu, G, pixels_per_group, C, partials,
+                                       partials_bytes);
+    if (!chunks) return OESS_EINVAL;
+    hipLaunchKernelGGL(partials_reduce_kernel<false>, dim3((unsigned)(((int64_t)G * C + 31) / 32)), dim3(256), 0, st, partials, chunks, G,
+                       C, s1, s2, 1.f, 0.f, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(in_bwd_apply_kernel, apply_grid(pixels_per_group, G, C), dim3(THREADS), 0, st,
                        (const uint16_t*)x, (int64_t)x_pix_stride, (const uint16_t*)dy, (int64_t)dy_pix_stride, mean, rstd, s1,
                        s2, relu, (int64_t)pixels_per_group, G, C, (uint16_t*)dx, (int64_t)dx_pix_stride);
@@ -615,22 +634,19 @@ int oess_instnorm_bwd_nhwc_bf16(const void* x, long long x_pix_stride, const voi
 int oess_batchnorm_bwd_nhwc_bf16(const void* x, long long x_pix_stride, const void* dy, long long dy_pix_stride, const void* y_out,
                                  long long y_pix_stride, const float* mean, const float* rstd, const float* gamma, int relu,
                                  long long pixels, int C, float* dbeta, float* dgamma, void* dx, long long dx_pix_stride,
-                                 void* dresidual, long long dres_pix_stride, oess_stream_t stream) {
+                                 void* dresidual, long long dres_pix_stride, float* partials, size_t partials_bytes,
+                                 oess_stream_t stream) {
     if (!x || !dy || !mean || !rstd || !dbeta || !dgamma || !dx || pixels <= 0 || C <= 0 || (C & 7) || C > 2048 ||
         (x_pix_stride & 7) || (dy_pix_stride & 7) || (dx_pix_stride & 7) || (relu && !y_out) || (y_out && (y_pix_stride & 7)) ||
         (dresidual && (dres_pix_stride & 7)))
         return OESS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    OESS_HIP(zero_pair(dbeta, dgamma, (size_t)C, st));
-    const int cl = C >> 3;
-    if (cl > THREADS) return OESS_EINVAL;
-    const int rows = THREADS / cl;
-    const size_t lds = (size_t)rows * C * 2 * sizeof(float);
-    dim3 grid(stats_chunks(pixels, 1, 512), 1u);
     // dbeta = sum g, dgamma = sum g * xhat (exactly the two sums dx needs)
-    hipLaunchKernelGGL(stats_kernel<1>, grid, dim3(THREADS), lds, st, (const uint16_t*)x, (int64_t)x_pix_stride,
-                       (const uint16_t*)dy, (int64_t)dy_pix_stride, mean, rstd, relu, (int64_t)pixels, C, dbeta, dgamma,
-                       (const uint16_t*)y_out, (int64_t)y_pix_stride);
+    const int chunks = launch_stats<1>(st, x, x_pix_stride, dy, dy_pix_stride, mean, rstd, relu, 1, pixels, C, partials, partials_bytes,
+                                       y_out, y_pix_stride);
+    if (!chunks) return OESS_EINVAL;
+    hipLaunchKernelGGL(partials_reduce_kernel<false>, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, st, partials, chunks, 1, C, dbeta,
+                       dgamma, 1.f, 0.f, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(in_bwd_apply_kernel, apply_grid(pixels, 1, C), dim3(THREADS), 0, st, (const uint16_t*)x,
                        (int64_t)x_pix_stride, (const uint16_t*)dy, (int64_t)dy_pix_stride, mean, rstd, dbeta, dgamma, relu,
                        (int64_t)pixels, 1, C, (uint16_t*)dx, (int64_t)dx_pix_stride, (const uint16_t*)y_out, (int64_t)y_pix_stride,

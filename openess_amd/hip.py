@@ -628,26 +628,14 @@ def attention_d64(qkv, B, L, heads, out=None):
     return out
 
 
-# persistent zero accumulators for the norm statistics (self-cleaning: oess_norm_finalize(rezero=1) clears what it read),
-# so a BatchNorm / InstanceNorm forward issues no memset.  `busy` guards against an exception between stats and finalize.
+# scratch of oess_norm_reduce_finalize_tile_stats (per-slice double sums + last-block tickets; tickets are kept zero by the kernel)
 _STATS_SCRATCH = {}
 
 
 class _StatsScratch:
     def __init__(self, n, device):
-        self.buf = torch.zeros((2, n), dtype=torch.float32, device=device)
-        self.buf64 = torch.zeros((2, n), dtype=torch.float64, device=device)       # tile-statistics totals (double, kept zero) ...
-        self.tickets = torch.zeros(((n + 31) // 32,), dtype=torch.int32, device=device)   # ... and their last-block tickets
-        self.busy = False
-
-    def acquire(self):
-        if self.busy:                      # a previous use never reached its finalize: clean up the slow way
-            self.buf.zero_()
-        self.busy = True
-        return self.buf
-
-    def release(self):
-        self.busy = False
+        self.buf64 = torch.zeros((64, n), dtype=torch.float64, device=device)      # [32 slices][2][C]
+        self.tickets = torch.zeros(((n + 31) // 32,), dtype=torch.int32, device=device)
 
 
 def _stats_scratch(n, device):
@@ -659,6 +647,14 @@ def _stats_scratch(n, device):
     return sc
 
 
+def _norm_partials(G, ppg, C, device, backward=False):
+    """Workspace of the deterministic statistics kernels (per-workgroup partial sums, reduced in a fixed order)."""
+    lib = _lib.load()
+    nbytes = lib.oess_norm_partials_bytes(G, ppg, C, int(backward))
+    ws = _workspace(nbytes, device, tag=("norm_part", torch.cuda.current_stream(device).cuda_stream))
+    return ws, ws.numel()
+
+
 # ------------------------------------------------------------------------------------------ norms / resampling
 def _norm_forward(x_nhwc, G, gamma, beta, eps, relu, residual, running=None, momentum=0.1, out=None):
     """Shared BatchNorm(train)/InstanceNorm forward on an NHWC bf16 view.  Returns (out, mean, rstd)."""
@@ -667,17 +663,14 @@ def _norm_forward(x_nhwc, G, gamma, beta, eps, relu, residual, running=None, mom
     ppg = (B * H * W) // G
     dev = x_nhwc.device
     stats = torch.empty((6, G, C), dtype=torch.float32, device=dev)        # (unused, unused), mean, rstd, scale, shift
-    sc = _stats_scratch(G * C, dev)
-    acc = sc.acquire()                                                      # sum, sumsq: persistent, kept zero
-    _lib.check(lib.oess_norm_stats_nhwc_bf16(_ptr(x_nhwc), ps, G, ppg, C, _ptr(acc[0]), _ptr(acc[1]), 1, _stream()),
-               "oess_norm_stats_nhwc_bf16")
     rm = rv = None
     if running is not None:
         rm, rv = running
-    _lib.check(lib.oess_norm_finalize(_ptr(acc[0]), _ptr(acc[1]), 1, G, C, float(ppg), float(eps), _ptr(gamma), _ptr(beta),
-                                      _ptr(rm), _ptr(rv), float(momentum), _ptr(stats[2]), _ptr(stats[3]), _ptr(stats[4]),
-                                      _ptr(stats[5]), _stream()), "oess_norm_finalize")
-    sc.release()
+    ws, wsn = _norm_partials(G, ppg, C, dev)
+    _lib.check(lib.oess_norm_stats_finalize_nhwc_bf16(_ptr(x_nhwc), ps, G, ppg, C, float(eps), _ptr(gamma), _ptr(beta), _ptr(rm),
+                                                      _ptr(rv), float(momentum), _ptr(stats[2]), _ptr(stats[3]), _ptr(stats[4]),
+                                                      _ptr(stats[5]), _ptr(ws), wsn, _stream()),
+               "oess_norm_stats_finalize_nhwc_bf16")
     if out is None:
         out = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=dev)
     _, _, _, _, ops = _nhwc_geom(out)
@@ -728,9 +721,10 @@ class _BatchNormTrainFn(torch.autograd.Function):
         dres = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=x.device) if (ctx.has_res and ctx.relu) else None
         dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
         g32 = gamma.detach().float().contiguous()
+        ws, wsn = _norm_partials(1, B * H * W, C, x.device, backward=True)
         _lib.check(lib.oess_batchnorm_bwd_nhwc_bf16(_ptr(xn), xps, _ptr(gn), gps, None if out is None else _ptr(out), C, _ptr(mean),
                                                     _ptr(rstd), _ptr(g32), int(ctx.relu), B * H * W, C, _ptr(dgb[0]), _ptr(dgb[1]),
-                                                    _ptr(dx), C, None if dres is None else _ptr(dres), C, _stream()),
+                                                    _ptr(dx), C, None if dres is None else _ptr(dres), C, _ptr(ws), wsn, _stream()),
                    "oess_batchnorm_bwd_nhwc_bf16")
         gres = None
         if ctx.has_res:
@@ -776,8 +770,9 @@ class _InstanceNormFn(torch.autograd.Function):
         _, _, _, _, gps = _nhwc_geom(gn)
         dx = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=x.device)
         s = torch.empty((2, B, C), dtype=torch.float32, device=x.device)
+        ws, wsn = _norm_partials(B, H * W, C, x.device, backward=True)
         _lib.check(lib.oess_instnorm_bwd_nhwc_bf16(_ptr(xn), xps, _ptr(gn), gps, _ptr(mean), _ptr(rstd), int(ctx.relu), B, H * W,
-                                                   C, _ptr(s[0]), _ptr(s[1]), _ptr(dx), C, _stream()),
+                                                   C, _ptr(s[0]), _ptr(s[1]), _ptr(dx), C, _ptr(ws), wsn, _stream()),
                    "oess_instnorm_bwd_nhwc_bf16")
         return dx.permute(0, 3, 1, 2), None, (gy if ctx.has_res else None), None
 
@@ -961,7 +956,8 @@ def channel_sum(x_nhwc):
     lib = _lib.load()
     B, H, W, C, ps = _nhwc_geom(x_nhwc)
     st = torch.empty((2, C), dtype=torch.float32, device=x_nhwc.device)
-    _lib.check(lib.oess_norm_stats_nhwc_bf16(_ptr(x_nhwc), ps, 1, B * H * W, C, _ptr(st[0]), _ptr(st[1]), 0, _stream()),
+    ws, wsn = _norm_partials(1, B * H * W, C, x_nhwc.device)
+    _lib.check(lib.oess_norm_stats_nhwc_bf16(_ptr(x_nhwc), ps, 1, B * H * W, C, _ptr(st[0]), _ptr(st[1]), _ptr(ws), wsn, _stream()),
                "oess_norm_stats_nhwc_bf16")
     return st[0]
 

@@ -70,6 +70,58 @@ def test_e2vid_recurrent_latents(g, keys):
     assert torch.equal(latent2[8], latent[8])
 
 
+@pytest.fixture(scope="module")
+def gpre():
+    return dict(np.load(os.path.join(GOLDEN, "e2vid_pre.npz")))
+
+
+@pytest.mark.parametrize("case", ["sparse", "dense", "zeros", "single"])
+def test_event_preprocessor_matches_reference_golden(gpre, case):
+    """EventPreprocessor.__call__ on the HIP kernels vs the REFERENCE's own output
+    (e2vid/utils/inference_utils.py:70-87, tests/golden/gen_golden_e2vid_pre.py): fp32 formula in the reference's operation
+    order; statistics are double sums here vs torch's float32 tree sums there -> 2e-6 relative; the all-zero tensor passes
+    through untouched and the single-non-zero tensor is NaN everywhere exactly like the reference (unguarded 0/0)."""
+    from openess_amd.e2vid.utils.inference_utils import EventPreprocessor
+    x = torch.from_numpy(gpre[f"pre_in_{case}"]).cuda()
+    got = EventPreprocessor()(x).cpu().numpy()
+    want = gpre[f"pre_out_{case}"]
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_allclose(np.nan_to_num(got), np.nan_to_num(want), rtol=2e-5, atol=2e-6)
+    # the fused slice form feeds the encoder the same values (bf16, padded to 8 channels)
+    from openess_amd import hip
+    y = hip.event_slice_to_nhwc8(x.contiguous(), 0, 5).float().cpu().numpy()
+    if case != "single":
+        np.testing.assert_allclose(y[:, :5], want, rtol=1e-2, atol=1e-2)
+        assert np.abs(y[:, 5:]).max() == 0
+
+
+def test_update_reconstruction_with_padding_matches_reference_golden(gpre, keys):
+    """three recurrent `ImageReconstructor.update_reconstruction` steps at 30x44 (CropParameters pads to
+    32x48 by reflection) vs the outputs of the reference's own ImageReconstructor (e2vid/image_reconstructor.py:80-123)."""
+    from openess_amd.e2vid.image_reconstructor import ImageReconstructor
+    from openess_amd.e2vid.model.model import E2VIDRecurrent
+    m = E2VIDRecurrent(E2VID_LIGHTWEIGHT_CONFIG).eval()
+    fill_by_name(m, 11)
+    m.cuda()
+    ev = torch.from_numpy(gpre["rec_events"]).cuda()
+    rec = ImageReconstructor(m, 30, 44, 5, torch.device("cuda"))
+    assert rec.crop.needs_pad
+    for i in range(3):
+        img, states, latent = rec.update_reconstruction(ev[:, 5 * i:5 * i + 5], reconstruct=True)
+    for k in (1, 2, 4, 8):
+        got = latent[k].float().cpu().numpy()
+        assert got.shape == gpre[f"rec_latent_{k}"].shape
+        assert relerr(got, gpre[f"rec_latent_{k}"]) < 3e-2, k
+    c2 = states[2]['cell'].permute(0, 3, 1, 2).float().cpu().numpy()          # deepest ConvLSTM cell state (fp32 NHWC here)
+    assert c2.shape == gpre["rec_state_c_2"].shape and relerr(c2, gpre["rec_state_c_2"]) < 3e-2
+    want = gpre["rec_img"]                                                     # the reference returns the padded 32x48 image
+    got = img.float().cpu().numpy()
+    if got.shape != want.shape:
+        cp = rec.crop
+        want = want[:, :, cp.iy0:cp.iy1, cp.ix0:cp.ix1]
+    assert got.shape == want.shape and np.abs(got - want).max() < 3e-2
+
+
 def test_e2vid_offline_reconstruction_image(g, keys):
     """the full UNetRecurrent forward (residual blocks, transposed-conv decoders on the dgrad kernels, pred + sigmoid)
     after 3 recurrent steps vs the reference's own image (golden) and the fp32 oracle."""

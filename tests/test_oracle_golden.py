@@ -1,5 +1,7 @@
 """Pin the oracle against golden vectors produced by the reference itself
 (tests/golden/gen_golden.py, run in the build container).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -160,3 +162,34 @@ def test_consistency_losses_golden():
         l1, lc = ol.consistency_losses(a, b, a, b)
         np.testing.assert_allclose(l1.numpy(), g[f"{tag}_l1"], rtol=1e-6)
         np.testing.assert_allclose(lc.numpy(), g[f"{tag}_cos"], rtol=1e-6, atol=1e-7)
+
+
+# ---- the reference's own EventPreprocessor / CropParameters (tests/golden/gen_golden_e2vid_pre.py)
+@pytest.fixture(scope="module")
+def golden_pre():
+    return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2vid_pre.npz")))
+
+
+@pytest.mark.parametrize("case", ["sparse", "dense", "zeros", "single"])
+def test_event_preprocessor_oracle_equals_reference(golden_pre, case):
+    """oracle.nets.event_preprocess against EventPreprocessor.__call__ (e2vid/utils/inference_utils.py:70-87) run from the
+    reference: bit-exact, including the unguarded 0/0 = NaN of a tensor with a single non-zero value and the untouched
+    all-zero tensor (`if num_nonzeros > 0`)."""
+    import torch
+    from oracle import nets as on
+    got = on.event_preprocess(torch.from_numpy(golden_pre[f"pre_in_{case}"].copy())).numpy()
+    np.testing.assert_array_equal(got, golden_pre[f"pre_out_{case}"])
+
+
+def test_crop_parameters_mirror_equals_reference(golden_pre):
+    """CropParameters (e2vid/utils/inference_utils.py:284-311): every derived attribute and the reflection pad."""
+    import torch
+    from openess_amd.e2vid.utils.inference_utils import CropParameters
+    attrs = ("width_crop_size", "height_crop_size", "padding_top", "padding_bottom", "padding_left", "padding_right", "cx", "cy",
+             "ix0", "ix1", "iy0", "iy1")
+    for (w, h, n), want in zip(golden_pre["crop_cases"].tolist(), golden_pre["crop_attrs"].tolist()):
+        cp = CropParameters(w, h, n)
+        assert [getattr(cp, a) for a in attrs] == want, (w, h, n)
+        assert cp.needs_pad == any(want[2:6])
+    cp = CropParameters(44, 30, 3)
+    np.testing.assert_array_equal(cp.pad(torch.from_numpy(golden_pre["pad_in"])).numpy(), golden_pre["pad_out"])
