@@ -9,6 +9,23 @@ def load_png(path):
     return np.array(Image.open(path))
 
 
+def load_png_gray(path):
+    """cv2.imread(path, 0) (IMREAD_GRAYSCALE): always one 8-bit channel (datasets/ddd17_events_loader.py:131,
+    DSEC/dataset/sequence_ov.py:230 read the GROUND-TRUTH label this way).  8-bit gray files -- what both datasets ship --
+    pass through untouched; 16-bit gray is scaled >> 8; palette / colour files are expanded and reduced with OpenCV's
+    fixed-point BGR2GRAY rule Y = (4899 R + 9617 G + 1868 B + 8192) >> 14 (restated: cv2 is absent, unpinned for those modes)."""
+    from PIL import Image
+    im = Image.open(path)
+    if im.mode == 'L':
+        return np.array(im)
+    if im.mode in ('I;16', 'I;16B', 'I'):
+        return (np.array(im).astype(np.uint32) >> 8).astype(np.uint8)
+    if im.mode == '1':
+        return np.array(im.convert('L'))
+    rgb = np.array(im.convert('RGB')).astype(np.uint32)
+    return ((4899 * rgb[..., 0] + 9617 * rgb[..., 1] + 1868 * rgb[..., 2] + 8192) >> 14).astype(np.uint8)
+
+
 def image_to_chw_float(path):
     """`np.array(Image.open(p))` -> `[frame / 255]` -> float32 CHW (DSEC/dataset/sequence_ov.py:324-328,
     datasets/ddd17_events_loader.py:214-217): float64 division, then one rounding to float32."""

@@ -119,7 +119,7 @@ class DDD17Events(Dataset):
 
     def __getitem__(self, idx):
         file_path = self.files[idx]
-        label_tensor = torch.from_numpy(np.array(self._resize_label(_io.load_png(file_path)))).long()
+        label_tensor = torch.from_numpy(np.array(self._resize_label(_io.load_png_gray(file_path)))).long()
         events = None
         if self.config_option in ('recon2voxel', 'frame2voxel'):
             directory = dirname(dirname(file_path))

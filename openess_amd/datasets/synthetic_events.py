@@ -51,7 +51,8 @@ class SyntheticEvents(Dataset):
 
 
 def collate(samples):
-    """Batch the reference-shaped tuples (6 items for DDD17, 7 for DSEC; the last one is the file path).  Raw-event dicts
+    """Batch the reference-shaped tuples (6 items for DDD17, 7 for DSEC; the last one is the file path) into ONE layout,
+    the 7-slot DSEC one with sam_feat = None for DDD17.  Raw-event dicts
     in slot 0 are concatenated into SoA columns with per-sub-window segment offsets (pinned by DataLoader(pin_memory=True))."""
     first = [s[0] for s in samples]
     if isinstance(first[0], dict) and 'events' in first[0]:                       # DDD17: int64 [N,4] rows per sample
@@ -72,5 +73,9 @@ def collate(samples):
     else:
         batch0 = torch.stack(first)
     n = len(samples[0])
+    if n not in (6, 7):
+        raise ValueError(f"dataset tuples have 6 (DDD17) or 7 (DSEC) items, got {n}")
     rest = [torch.stack([s[i] for s in samples]) for i in range(1, n - 1)]
+    if n == 6:                     # DDD17 has no sam_feat (ddd17_events_loader.py:290): the batch ALWAYS carries the 7-slot layout
+        rest = rest[:4] + [None]   # (first, label, frame | recon, pl, superpixel, sam_feat | None, file_paths); nothing downstream guesses
     return (batch0, *rest, [s[n - 1] for s in samples])

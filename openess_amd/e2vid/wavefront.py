@@ -31,15 +31,27 @@ class EncoderWavefront:
         self.conv_done = [[] for _ in range(n)]          # per level: event after the encoder conv of sub-window t
         self.begin_called = True
 
-    def end(self):
-        """The current stream continues after all levels have finished their last sub-window."""
+    def end(self, *consumed_on_main):
+        """The current stream continues after all levels have finished their last sub-window.  `consumed_on_main`: tensors that
+        were ALLOCATED on a level stream (latents are views of the ConvLSTM cat(x, h) buffers, the head output) and are read by
+        kernels of the current stream from here on: the caching allocator is told so (record_stream), otherwise a block freed
+        by the caller could be handed out again on the level stream while those kernels still read it."""
         main = torch.cuda.current_stream(self.device)
         for s in self.streams:
             main.wait_stream(s)
+        for t in consumed_on_main:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(main)
         self.begin_called = False
+
+    def _check(self):
+        if not self.begin_called:
+            raise RuntimeError("EncoderWavefront: begin() must bracket the recurrent loop (the level streams are not ordered "
+                               "after the current stream otherwise)")
 
     # ---- used by UNetRecurrent.forward
     def before_conv(self, level):
+        self._check()
         if level > 0:
             self.streams[level].wait_event(self.lstm_done[level - 1][-1])       # h_{l-1}(t) is this conv's input
 
@@ -49,6 +61,7 @@ class EncoderWavefront:
         self.conv_done[level].append(e)
 
     def before_lstm(self, level):
+        self._check()
         t = len(self.conv_done[level]) - 1
         nxt = level + 1
         if nxt < len(self.streams) and t >= 2 and len(self.conv_done[nxt]) > t - 2:

@@ -29,6 +29,15 @@ class BaseTrainer(object):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.do_val_training_epoch = True
+        # Precision contract (INTEGRATION.md "Precision"): the reference's `use_amp` switches torch.autocast(fp16) + GradScaler
+        # (pretrain_trainer.py:344-353).  This build has ONE numeric mode whatever the flag says: bf16 storage of activations /
+        # activation gradients / MFMA weight operands, fp32 accumulation, fp32 master weights, optimiser state and losses; no
+        # loss scaling is needed (bf16 has fp32's exponent range).  Say so once instead of silently ignoring the key.
+        msg = ("numeric mode: bf16 storage / fp32 accumulate (MFMA), fp32 master weights and losses; YAML use_amp={} is accepted "
+               "and has no effect (no fp32-activation or fp16-autocast mode in this build)".format(getattr(settings, 'use_amp', False)))
+        settings.logger.info(msg)
+        if self.rank_hint() == 0:
+            print(msg)
         self.metrics_semseg_b = MetricsSemseg(settings.semseg_num_classes, settings.semseg_ignore_label,
                                               settings.semseg_class_names)
         self.init_fn()
@@ -53,6 +62,10 @@ class BaseTrainer(object):
         total_steps = settings.num_epochs * len(self.train_loader_sensor_b)
         self.lr_schedulers = {k: torch.optim.lr_scheduler.CosineAnnealingLR(v, T_max=max(total_steps, 1))
                               for k, v in self.optimizers_dict.items()}
+
+    @staticmethod
+    def rank_hint():
+        return dist.get_rank() if dist.is_initialized() else 0
 
     # ------------------------------------------------------------------ hooks for subclasses
     def init_fn(self):
@@ -128,9 +141,9 @@ class BaseTrainer(object):
         via ONE batched launch sequence of the HIP voxelizer (rectification, time normalisation, crop fused)."""
         s = self.settings
         first = sample_batched[0]
+        if len(sample_batched) != 7:            # datasets.synthetic_events.collate emits the 7-slot layout for every dataset
+            raise ValueError(f"prepare_batch expects collate's 7-slot batch, got {len(sample_batched)} items")
         rest = [t.to(self.device, non_blocking=True) if torch.is_tensor(t) else t for t in sample_batched[1:]]
-        if len(rest) == 5:                      # DDD17's 6-tuple has no sam_feat (ddd17_events_loader.py:290): keep slot 5 = None
-            rest = rest[:4] + [None] + rest[4:]
         ds = self._voxel_ds[split]
         if isinstance(first, dict) and 'events_list' in first:            # DDD17: int64 [N,4] rows per sample
             first = ds.voxelize_batch(first['events_list'], self.device, flips=first.get('flip'))

@@ -122,7 +122,7 @@ class PretrainStep:
                 _, _, latent_real = self.reconstructor.update_reconstruction(
                     event, channel_slice=(i * self.bins, self.bins), wavefront=wf)
             if wf is not None:
-                wf.end()
+                wf.end(*latent_real.values())
             content = {k: v.detach() for k, v in latent_real.items()}          # trainTaskStepPretrain (:550-562)
             pred, feat_voxel = self.task_backend(content)
             loss_dense = self.task_loss(pred[1], pl) * self.weight_task_loss
