@@ -204,7 +204,14 @@ int oess_conv2d_pack_weight(const float* w_oihw, int Cout, int Cin, int R, int S
 int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int Cin, const void* w_packed,
                          const float* bias, int Cout, int R, int S, int stride, int pad, int dil, int relu,
                          const void* residual, long long res_pix_stride, void* out_bf16, float* out_f32,
-                         long long out_pix_stride, float* tile_stats, oess_stream_t stream);
+                         long long out_pix_stride, float* tile_stats, void* workspace, size_t workspace_bytes,
+                         oess_stream_t stream);
+/* workspace (nullable): oess_conv2d_fwd_workspace_bytes(...) bytes of scratch for the split-K form that small-M / long-K layers
+ * take (ASPP dilated 3x3 at output stride 16, models/deeplabv3.py:295-348: 140 workgroups x 288 K-slabs otherwise); the query
+ * returns 0 for layers that run in one pass.  Without a workspace every layer runs in one pass (same result up to the
+ * summation order of the fp32 accumulators). */
+size_t oess_conv2d_fwd_workspace_bytes(int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil,
+                                       int with_tile_stats, int out_is_f32);
 /* tile_stats (nullable): [ceil(M/128)][2][Cout] fp32, per-128-row-tile column sums and sums of squares of the fp32
  * result (BatchNorm batch statistics straight from the accumulators; bias-free, no activation/residual).
  * oess_norm_reduce_finalize_tile_stats turns them into mean / rstd / scale / shift. */
@@ -217,6 +224,15 @@ int oess_norm_reduce_finalize_tile_stats(const float* tile_stats, int tiles, int
                                          unsigned int* counters, float count, float eps, const float* gamma, const float* beta,
                                          float* running_mean, float* running_var, float momentum, float* mean, float* rstd,
                                          float* scale, float* shift, oess_stream_t stream);
+
+/* Small maps (tiles <= 512, C % 64 == 0): the reduce / finalize above AND oess_norm_apply_nhwc_bf16 in one launch, no
+ * cross-workgroup protocol: every workgroup re-reduces the tile partials of its 64 channels (fixed order, double) and
+ * applies out = act(x * scale + shift [+ residual]) to its pixel chunk; x may alias out.  mean / rstd nullable. */
+int oess_norm_tile_stats_apply_nhwc_bf16(const float* tile_stats, int tiles, int C, float count, float eps, const float* gamma,
+                                         const float* beta, float* running_mean, float* running_var, float momentum, float* mean,
+                                         float* rstd, const void* x, long long x_pix_stride, const void* residual,
+                                         long long res_pix_stride, int relu, long long pixels, void* out, long long out_pix_stride,
+                                         oess_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * ConvLSTM gate fusion.  Replaces the chunk/sigmoid/tanh/mul/add tail of ConvLSTM.forward

@@ -81,7 +81,10 @@ SIGNATURES = {
     "oess_conv2d_packed_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     "oess_conv2d_pack_weight": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
     "oess_conv2d_fwd_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,
-                                     c_int, c_int, c_int, c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp]),
+                                     c_int, c_int, c_int, c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp, c_sz, c_vp]),
+    "oess_conv2d_fwd_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "oess_norm_tile_stats_apply_nhwc_bf16": (c_int, [c_vp, c_int, c_int, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_ll,
+                                                     c_vp, c_ll, c_int, c_ll, c_vp, c_ll, c_vp]),
     "oess_norm_reduce_finalize_tile_stats": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_f,
                                                      c_vp, c_vp, c_vp, c_vp, c_vp]),
 }

@@ -60,6 +60,11 @@ struct ConvArgs {
     long long lstm_h_stride;
     int lstm_C;
     unsigned inv_cpt, inv_s;   // exact small-range reciprocals: kc / cpt == (kc * inv_cpt) >> 20, tap / S == (tap * inv_s) >> 16
+    // split-K (small-M, long-K layers: DeepLab's ASPP at output stride 16): grid.y = ksplit, workgroup (tile, z) reduces
+    // K-slabs [z * kt_per, (z + 1) * kt_per) and writes its fp32 accumulators to partial[z][M][Cout]; splitk_reduce_kernel
+    // adds the slices in a fixed order and does what the epilogue would have done (bias / residual / activation / tile stats)
+    float* partial;
+    int ksplit, kt_per;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
@@ -510,7 +515,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_dma_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int KT = a.Kpad / BK;
+    // K-slab range of this workgroup: everything, or slice blockIdx.y of a split-K launch
+    const int kbeg = (EPI == 0 && a.partial) ? (int)blockIdx.y * a.kt_per : 0;
+    const int KT = (EPI == 0 && a.partial) ? ((kbeg + a.kt_per < a.Kpad / BK) ? kbeg + a.kt_per : a.Kpad / BK) : a.Kpad / BK;
     const int cpt = a.Cin >> 3, ntaps = a.R * a.S;
 
     // buffer descriptors (wave-uniform kernel arguments only)
@@ -609,7 +616,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_dma_kernel(ConvArgs a) {
 
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s < KT) issue(s);
+        if (kbeg + s < KT) issue(kbeg + s);
     constexpr bool LSTM_PREF = (EPI == 1 && MT == 2 && NT == 2);
     LstmPrefetch pref;
     if constexpr (LSTM_PREF) lstm_prefetch(a, pref, m0, n0, tid);
@@ -645,7 +652,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_dma_kernel(ConvArgs a) {
             asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(FA_[0]), "+v"(FB_[0]) : "n"(N_) : "memory");             \
     }
 
-    for (int kt = 0; kt < KT; ++kt) {
+    for (int kt = kbeg; kt < KT; ++kt) {
         // retire slab kt: at most NSTAGE-2 younger slabs may stay in flight (fewer at the tail)
         if (kt + NSTAGE - 2 < KT) {
             if constexpr (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -686,7 +693,83 @@ __global__ __launch_bounds__(NTHREADS) void conv_fwd_dma_kernel(ConvArgs a) {
 
     if constexpr (LSTM_PREF) lstm_epilogue<MT, NT, true, false>(a, acc, smem, m0, n0, wm, wn, lane, tid, &pref);
     else if constexpr (EPI == 1) lstm_epilogue<MT, NT, false, false>(a, acc, smem, m0, n0, wm, wn, lane, tid);
-    else conv_epilogue<BMX, BN, BN + 8, NTHREADS, WAVES_N>(a, acc, smem, m0, n0, wm, wn, lane, tid);
+    else {
+        if (a.partial) {        // split-K slice: raw fp32 accumulators, 128-byte row segments per half wave
+            float* dst = a.partial + (size_t)blockIdx.y * (size_t)a.M * a.Cout;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int n = n0 + wn * WN + j * 32 + (lane & 31);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        if (m < a.M && n < a.Cout) dst[(size_t)m * a.Cout + n] = acc[i][j][e];
+                    }
+                }
+            return;
+        }
+        conv_epilogue<BMX, BN, BN + 8, NTHREADS, WAVES_N>(a, acc, smem, m0, n0, wm, wn, lane, tid);
+    }
+}
+
+// Split-K tail: out[m][n] = act(sum_z partial[z][m][n] + bias[n] [+ residual]) as bf16 NHWC, slices added in z order
+// (deterministic), plus the per-128-row-tile column sums / sums of squares of the fp32 result that the conv epilogue
+// provides for BatchNorm (same [tiles_m][2][Cout] layout).  grid = (tiles_m, ceil(Cout / 64)); thread = (row lane, 4 columns).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a) {
+    __shared__ float red[16][64][2];
+    const int tile = blockIdx.x, n = blockIdx.y * 64 + (threadIdx.x & 15) * 4, rl = threadIdx.x >> 4;
+    const size_t MN = (size_t)a.M * a.Cout;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool n_ok = n < a.Cout;               // Cout % 4 == 0 (host-checked): a float4 is inside the row or not at all
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias && n_ok) { bv[0] = a.bias[n]; bv[1] = a.bias[n + 1]; bv[2] = a.bias[n + 2]; bv[3] = a.bias[n + 3]; }
+    for (int r = rl; r < 128; r += 16) {
+        const int m = tile * 128 + r;
+        if (m >= a.M || !n_ok) continue;
+        const float* p = a.partial + (size_t)m * a.Cout + n;
+        float4 v = *reinterpret_cast<const float4*>(p);
+        for (int z = 1; z < a.ksplit; ++z) {
+            const float4 w = *reinterpret_cast<const float4*>(p + (size_t)z * MN);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        float f[4] = {v.x + bv[0], v.y + bv[1], v.z + bv[2], v.w + bv[3]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s1[k] += f[k]; s2[k] += f[k] * f[k]; }
+        if (a.out_f32) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) f[k] = conv_act(f[k], a.relu);
+            *reinterpret_cast<float4*>(a.out_f32 + (long long)m * a.out_pix_stride + n) = make_float4(f[0], f[1], f[2], f[3]);
+            continue;
+        }
+        if (a.residual || a.relu) {
+            // the one-pass epilogue rounds the conv result to bf16 BEFORE the residual add: keep that rounding point
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float t = bf16_to_f32(f32_to_bf16(f[k]));
+                if (a.residual) t += bf16_to_f32(a.residual[(long long)m * a.res_pix_stride + n + k]);
+                f[k] = conv_act(t, a.relu);
+            }
+        }
+        uint2 o;
+        o.x = pack_bf16x2(f[0], f[1]);
+        o.y = pack_bf16x2(f[2], f[3]);
+        *reinterpret_cast<uint2*>(a.out + (long long)m * a.out_pix_stride + n) = o;
+    }
+    if (!a.stats) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[rl][(threadIdx.x & 15) * 4 + k][0] = s1[k]; red[rl][(threadIdx.x & 15) * 4 + k][1] = s2[k]; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int nn = blockIdx.y * 64 + threadIdx.x;
+        if (nn < a.Cout) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { t1 += red[r][threadIdx.x][0]; t2 += red[r][threadIdx.x][1]; }
+            a.stats[((size_t)tile * 2 + 0) * a.Cout + nn] = t1;
+            a.stats[((size_t)tile * 2 + 1) * a.Cout + nn] = t2;
+        }
+    }
 }
 
 // =================================================================================================
@@ -1288,7 +1371,9 @@ struct LstmOut { const float* prev; float* cell; void* h; long long h_stride; in
 int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, int Cin, const void* w_packed,
                   const float* bias, int Cout, int R, int S, int stride, int pad, int dil, int relu,
                   const void* residual, long long res_pix_stride, void* out_bf16, float* out_f32,
-                  long long out_pix_stride, float* tile_stats, const LstmOut* lstm, oess_stream_t stream) {
+                  long long out_pix_stride, float* tile_stats, const LstmOut* lstm, oess_stream_t stream,
+                  void* workspace = nullptr, size_t workspace_bytes = 0, size_t* want_workspace = nullptr) {
+    if (want_workspace) *want_workspace = 0;
     if (lstm) {
         if (!lstm->cell || !lstm->h || lstm->C <= 0 || (lstm->C & 31) || Cout != 4 * lstm->C || (lstm->h_stride & 1) ||
             lstm->h_stride < lstm->C || residual || relu || tile_stats || out_f32 || stride != 1)
@@ -1322,6 +1407,7 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
     a.lstm_prev = lstm ? lstm->prev : nullptr; a.lstm_cell = lstm ? lstm->cell : nullptr;
     a.lstm_h = lstm ? (uint16_t*)lstm->h : nullptr; a.lstm_h_stride = lstm ? lstm->h_stride : 0; a.lstm_C = lstm ? lstm->C : 0;
     a.tiles_m = (a.M + BM - 1) / BM;
+    a.partial = nullptr; a.ksplit = 1; a.kt_per = 0;
     hipStream_t st = (hipStream_t)stream;
     static bool attrs_set = false;
     if (!attrs_set) {       // > 64 KiB of dynamic LDS needs an explicit opt-in
@@ -1367,12 +1453,14 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
     // (1) Cin == 8 stencil layers (E2VID head): LDS halo tile instead of the im2col gather
     if (!lstm && Cin == 8 && stride == 1 && dil == 1 && R == 5 && S == 5 && Cout <= 32 && (Cout & 3) == 0 && !residual && !out_f32 &&
         !tile_stats && (out_pix_stride & 3) == 0 && a.Kpad == 256 && dma_ok) {
+        if (want_workspace) return OESS_OK;
         const int tiles = B * ((a.Ho + 7) / 8) * ((a.Wo + 63) / 64);
         hipLaunchKernelGGL((conv_smallcin_kernel<5, 5>), dim3(tiles < 512 ? tiles : 512), dim3(256), 0, st, a);   // persistent: 2 workgroups per CU
         OESS_HIP(hipGetLastError());
         return OESS_OK;
     }
     if (!dma_ok) {
+        if (want_workspace) return OESS_OK;
         if (lstm) return OESS_EINVAL;       // the fused ConvLSTM epilogue exists only in the LDS-DMA kernels
         const size_t tab = (size_t)(a.Kpad / 8) * 8;
         size_t lds = (size_t)2 * (BM + bn) * 8 * 16 + tab;
@@ -1387,6 +1475,7 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
     //     is what the layer wants (tile quantisation of small maps)
     if (R == 3 && S == 3 && stride == 1 && pad == dil && fastk && bn == 128 && a.Kpad == 9 * Cin && a.Ho == H && a.Wo == W &&
         (dil + 127 + dil * ((BM + W - 2) / W) + dil + 1) <= HALO_ROWS && !want64) {
+        if (want_workspace) return OESS_OK;
         const size_t lds = (size_t)2 * HALO_ROWS * 128 + (size_t)2 * 128 * 128;
         if (lstm) hipLaunchKernelGGL((conv3x3_halo_kernel<1>), grid, block, lds, st, a);
         else hipLaunchKernelGGL((conv3x3_halo_kernel<0>), grid, block, lds, st, a);
@@ -1401,6 +1490,39 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
         OESS_HIP(hipGetLastError());
         return OESS_OK;
     }
+    // (3a) split-K for small-M / long-K layers (DeepLabv3's ASPP at output stride 16: M = 8 960 = 70 row tiles x 2 column
+    //      tiles = 140 workgroups for 512 slots, K = 18 432 = 288 slabs each: 272 us at 311 TFLOP/s).  Model (us): a workgroup
+    //      spends 1.1 per slab + 6 fixed; the fp32 slices cost a write and a read of ks * M * Cout * 4 bytes at ~3 TB/s plus
+    //      one launch.  Taken when it beats both the one-pass 128-row tiling and the 64-row tiling by 15 %.
+    if (!lstm && bn == 128 && (Cout & 3) == 0 && a.Kpad / BK >= 32 && t128 <= 384 && (!out_f32 || (out_pix_stride & 3) == 0)) {
+        const int KTall = a.Kpad / BK;
+        auto rounds = [](long long wg, long long slots) { return (double)((wg + slots - 1) / slots); };
+        const double t_one = rounds(t128, 512) * (KTall * 1.1 + 6.0);
+        const double t_64 = rounds(t64, 768) * (KTall * 0.62 + 6.0);
+        int best = 1;
+        double tbest = (tile_stats ? t_one : (t_one < t_64 ? t_one : t_64)) / 1.15;
+        for (int ks = 2; ks <= 8; ++ks) {
+            const int per = (KTall + ks - 1) / ks;
+            if (per < 8 || (long long)per * (ks - 1) >= KTall) continue;       // every slice non-empty
+            const double tk = rounds(t128 * ks, 512) * (per * 1.1 + 6.0) + 2.0 * ks * (double)a.M * Cout * 4.0 / 3.0e6 + 5.0;
+            if (tk < tbest) { tbest = tk; best = ks; }
+        }
+        if (best > 1) {
+            const size_t need = (size_t)best * (size_t)a.M * Cout * sizeof(float);
+            if (want_workspace) { *want_workspace = need; return OESS_OK; }
+            if (workspace && workspace_bytes >= need) {
+                a.partial = (float*)workspace; a.ksplit = best; a.kt_per = (KTall + best - 1) / best;
+                const size_t lds = (size_t)2 * (BM + 128) * 8 * 16;
+                const dim3 gridk(a.tiles_m * a.tiles_n, best);
+                if (fastk) hipLaunchKernelGGL((conv_fwd_dma_kernel<128, 128, 2, true>), gridk, block, lds, st, a);
+                else hipLaunchKernelGGL((conv_fwd_dma_kernel<128, 128, 2, false>), gridk, block, lds, st, a);
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(a.tiles_m, (Cout + 63) / 64), dim3(256), 0, st, a);
+                OESS_HIP(hipGetLastError());
+                return OESS_OK;
+            }
+        }
+    }
+    if (want_workspace) return OESS_OK;
     // (3b) large plain-GEMM layers (1x1, Cin % 64 == 0, Cout % 256 == 0, K >= 256): 256 x 256 tiles on ONE 8-wave workgroup per
     //      CU, wave tile 64 x 128 (24 fragment reads per 32 MFMAs instead of 16 per 16, half the L2 -> LDS bytes per FLOP).
     //      Same template as rule (6).  Measured against the 128 x 128 tiling on the teacher's layers at M = 140 800:
@@ -1463,9 +1585,21 @@ extern "C" {
 int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int Cin, const void* w_packed,
                          const float* bias, int Cout, int R, int S, int stride, int pad, int dil, int relu,
                          const void* residual, long long res_pix_stride, void* out_bf16, float* out_f32,
-                         long long out_pix_stride, float* tile_stats, oess_stream_t stream) {
+                         long long out_pix_stride, float* tile_stats, void* workspace, size_t workspace_bytes,
+                         oess_stream_t stream) {
     return conv_fwd_impl(in, in_pix_stride, B, H, W, Cin, w_packed, bias, Cout, R, S, stride, pad, dil, relu, residual,
-                         res_pix_stride, out_bf16, out_f32, out_pix_stride, tile_stats, nullptr, stream);
+                         res_pix_stride, out_bf16, out_f32, out_pix_stride, tile_stats, nullptr, stream, workspace, workspace_bytes);
+}
+
+size_t oess_conv2d_fwd_workspace_bytes(int B, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int dil,
+                                       int with_tile_stats, int out_is_f32) {
+    // runs the dispatch rules of oess_conv2d_fwd_bf16 on dummy (never dereferenced) pointers up to the split-K decision
+    size_t need = 0;
+    static const char dummy[16] = {0};
+    const int rc = conv_fwd_impl(dummy, Cin, B, H, W, Cin, dummy, nullptr, Cout, R, S, stride, pad, dil, 0, nullptr, 0,
+                                 out_is_f32 ? nullptr : (void*)dummy, out_is_f32 ? (float*)dummy : nullptr, (Cout + 7) / 8 * 8,
+                                 with_tile_stats ? (float*)dummy : nullptr, nullptr, nullptr, nullptr, 0, &need);
+    return rc == OESS_OK ? need : 0;
 }
 
 int oess_convlstm_fused_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int Cin, const void* w_packed_gates,

@@ -30,6 +30,9 @@ def to_cl_bf16(x, pad_to=8):
         return x
     if Cp == C:
         return x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    if Cp == 8 and pad_to == 8 and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and not x.requires_grad:
+        # images / event slices (C <= 8, NCHW fp32): ONE kernel for the NCHW -> NHWC8 re-layout + bf16 + zero padding
+        return hip.event_slice_to_nhwc8(x, 0, C, normalize=False)
     out = torch.zeros((B, H, W, Cp), dtype=torch.bfloat16, device=x.device)
     out[..., :C] = x.permute(0, 2, 3, 1)
     return from_nhwc(out)

@@ -428,6 +428,9 @@ def _nhwc_geom(x):
     return B, H, W, C, ps
 
 
+_CONV_WS_NEED = {}
+
+
 def conv_packed_bytes(Cout, Cin, R, S, flip=False):
     return _lib.load().oess_conv2d_packed_bytes(Cout, Cin, R, S, int(flip))
 
@@ -448,9 +451,10 @@ def pack_conv_weight(w, flip=False):
 
 
 def conv2d_nhwc(x, packed, bias, Cout, R, S, stride=1, pad=0, dil=1, relu=False, residual=None, out=None,
-                out_f32=False, tile_stats=None):
+                out_f32=False, tile_stats=None, allow_splitk=True):
     """out = act(conv(x, w) + bias [+ residual]) on NHWC bf16 views (channel slices of wider buffers are fine).
-    x's channel count must be a multiple of 8 (zero-padded channels; packed weights are zero there)."""
+    x's channel count must be a multiple of 8 (zero-padded channels; packed weights are zero there).
+    allow_splitk=False withholds the scratch of the split-K form (small-M / long-K layers): one pass, for A/B tests."""
     lib = _lib.load()
     _need_gpu(x, packed)
     B, H, W, Cin, ps_in = _nhwc_geom(x)
@@ -472,9 +476,17 @@ def conv2d_nhwc(x, packed, bias, Cout, R, S, stride=1, pad=0, dil=1, relu=False,
         _, _, _, _, ps_res = _nhwc_geom(residual)
     if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
         bias = bias.float().contiguous()
+    ws, wsn = None, 0
+    key = (B, H, W, Cin, Cout, R, S, stride, pad, dil, tile_stats is not None, o_f32 is not None)
+    need = _CONV_WS_NEED.get(key)
+    if need is None:       # host-only query of the dispatch rules (split-K layers want fp32 slice scratch), cached per geometry
+        need = _CONV_WS_NEED[key] = lib.oess_conv2d_fwd_workspace_bytes(*key[:10], int(key[10]), int(key[11]))
+    if need and allow_splitk:
+        ws = _workspace(need, x.device, tag=("conv_splitk", torch.cuda.current_stream(x.device).cuda_stream))
+        wsn = ws.numel()
     _lib.check(lib.oess_conv2d_fwd_bf16(_ptr(x), ps_in, B, H, W, Cin, _ptr(packed), _ptr(bias), Cout, R, S, stride, pad,
                                         dil, int(relu), _ptr(residual), ps_res, o_bf16, o_f32, ps_out, _ptr(tile_stats),
-                                        _stream()),
+                                        _ptr(ws), wsn, _stream()),
                "oess_conv2d_fwd_bf16")
     return out
 
@@ -564,13 +576,13 @@ _conv2d_nhwc_raw = conv2d_nhwc
 
 
 def conv2d_nhwc(x, packed, bias, Cout, R, S, stride=1, pad=0, dil=1, relu=False, residual=None, out=None,
-                out_f32=False, tile_stats=None):
+                out_f32=False, tile_stats=None, allow_splitk=True):
     t = _CONV_TIMING
     if t is None or Cout <= 64:
-        return _conv2d_nhwc_raw(x, packed, bias, Cout, R, S, stride, pad, dil, relu, residual, out, out_f32, tile_stats)
+        return _conv2d_nhwc_raw(x, packed, bias, Cout, R, S, stride, pad, dil, relu, residual, out, out_f32, tile_stats, allow_splitk)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    y = _conv2d_nhwc_raw(x, packed, bias, Cout, R, S, stride, pad, dil, relu, residual, out, out_f32, tile_stats)
+    y = _conv2d_nhwc_raw(x, packed, bias, Cout, R, S, stride, pad, dil, relu, residual, out, out_f32, tile_stats, allow_splitk)
     e1.record()
     fl = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * Cout * x.shape[3] * R * S
     t["events"].append((e0, e1))
@@ -962,9 +974,10 @@ def channel_sum(x_nhwc):
     return st[0]
 
 
-def conv_bn_train_nhwc(x, packed, Cout, R, S, stride, pad, dil, bn, relu=False, residual=None):
+def conv_bn_train_nhwc(x, packed, Cout, R, S, stride, pad, dil, bn, relu=False, residual=None, out=None):
     """Bias-free conv + nn.BatchNorm2d in TRAIN mode [+ residual] [+ ReLU], inference form (frozen teacher): the batch
-    statistics come from the conv epilogue's fp32 accumulators (no separate statistics pass over the activation)."""
+    statistics come from the conv epilogue's fp32 accumulators (no separate statistics pass over the activation).
+    `out`: optional NHWC bf16 destination view (e.g. a channel slice of a concat buffer)."""
     lib = _lib.load()
     B, H, W, _, _ = _nhwc_geom(x)
     Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
@@ -972,19 +985,28 @@ def conv_bn_train_nhwc(x, packed, Cout, R, S, stride, pad, dil, bn, relu=False, 
     M = B * Ho * Wo
     tiles = (M + 127) // 128
     part = torch.empty((tiles, 2, Cout), dtype=torch.float32, device=x.device)
-    y = conv2d_nhwc(x, packed, None, Cout, R, S, stride, pad, dil, tile_stats=part)
+    y = conv2d_nhwc(x, packed, None, Cout, R, S, stride, pad, dil, tile_stats=part, out=out)
+    _, _, _, _, yps = _nhwc_geom(y)
+    mom = 0.0 if bn.momentum is None else bn.momentum
+    rps = 0
+    if residual is not None:
+        _, _, _, _, rps = _nhwc_geom(residual)
+    from . import engine as _engine
+    if tiles <= 320 and Cout % 64 == 0:
+        # small map: statistics + apply in ONE launch (every workgroup reduces the partials of its 64 channels itself)
+        _lib.check(lib.oess_norm_tile_stats_apply_nhwc_bf16(_ptr(part), tiles, Cout, float(M), float(bn.eps), _ptr(bn.weight.detach()),
+                                                            _ptr(bn.bias.detach()), _ptr(bn.running_mean), _ptr(bn.running_var),
+                                                            float(mom), None, None, _ptr(y), yps, _ptr(residual), rps, int(relu), M,
+                                                            _ptr(y), yps, _stream()), "oess_norm_tile_stats_apply_nhwc_bf16")
+        _engine.bump_bn_counter(bn)
+        return y
     st = torch.empty((6, 1, Cout), dtype=torch.float32, device=x.device)
     sc = _stats_scratch(Cout, x.device)
-    mom = 0.0 if bn.momentum is None else bn.momentum
     _lib.check(lib.oess_norm_reduce_finalize_tile_stats(_ptr(part), tiles, Cout, _ptr(sc.buf64), _ptr(sc.tickets),
                                                         float(M), float(bn.eps), _ptr(bn.weight.detach()), _ptr(bn.bias.detach()),
                                                         _ptr(bn.running_mean), _ptr(bn.running_var), float(mom), _ptr(st[2]), _ptr(st[3]),
                                                         _ptr(st[4]), _ptr(st[5]), _stream()), "oess_norm_reduce_finalize_tile_stats")
-    rps = 0
-    if residual is not None:
-        _, _, _, _, rps = _nhwc_geom(residual)
-    _lib.check(lib.oess_norm_apply_nhwc_bf16(_ptr(y), Cout, _ptr(st[4]), _ptr(st[5]), _ptr(residual), rps, int(relu), 1, M, Cout,
-                                             _ptr(y), Cout, _stream()), "oess_norm_apply_nhwc_bf16")
-    from . import engine as _engine
+    _lib.check(lib.oess_norm_apply_nhwc_bf16(_ptr(y), yps, _ptr(st[4]), _ptr(st[5]), _ptr(residual), rps, int(relu), 1, M, Cout,
+                                             _ptr(y), yps, _stream()), "oess_norm_apply_nhwc_bf16")
     _engine.bump_bn_counter(bn)
     return y

@@ -28,14 +28,18 @@ class HipConv2d(nn.Conv2d):
         return engine.conv2d_infer(x, pw, self.out_channels, k, s, p, d)
 
 
-def conv_bn(conv, bn, x, relu=False, residual=None):
+def conv_bn(conv, bn, x, relu=False, residual=None, out=None):
     """conv -> BatchNorm2d [-> + residual] [-> ReLU] with nn.BatchNorm2d semantics for both bn.training states.
     No autograd needed (frozen teacher, validation): train-mode BN takes its batch statistics from the conv
     epilogue (no statistics pass); eval-mode BN is folded into the packed weights and the whole tail is the
     conv epilogue.  With autograd: MFMA conv + library BatchNorm."""
     needs_grad = torch.is_grad_enabled() and (conv.weight.requires_grad or x.requires_grad or bn.weight.requires_grad)
     if needs_grad or conv.bias is not None:
-        return engine.batch_norm_act(conv(x), bn, relu=relu, residual=residual)
+        y = engine.batch_norm_act(conv(x), bn, relu=relu, residual=residual)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
     if x.shape[1] % 8 or x.dtype != torch.bfloat16:
         x = engine.to_cl_bf16(x)
     elif x.stride(1) != 1:
@@ -46,10 +50,11 @@ def conv_bn(conv, bn, x, relu=False, residual=None):
     if bn.training:
         pw = conv._pw.get(conv.weight, None, None, cin_pad=x.shape[1])
         y = hip.conv_bn_train_nhwc(engine.nhwc(x), pw.packed, conv.out_channels, k, k, s, p, d, bn, relu=relu,
-                                   residual=None if residual is None else engine.nhwc(residual))
+                                   residual=None if residual is None else engine.nhwc(residual),
+                                   out=None if out is None else engine.nhwc(out))
         return engine.from_nhwc(y)
     pw = conv._pw_folded.get(conv.weight, None, bn, cin_pad=x.shape[1])
-    return engine.conv2d_infer(x, pw, conv.out_channels, k, s, p, d, relu=relu, residual=residual)
+    return engine.conv2d_infer(x, pw, conv.out_channels, k, s, p, d, relu=relu, residual=residual, out=out)
 
 
 def conv3x3(in_planes, out_planes, stride=1, groups=1, dilation=1):

@@ -43,8 +43,8 @@ class IntermediateLayerGetter(nn.ModuleDict):
 
 
 class _ConvBNReLU(nn.Sequential):
-    def forward(self, x):
-        return conv_bn(self[0], self[1], x, relu=True)
+    def forward(self, x, out=None):
+        return conv_bn(self[0], self[1], x, relu=True, out=out)
 
 
 class ASPPConv(_ConvBNReLU):
@@ -58,12 +58,16 @@ class ASPPPooling(nn.Sequential):
         super().__init__(nn.AdaptiveAvgPool2d(1), nn.Conv2d(in_channels, out_channels, 1, bias=False),
                          nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True))
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         size = x.shape[-2:]
         y = x.float().mean(dim=(2, 3), keepdim=True)                       # AdaptiveAvgPool2d(1)
         y = torch.matmul(y.flatten(1), self[1].weight.flatten(1).t())[:, :, None, None]   # B x C x 1 x 1: a GEMV, not a conv
         y = F.relu(self[2](y))
-        return y.to(x.dtype).expand(-1, -1, size[0], size[1])              # bilinear from 1x1 == broadcast
+        y = y.to(x.dtype).expand(-1, -1, size[0], size[1])                 # bilinear from 1x1 == broadcast
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
 
 
 class ASPP(nn.Module):
@@ -80,7 +84,16 @@ class ASPP(nn.Module):
                                      nn.ReLU(inplace=True), nn.Dropout(0.1))
 
     def forward(self, x):
-        res = torch.cat([conv(x) for conv in self.convs], dim=1)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            res = torch.cat([conv(x) for conv in self.convs], dim=1)
+        else:
+            # no autograd: every branch writes its channel slice of ONE NHWC concat buffer (conv output, BatchNorm apply in
+            # place on the slice) -- no torch.cat pass over the 5 x 256 channels
+            B, _, H, W = x.shape
+            oc = self.convs[0][0].out_channels
+            res = engine.empty_cl(B, oc * len(self.convs), H, W, x.device)
+            for i, conv in enumerate(self.convs):
+                conv(x, out=res[:, i * oc:(i + 1) * oc])
         y = conv_bn(self.project[0], self.project[1], res, relu=True)
         return self.project[3](y)
 

@@ -163,6 +163,84 @@ def test_conv_256_tile_kernel_stats_residual_and_ragged_rows():
     np.testing.assert_allclose(y2.float().reshape(-1, Cout).cpu().numpy(), ref2.cpu().numpy(), rtol=1e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("dil", [6, 12, 18])
+def test_conv_splitk_aspp_full_size_equals_one_pass(dil):
+    """Split-K form of the small-M / long-K layers (DeepLabv3's ASPP at the BASELINE geometry: B = 8, 28 x 40 x 2048 -> 256,
+    3 x 3 dilated; M = 8 960, K = 18 432): fp32 K-slices + fixed-order reduce kernel against the one-pass kernel and the fp32
+    reference -- output, BatchNorm tile statistics, residual + ReLU tail, channel-slice destination, fp32 logits form."""
+    from openess_amd import _lib, hip
+    torch.manual_seed(20 + dil)
+    B, H, W, Cin, Cout = 8, 28, 40, 2048, 256
+    assert _lib.load().oess_conv2d_fwd_workspace_bytes(B, H, W, Cin, Cout, 3, 3, 1, dil, dil, 1, 0) > 0      # the rule takes it
+    x = torch.randn(B, H, W, Cin, device="cuda").bfloat16()
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda") / np.sqrt(Cin * 9)
+    packed = hip.pack_conv_weight(w)
+    ref = ref_conv(x, w, None, 1, dil, dil).reshape(-1, Cout)
+    tiles = (B * H * W + 127) // 128
+    p1 = torch.full((tiles, 2, Cout), float("nan"), device="cuda")
+    p2 = torch.full((tiles, 2, Cout), float("nan"), device="cuda")
+    buf = torch.zeros(B, H, W, 5 * Cout, device="cuda", dtype=torch.bfloat16)          # ASPP concat buffer: branch 2's slice
+    y_split = hip.conv2d_nhwc(x, packed, None, Cout, 3, 3, 1, dil, dil, tile_stats=p1, out=buf[..., 2 * Cout:3 * Cout])
+    y_one = hip.conv2d_nhwc(x, packed, None, Cout, 3, 3, 1, dil, dil, tile_stats=p2, allow_splitk=False)
+    assert float(buf[..., :2 * Cout].abs().max()) == 0 and float(buf[..., 3 * Cout:].abs().max()) == 0
+    np.testing.assert_allclose(y_split.float().reshape(-1, Cout).cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=1e-2)
+    assert float((y_split.float() - y_one.float()).abs().max()) <= 2e-2          # same sums, different fp32 association
+    np.testing.assert_allclose(p1.cpu().numpy(), p2.cpu().numpy(), rtol=2e-3, atol=2e-2)
+    np.testing.assert_allclose(p1[:, 0].double().sum(0).cpu().numpy(), ref.double().sum(0).cpu().numpy(), rtol=2e-3, atol=1.0)
+    np.testing.assert_allclose(p1[:, 1].double().sum(0).cpu().numpy(), (ref.double() ** 2).sum(0).cpu().numpy(), rtol=2e-3)
+    res = torch.randn(B, H, W, Cout, device="cuda").bfloat16()
+    bias = torch.randn(Cout, device="cuda")
+    y2 = hip.conv2d_nhwc(x, packed, bias, Cout, 3, 3, 1, dil, dil, relu=True, residual=res)
+    ref2 = (ref + bias + res.float().reshape(-1, Cout)).clamp_min(0)
+    np.testing.assert_allclose(y2.float().reshape(-1, Cout).cpu().numpy(), ref2.cpu().numpy(), rtol=1e-2, atol=2e-2)
+    y3 = hip.conv2d_nhwc(x, packed, bias, Cout, 3, 3, 1, dil, dil, out_f32=True)
+    np.testing.assert_allclose(y3.reshape(-1, Cout).cpu().numpy(), (ref + bias).cpu().numpy(), rtol=2e-3, atol=2e-3)
+    # bit-repeatable: the slices are added in a fixed order
+    y_again = hip.conv2d_nhwc(x, packed, None, Cout, 3, 3, 1, dil, dil)
+    assert torch.equal(y_again, hip.conv2d_nhwc(x, packed, None, Cout, 3, 3, 1, dil, dil))
+
+
+@pytest.mark.parametrize("shape", [(8, 28, 40, 1024, 256, 1), (8, 28, 40, 512, 2048, 1), (8, 55, 80, 128, 512, 1), (2, 13, 17, 64, 64, 3)])
+@pytest.mark.parametrize("tail", ["plain", "relu", "res_relu", "slice"])
+def test_conv_bn_small_map_one_launch_matches_batchnorm(shape, tail):
+    """conv + train-mode BatchNorm [+ residual] [+ ReLU] on a small map: statistics and apply in ONE launch
+    (oess_norm_tile_stats_apply_nhwc_bf16) against nn.BatchNorm2d on the fp32 conv of the same operands, incl. running
+    statistics, a channel-slice destination (ASPP concat buffer) and bit-repeatability."""
+    from openess_amd import hip
+    B, H, W, Cin, Cout, k = shape
+    torch.manual_seed(sum(shape))
+    x = torch.randn(B, H, W, Cin, device="cuda").bfloat16()
+    w = torch.randn(Cout, Cin, k, k, device="cuda") / np.sqrt(Cin * k * k)
+    packed = hip.pack_conv_weight(w)
+    bn = torch.nn.BatchNorm2d(Cout).cuda().train()
+    bn.weight.data.uniform_(0.5, 1.5)
+    bn.bias.data.normal_()
+    refbn = torch.nn.BatchNorm2d(Cout).cuda().train()
+    refbn.load_state_dict(bn.state_dict())
+    res = torch.randn(B, H, W, Cout, device="cuda").bfloat16() if tail == "res_relu" else None
+    out = None
+    if tail == "slice":
+        buf = torch.zeros(B, H, W, 3 * Cout, device="cuda", dtype=torch.bfloat16)
+        out = buf[..., Cout:2 * Cout]
+    relu = tail in ("relu", "res_relu", "slice")
+    with torch.no_grad():
+        y = hip.conv_bn_train_nhwc(x, packed, Cout, k, k, 1, k // 2, 1, bn, relu=relu, residual=res, out=out)
+        yr = refbn(ref_conv(x, w, None, 1, k // 2, 1).permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        if res is not None:
+            yr = yr + res.float()
+        if relu:
+            yr = yr.clamp_min(0)
+    np.testing.assert_allclose(y.float().cpu().numpy(), yr.cpu().numpy(), rtol=2e-2, atol=3e-2)
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), refbn.running_mean.cpu().numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), refbn.running_var.cpu().numpy(), rtol=2e-3, atol=1e-4)
+    if tail == "slice":
+        assert float(buf[..., :Cout].abs().max()) == 0 and float(buf[..., 2 * Cout:].abs().max()) == 0
+    with torch.no_grad():
+        y2 = hip.conv_bn_train_nhwc(x, packed, Cout, k, k, 1, k // 2, 1, bn, relu=relu, residual=res)
+        y3 = hip.conv_bn_train_nhwc(x, packed, Cout, k, k, 1, k // 2, 1, bn, relu=relu, residual=res)
+    assert torch.equal(y2, y3)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W,Cx,C", [(2, 9, 11, 32, 32), (1, 13, 10, 64, 64), (3, 8, 8, 96, 32),
                                           (1, 110, 160, 128, 128)])     # one DSEC level at full width: 552 tiles > 512 slots (second round, ragged last m-tile)
