@@ -115,6 +115,51 @@ __global__ __launch_bounds__(THREADS) void resize_fwd_kernel(const void* __restr
     }
 }
 
+// Upsampling form of the bf16 forward (DeepLabv3 returns its 256-channel OS16 feature map at the input size: 28 x 40 -> 440 x 640,
+// a 1.15 GB write per batch of 8).  One workgroup per OUTPUT ROW: the two source rows are blended vertically ONCE into an
+// fp32 LDS row V[x][c] = hy * in[y0][x][c] + wy * in[y1][x][c] (W_in * C * 4 bytes), every output pixel is then
+// hx * V[x0] + wx * V[x1]: 2 LDS reads and 2 FMAs per channel instead of 4 global loads, 4 conversions and 7 FLOPs, and the
+// output leaves through non-temporal 16-byte stores.  (Association: columns first, then x -- ATen blends x first; the
+// difference is fp32 rounding, 2^-16 of the bf16 result's ulp.  The general kernel above keeps ATen's order for fp32.)
+__global__ __launch_bounds__(THREADS) void resize_up_rows_bf16_kernel(const uint16_t* __restrict__ in, int64_t ips, int C, Axis ay, Axis ax,
+                                                                      uint16_t* __restrict__ out, int64_t ops) {
+    extern __shared__ __attribute__((aligned(16))) float vrow[];            // [ax.in][C]
+    const int cv = C >> 3;
+    const int oy = blockIdx.x % ay.out;
+    const int64_t b = blockIdx.x / ay.out;
+    int y0, y1; float wy;
+    src_index(ay, oy, y0, y1, wy);
+    const float hy = 1.f - wy;
+    const int64_t row0 = (b * ay.in + y0) * ax.in, row1 = (b * ay.in + y1) * ax.in, orow = (b * ay.out + oy) * (int64_t)ax.out;
+    for (int j = threadIdx.x; j < ax.in * cv; j += THREADS) {
+        const int x = j / cv, c = (j - x * cv) * 8;
+        float a[8], d[8];
+        loadv<true, 8>(in, (row0 + x) * ips + c, a);
+        loadv<true, 8>(in, (row1 + x) * ips + c, d);
+        float4* dst = reinterpret_cast<float4*>(vrow + (size_t)x * C + c);
+        dst[0] = make_float4(hy * a[0] + wy * d[0], hy * a[1] + wy * d[1], hy * a[2] + wy * d[2], hy * a[3] + wy * d[3]);
+        dst[1] = make_float4(hy * a[4] + wy * d[4], hy * a[5] + wy * d[5], hy * a[6] + wy * d[6], hy * a[7] + wy * d[7]);
+    }
+    __syncthreads();
+    // thread = (channel chunk fixed, pixel lane): the column weights of a pixel are computed once per pixel lane iteration
+    const int cl = threadIdx.x % cv, pl = threadIdx.x / cv, ppi = THREADS / cv;
+    if (pl >= ppi) return;
+    const int c = cl * 8;
+    for (int ox = pl; ox < ax.out; ox += ppi) {
+        int x0, x1; float wx;
+        src_index(ax, ox, x0, x1, wx);
+        const float hx = 1.f - wx;
+        const float4* p0 = reinterpret_cast<const float4*>(vrow + (size_t)x0 * C + c);
+        const float4* p1 = reinterpret_cast<const float4*>(vrow + (size_t)x1 * C + c);
+        const float4 a0 = p0[0], a1 = p0[1], b0 = p1[0], b1 = p1[1];
+        float r[8] = {hx * a0.x + wx * b0.x, hx * a0.y + wx * b0.y, hx * a0.z + wx * b0.z, hx * a0.w + wx * b0.w,
+                      hx * a1.x + wx * b1.x, hx * a1.y + wx * b1.y, hx * a1.z + wx * b1.z, hx * a1.w + wx * b1.w};
+        const uint4 q = pack_bf16x8(r);
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_nt;
+        __builtin_nontemporal_store(u32x4_nt{q.x, q.y, q.z, q.w}, reinterpret_cast<u32x4_nt*>(out + (orow + ox) * ops + c));
+    }
+}
+
 // backward pass 1 (x): tmp[b, oy, ix, c] = sum_ox w(ox -> ix) * gout[b, oy, ox, c]        (tmp fp32, dense)
 template <bool BF16, int VEC>
 __global__ __launch_bounds__(THREADS) void resize_bwd_x_kernel(const void* __restrict__ gout, int64_t gps, int B, int C, Axis ay, Axis ax,
@@ -288,6 +333,12 @@ int oess_resize_bilinear_nhwc_fwd(const void* in, long long in_pix_stride, int B
     const Axis ay = make_axis(H, Ho, align_corners), ax = make_axis(W, Wo, align_corners);
     hipStream_t st = (hipStream_t)stream;
     const bool vec = vec_ok(in, in_pix_stride, C, is_bf16) && vec_ok(out, out_pix_stride, C, is_bf16);
+    if (is_bf16 && vec && Wo >= 4 * W && Ho >= 2 * H && (C >> 3) <= THREADS && (size_t)W * C * 4 <= 64 * 1024) {
+        hipLaunchKernelGGL(resize_up_rows_bf16_kernel, dim3((unsigned)((int64_t)B * Ho)), dim3(THREADS), (size_t)W * C * 4, st,
+                           (const uint16_t*)in, (int64_t)in_pix_stride, C, ay, ax, (uint16_t*)out, (int64_t)out_pix_stride);
+        OESS_HIP(hipGetLastError());
+        return OESS_OK;
+    }
 #define OESS_RS(BF, V) hipLaunchKernelGGL((resize_fwd_kernel<BF, V>), dim3((unsigned)((int64_t)B * Ho)), dim3(THREADS), 0, st, in, (int64_t)in_pix_stride, B, C, ay, ax, out, (int64_t)out_pix_stride)
     if (is_bf16) { if (vec) OESS_RS(true, 8); else OESS_RS(true, 1); }
     else { if (vec) OESS_RS(false, 4); else OESS_RS(false, 1); }

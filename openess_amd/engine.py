@@ -95,6 +95,29 @@ def conv2d_infer(x, pw, Cout, k, stride=1, pad=0, dil=1, relu=False, residual=No
     return from_nhwc(y)
 
 
+def _conv_backward(x, weight, pw, k, stride, pad, dil, gy, need_gx, need_gw, need_gb):
+    """Data / weight / bias gradients of conv2d on the MFMA kernels.  gy: channels_last bf16, logical NCHW."""
+    gx = gw = gb = None
+    Cin_x = x.shape[1]
+    gy8 = gy if gy.shape[1] % 8 == 0 else to_cl_bf16(gy)
+    if need_gx:
+        g_in = nhwc(gy8)
+        if stride != 1:         # strided conv: dilate dY with zeros, then the same stride-1 product
+            Hz = x.shape[2] - dil * (k - 1) + 2 * pad
+            Wz = x.shape[3] - dil * (k - 1) + 2 * pad
+            g_in = hip.zero_insert(g_in, stride, Hz, Wz)
+        gx = from_nhwc(hip.conv2d_nhwc(g_in, pw.flip(), None, Cin_x, k, k, 1, dil * (k - 1) - pad, dil))
+    if need_gw or need_gb:
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        if need_gw:
+            gw = hip.conv2d_wgrad(nhwc(x), nhwc(gy8), gy8.shape[1], Cin, k, k, stride, pad, dil)
+            if gy8.shape[1] != Cout:
+                gw = gw[:Cout]
+        if need_gb:
+            gb = hip.channel_sum(nhwc(gy8))[:Cout]
+    return gx, gw, gb
+
+
 class _ConvTrainFn(torch.autograd.Function):
     """Trainable conv, all three products on hand-written MFMA kernels: forward (conv_fwd.hip), data gradient
     (the same kernel on the rotated / transposed packed weight; strided convs first dilate dY with zeros) and
@@ -113,26 +136,88 @@ class _ConvTrainFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         pw, k, stride, pad, dil, has_bias = ctx.meta
         gy = gy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        gx = gw = gb = None
-        Cin_x = x.shape[1]
-        if ctx.needs_input_grad[0]:
-            gy8 = gy if gy.shape[1] % 8 == 0 else to_cl_bf16(gy)
-            g_in = nhwc(gy8)
-            if stride != 1:         # strided conv: dilate dY with zeros, then the same stride-1 product
-                Hz = x.shape[2] - dil * (k - 1) + 2 * pad
-                Wz = x.shape[3] - dil * (k - 1) + 2 * pad
-                g_in = hip.zero_insert(g_in, stride, Hz, Wz)
-            gx = from_nhwc(hip.conv2d_nhwc(g_in, pw.flip(), None, Cin_x, k, k, 1, dil * (k - 1) - pad, dil))
-        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            Cout, Cin = weight.shape[0], weight.shape[1]
-            gy8 = gy if gy.shape[1] % 8 == 0 else to_cl_bf16(gy)
-            if ctx.needs_input_grad[1]:
-                gw = hip.conv2d_wgrad(nhwc(x), nhwc(gy8), gy8.shape[1], Cin, k, k, stride, pad, dil)
-                if gy8.shape[1] != Cout:
-                    gw = gw[:Cout]
-            if has_bias and ctx.needs_input_grad[2]:
-                gb = hip.channel_sum(nhwc(gy8))[:Cout]
+        gx, gw, gb = _conv_backward(x, weight, pw, k, stride, pad, dil, gy, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                    has_bias and ctx.needs_input_grad[2])
         return gx, gw, gb, None, None, None, None, None, None
+
+
+class _ConvBNTrainFn(torch.autograd.Function):
+    """Bias-free conv -> nn.BatchNorm2d(train) [-> + residual] [-> ReLU] as ONE autograd node (models/_resnet.py:96-114,
+    models/deeplabv3.py:295-348).  Forward: the batch statistics come from the conv epilogue's fp32 accumulators (per-tile
+    partials, reduced in a fixed order in double) -- no statistics pass over the activation; backward: the fused BatchNorm
+    backward kernels (d(gamma), d(beta), dx, d(residual) with the ReLU mask from the stored output), then the conv's data and
+    weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, pw, k, stride, pad, dil, relu, eps, momentum, running_mean, running_var):
+        lib = hip._lib.load()
+        Cout = weight.shape[0]
+        xn = nhwc(x)
+        B, H, W, _, _ = hip._nhwc_geom(xn)
+        Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        M = B * Ho * Wo
+        tiles = (M + 127) // 128
+        part = torch.empty((tiles, 2, Cout), dtype=torch.float32, device=x.device)
+        y = hip.conv2d_nhwc(xn, pw.packed, None, Cout, k, k, stride, pad, dil, tile_stats=part)          # raw conv output (kept)
+        st = torch.empty((4, Cout), dtype=torch.float32, device=x.device)                                  # mean, rstd, scale, shift
+        sc = hip._stats_scratch(Cout, x.device)
+        hip._lib.check(lib.oess_norm_reduce_finalize_tile_stats(part.data_ptr(), tiles, Cout, sc.buf64.data_ptr(), sc.tickets.data_ptr(),
+                                                                float(M), float(eps), gamma.data_ptr(), beta.data_ptr(),
+                                                                running_mean.data_ptr(), running_var.data_ptr(), float(momentum),
+                                                                st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(),
+                                                                hip._stream()), "oess_norm_reduce_finalize_tile_stats")
+        out = torch.empty((B, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
+        rn = None if residual is None else nhwc(residual)
+        rps = 0 if rn is None else hip._nhwc_geom(rn)[4]
+        hip._lib.check(lib.oess_norm_apply_nhwc_bf16(y.data_ptr(), Cout, st[2].data_ptr(), st[3].data_ptr(),
+                                                     None if rn is None else rn.data_ptr(), rps, int(relu), 1, M, Cout, out.data_ptr(),
+                                                     Cout, hip._stream()), "oess_norm_apply_nhwc_bf16")
+        ctx.save_for_backward(x, weight, gamma, y, st, out if relu else None)
+        ctx.meta = (pw, k, stride, pad, dil, relu, residual is not None)
+        return from_nhwc(out)
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = hip._lib.load()
+        x, weight, gamma, y, st, out = ctx.saved_tensors
+        pw, k, stride, pad, dil, relu, has_res = ctx.meta
+        gy = gy.to(torch.bfloat16)
+        if gy.stride(1) != 1:
+            gy = gy.contiguous(memory_format=torch.channels_last)
+        gn = nhwc(gy)
+        B, Ho, Wo, C = y.shape
+        M = B * Ho * Wo
+        gps = hip._nhwc_geom(gn)[4]
+        dy = torch.empty((B, Ho, Wo, C), dtype=torch.bfloat16, device=y.device)                # gradient w.r.t. the raw conv output
+        dres = torch.empty((B, Ho, Wo, C), dtype=torch.bfloat16, device=y.device) if (has_res and relu) else None
+        dgb = torch.empty((2, C), dtype=torch.float32, device=y.device)
+        g32 = gamma.detach().float().contiguous()
+        ws, wsn = hip._norm_partials(1, M, C, y.device, backward=True)
+        hip._lib.check(lib.oess_batchnorm_bwd_nhwc_bf16(y.data_ptr(), C, gn.data_ptr(), gps, None if out is None else out.data_ptr(), C,
+                                                        st[0].data_ptr(), st[1].data_ptr(), g32.data_ptr(), int(relu), M, C,
+                                                        dgb[0].data_ptr(), dgb[1].data_ptr(), dy.data_ptr(), C,
+                                                        None if dres is None else dres.data_ptr(), C, ws.data_ptr(), wsn, hip._stream()),
+                       "oess_batchnorm_bwd_nhwc_bf16")
+        gres = None
+        if has_res:
+            gres = from_nhwc(dres) if dres is not None else gy                                  # no ReLU: the residual sees dy itself
+        gx, gw, _ = _conv_backward(x, weight, pw, k, stride, pad, dil, from_nhwc(dy), ctx.needs_input_grad[0],
+                                   ctx.needs_input_grad[1], False)
+        return (gx, gw, dgb[1].to(gamma.dtype), dgb[0].to(gamma.dtype), gres) + (None,) * 10
+
+
+def conv_bn_train(x, conv, bn, pw, relu=False, residual=None):
+    """Differentiable bias-free conv + train-mode BatchNorm2d [+ residual] [+ ReLU] (one autograd node, statistics from the conv
+    epilogue).  x: logical NCHW channels_last bf16 with C % 8 == 0."""
+    k, s, p, d = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0]
+    pw.get(conv.weight, None, None, cin_pad=x.shape[1])
+    if residual is not None and (residual.dtype != torch.bfloat16 or residual.stride(1) != 1):
+        residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = _ConvBNTrainFn.apply(x, conv.weight, bn.weight, bn.bias, residual, pw, k, s, p, d, bool(relu), float(bn.eps),
+                             0.0 if bn.momentum is None else float(bn.momentum), bn.running_mean, bn.running_var)
+    bump_bn_counter(bn)
+    return y
 
 
 def conv2d_train(x, weight, bias, pw, k, stride=1, pad=0, dil=1, out_f32=False, ver=None):

@@ -34,6 +34,18 @@ def conv_bn(conv, bn, x, relu=False, residual=None, out=None):
     epilogue (no statistics pass); eval-mode BN is folded into the packed weights and the whole tail is the
     conv epilogue.  With autograd: MFMA conv + library BatchNorm."""
     needs_grad = torch.is_grad_enabled() and (conv.weight.requires_grad or x.requires_grad or bn.weight.requires_grad)
+    if needs_grad and conv.bias is None and bn.training and bn.weight is not None and bn.running_mean is not None and \
+            conv.out_channels % 8 == 0 and conv.out_channels <= 2048:
+        # one autograd node: statistics from the conv epilogue (no statistics pass), fused BatchNorm backward
+        if x.shape[1] % 8 or x.dtype != torch.bfloat16:
+            x = engine.to_cl_bf16(x)
+        elif x.stride(1) != 1:
+            x = x.contiguous(memory_format=torch.channels_last)
+        y = engine.conv_bn_train(x, conv, bn, conv._pw, relu=relu, residual=residual)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
     if needs_grad or conv.bias is not None:
         y = engine.batch_norm_act(conv(x), bn, relu=relu, residual=residual)
         if out is not None:
