@@ -21,6 +21,8 @@ The ONE JSON line rank 0 prints carries, besides the headline `value` (inputs re
                 frame2recon_full
   ingest        the same step with the raw events starting in PINNED HOST buffers: H2D copy + voxelizer of batch i+1 on a
                 side HIP stream under step i (never `value`)
+  train_loop    train.py's own loop at the same size (tools/bench_train_loop.py): DataLoader workers -> pin thread ->
+                BaseTrainer.device_batches (side-stream ingest) -> train_step
   cpu_baseline  the oracle on this host's CPU (1 warm-up + 3 timed, median)
 """
 import argparse
@@ -479,6 +481,16 @@ def main():
                                                                    "HIP stream per ConvLSTM level, overlapping the teacher forward (e2vid/wavefront.py; "
                                                                    "opt-in: overlapped launches would blur the per-launch roofline timing)")
             out["configs"] = cfgs
+    if rank == 0 and extras and world == 1 and a.workload == "frame2voxel_pixel_distill":
+        # the PRODUCT loop (train.py dispatch, DataLoader workers, pin thread, side-stream ingest) beside the headline
+        try:
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_train_loop
+            out["train_loop"] = bench_train_loop.measure(batches=24, workers=6, prefetch=True)
+            out["train_loop"]["vs_headline"] = round(out["train_loop"]["value"] / out["value"], 3)
+        except Exception as e:      # never cost the headline
+            out["train_loop"] = {"error": repr(e)[:300]}
     if rank == 0:
         if world == 1 and not a.no_pmc and out["roofline"] is not None:
             torch.cuda.empty_cache()

@@ -15,13 +15,19 @@ from . import _synth
 
 class SyntheticEvents(Dataset):
     def __init__(self, length=16, sensor_hw=(480, 640), crop_rows=40, nr_events_data=20, nr_events_window=100000,
-                 nr_bins=5, num_classes=11, config_option='frame2voxel', superpixel_size=100, mode='train', seed=1205):
+                 nr_bins=5, num_classes=11, config_option='frame2voxel', superpixel_size=100, mode='train', seed=1205, pool=0):
         self.length, self.sensor_hw, self.crop_rows = length, tuple(sensor_hw), crop_rows
         self.nr_events_data, self.nr_events_window, self.nr_bins = nr_events_data, nr_events_window, nr_bins
         self.num_classes, self.config_option, self.superpixel_size = num_classes, config_option, superpixel_size
         self.mode, self.seed = mode, seed
         self.require_paired_data = False
         self.rectify_map = _synth.rectify_map(*self.sensor_hw)
+        # pool > 0: `pool` distinct samples are generated ONCE here (before the DataLoader forks its workers: the arrays are
+        # shared copy-on-write) and index i serves sample i % pool.  A worker then costs what a real loader costs -- copying
+        # a sample's raw columns out of a memory map -- instead of drawing 2 M random events per sample (~0.3 s of NumPy),
+        # so tools/bench_train_loop.py measures the ingest pipeline and not the random-number generator.
+        self.pool = int(pool)
+        self._pool = [self._make(i) for i in range(self.pool)] if self.pool > 0 else None
 
     def __len__(self):
         return self.length
@@ -30,6 +36,12 @@ class SyntheticEvents(Dataset):
         return self.sensor_hw[0] - self.crop_rows, self.sensor_hw[1]
 
     def __getitem__(self, index):
+        if self._pool is not None:
+            item = self._pool[index % self.pool]
+            return (*item[:-1], f"synthetic/{self.mode}/{index:06d}")
+        return self._make(index)
+
+    def _make(self, index):
         H, W = self.sensor_hw
         Hn = H - self.crop_rows
         rng = np.random.default_rng(self.seed + index + (0 if self.mode == 'train' else 10**6))

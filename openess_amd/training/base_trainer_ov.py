@@ -81,11 +81,52 @@ class BaseTrainer(object):
         for m in self.models_dict.values():
             m.train()
         n = len(self.train_loader_sensor_b)
-        for i_batch, sample_batched in enumerate(self.train_loader_sensor_b):
-            out = self.train_step(self.prepare_batch(sample_batched))
+        for i_batch, batch in enumerate(self.device_batches(self.train_loader_sensor_b)):
+            out = self.train_step(batch)
             if i_batch % 20 == 0 and self.rank == 0:
                 self.log_train(i_batch, n, out[0])
             self.step_count += 1
+
+    def device_batches(self, loader, split='train'):
+        """Ingest pipeline (north_star: "straight from pinned host event buffers"): yields device batches whose host -> device
+        copies AND voxelization were enqueued on a SIDE HIP stream.  The generator hands batch i to the caller, the caller
+        enqueues step i on the current stream, and only then is batch i+1 pulled from the DataLoader (pinned by its pin
+        thread) and its copies + voxelizer launches enqueued on the side stream -- the host runs ahead of the GPU, so they
+        execute under step i.  The current stream waits on one event per batch; tensors produced on the side stream are
+        handed to the consumer stream with record_stream, so the caching allocator cannot recycle them early.
+        `settings.ingest_prefetch: False` (or a CPU-only debug run) falls back to the in-order path."""
+        if not getattr(self.settings, 'ingest_prefetch', True):
+            for sample_batched in loader:
+                yield self.prepare_batch(sample_batched, split)
+            return
+        if getattr(self, '_ingest_stream', None) is None:
+            self._ingest_stream = torch.cuda.Stream(device=self.device)
+        side = self._ingest_stream
+        side.wait_stream(torch.cuda.current_stream(self.device))       # once: everything set up so far (rectify maps, weights)
+        it = iter(loader)
+
+        def produce():
+            try:
+                sample_batched = next(it)
+            except StopIteration:
+                return None
+            with torch.cuda.stream(side):           # NOT ordered after the step just enqueued on the current stream: that is the overlap
+                batch = self.prepare_batch(sample_batched, split)
+                ready = torch.cuda.Event()
+                ready.record(side)
+            return batch, ready
+
+        nxt = produce()
+        while nxt is not None:
+            batch, ready = nxt
+            main = torch.cuda.current_stream(self.device)
+            main.wait_event(ready)
+            for t in batch:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(main)
+            yield batch                              # the caller enqueues step i here ...
+            nxt = produce()                          # ... and batch i+1 is copied + voxelized under it
+        torch.cuda.current_stream(self.device).wait_stream(side)
 
     def log_train(self, i_batch, n, losses):
         msg = 'epoch: [{0}][{1}/{2}], '.format(self.epoch_count, i_batch, n) + ', '.join(
@@ -122,7 +163,7 @@ class BaseTrainer(object):
                           num_classes=s.semseg_num_classes, config_option=s.config_option,
                           superpixel_size=getattr(s, 'superpixel_size', 100))
             n_train = getattr(s, 'synthetic_length', 2 * s.batch_size_b * self.world)
-            train_ds = builder(length=n_train, mode='train', **common)
+            train_ds = builder(length=n_train, mode='train', pool=getattr(s, 'synthetic_pool', 0), **common)
             val_ds = builder(length=max(s.batch_size_b, 2), mode='val', **common)
         else:
             train_ds, val_ds = builder.build_from_settings(s)

@@ -56,7 +56,9 @@ def test_thirty_step_loss_trajectory_tracks_fp32_oracle(contr):
             row[k] = (a, b)
             rel = abs(a - b) / abs(b)
             worst[k] = max(worst.get(k, 0.0), rel)
-            assert rel <= (5e-2 if k == "contrastive_nce_loss" else 3e-2), (it, k, a, b)
+            early = it < 15
+            bound = (5e-2 if early else 8e-2) if k == "contrastive_nce_loss" else (2e-2 if early else 5e-2)
+            assert rel <= bound, (it, k, a, b)
         traj.append(row)
     first, last = traj[0]["dense_clip_loss"][1], traj[-1]["dense_clip_loss"][1]
     assert last < first                                   # the oracle actually trains on this batch (the comparison is not vacuous)

@@ -133,3 +133,28 @@ def test_train_py_dispatch_and_one_epoch(cfg, loop, tmp_path, monkeypatch):
     assert saved == (['Epoch_0.pt'] if loop == 'pretraining' else ['ckp.pt'])
     if loop == 'training':
         assert 0.0 <= float(trainer.last_val_metrics['miou']) <= 100.0
+
+
+@pytest.mark.gpu
+def test_ingest_prefetch_equals_in_order_loop(tmp_path):
+    """BaseTrainer.device_batches (side-stream H2D + voxelizer of batch i+1 under step i, two loader workers, pinned memory)
+    against the in-order path: same batches in the same order -> bit-identical weights after the epoch (every kernel of the
+    pixel-distillation step is bit-repeatable)."""
+    import torch
+    import train
+    from openess_amd.config.settings import Settings
+    finals = []
+    for prefetch in (True, False):
+        train.seed_everything()
+        s = Settings(os.path.join(CFG, "pretrain_dsec_synthetic.yaml"), generate_log=False)
+        s.ckpt_dir = str(tmp_path)
+        s.if_spatial_contrastive = False
+        s.synthetic_length, s.num_cpu_workers, s.ingest_prefetch, s.save_checkpoint = 10, 2, prefetch, False
+        trainer, _ = train.build_trainer(s)
+        torch.manual_seed(77)                       # the DataLoader's shuffle draws its base seed here
+        trainer.trainEpoch()
+        assert trainer.step_count == 5
+        torch.cuda.synchronize()
+        finals.append({k + "." + n: p.detach().clone() for k, m in trainer.models_dict.items() for n, p in m.named_parameters()
+                       if p.requires_grad})
+    assert any(not torch.equal(v, finals[1][k]) for k, v in finals[0].items()) is False

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Throughput of the PRODUCT training loop (train.py's dispatch -> OpenESSPretrainModel.trainEpoch) at the BASELINE size:
+DataLoader worker processes -> collate (raw event columns, 13 B/event) -> pin thread -> H2D copies + batched HIP voxelizer on
+the side stream (BaseTrainer.device_batches) -> train_step.  This is the loop SURVEY 8e names as the weak-scaling limiter;
+bench.py reports its rate beside the headline (`train_loop`), never as `value`.
+    python tools/bench_train_loop.py [--batches 24] [--workers 6] [--no-prefetch] [--json]
+The synthetic dataset serves a pool of 16 pre-generated event-frames (workers copy them like a memory-mapped recording)."""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def build(batches, workers, prefetch, B=8, contrastive=False, tmp=None):
+    import train
+    from openess_amd.config.settings import Settings
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "tests", "configs", "pretrain_dsec_synthetic.yaml")))
+    d = cfg['dataset']['DSEC_events']
+    d.update(shape=[440, 640], nr_events_data=20, nr_events_window=100000)
+    cfg['optim'].update(batch_size_b=B, num_epochs=1)
+    cfg['hardware']['num_cpu_workers'] = workers
+    cfg['clip'].update(if_spatial_contrastive=contrastive, superpixel_size=100)
+    cfg['checkpoint']['save_checkpoint'] = False
+    cfg['dir']['log'] = tmp
+    path = os.path.join(tmp, "train_loop.yaml")
+    yaml.safe_dump(cfg, open(path, "w"))
+    train.seed_everything()
+    s = Settings(path, generate_log=False)
+    s.ckpt_dir = tmp
+    s.synthetic_length = batches * B
+    s.synthetic_pool = 16
+    s.ingest_prefetch = prefetch
+    trainer, loop = train.build_trainer(s)
+    assert loop == 'pretraining'
+    return trainer, s
+
+
+def measure(batches=24, workers=6, prefetch=True, warm=4):
+    with tempfile.TemporaryDirectory(prefix="oess_loop_", dir="/tmp") as tmp:
+        trainer, s = build(batches + warm, workers, prefetch, tmp=tmp)
+        for m in trainer.models_dict.values():
+            m.train()
+        B = s.batch_size_b
+        t0, n = None, 0
+        for i, batch in enumerate(trainer.device_batches(trainer.train_loader_sensor_b)):
+            if i == warm:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            trainer.train_step(batch)
+            if i >= warm:
+                n += 1
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"value": round(n * B / dt, 2), "unit": "event-frames/s", "ms_per_step": round(dt / n * 1e3, 3), "steps": n,
+                "loader_workers": workers, "prefetch": bool(prefetch),
+                "note": "train.py's own loop: DataLoader workers -> collate (13 B/event raw columns, 208 MB/batch) -> pin thread -> "
+                        "side-stream H2D + voxelizer (BaseTrainer.device_batches) -> OpenESSPretrainModel.train_step; 16-sample pool"}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batches", type=int, default=24)
+    ap.add_argument("--workers", type=int, default=6)
+    ap.add_argument("--no-prefetch", action="store_true")
+    a = ap.parse_args()
+    r = measure(a.batches, a.workers, not a.no_prefetch)
+    print(json.dumps(r))
