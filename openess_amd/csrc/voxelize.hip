@@ -490,40 +490,25 @@ __device__ __forceinline__ int block_incl_scan_256(int v, int* wsum) {
 // reads rows `tile` and `tile + 1`: two contiguous rows of nSl ints.  Record region of (segment, slice) =
 // [(segment * nSl + slice) * RSTRIDE, + RSTRIDE): fixed, no allocator (the workspace holds 4 records per event anyway).
 constexpr int RSTRIDE = 4 * SSL;      // worst case: every event of the slice in 4 tiles
-
-// Stores of the sort kernel.  WT (the fused launch below): write-through at agent scope (`sc1`), so that a splat workgroup
-// on ANOTHER XCD finds the data in memory once this workgroup has counted itself done -- the 8 XCD L2s are not coherent with
-// each other, and an agent-scope release would write back the whole L2 (norm_ops.hip: 25-31 us per call).
-template <bool WT>
-__device__ __forceinline__ void st_tab(int* p, int v) {
-    if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // global_store_dword ... sc1
-    else *p = v;
-}
-template <bool WT>
-__device__ __forceinline__ void st_rec(float4* p, const float4 v) {
-    if (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(p), "v"(f32x4_t{v.x, v.y, v.z, v.w}) : "memory");
-    else store_stream(p, v);
-}
-
-// tstride: ints per segment of the run table, a multiple of 32 (no cache line holds entries of two segments: a line that a
-// splat workgroup of segment s pulled into its L2 can therefore never be a stale copy of segment s + 1's entries)
-template <typename Src, bool WT>
-__device__ __forceinline__ void tri_sort_body(const Src& src, const int64_t* __restrict__ seg_off, const Geom& g, int nSl,
-                                              size_t tstride, int* __restrict__ table, typename Src::Rec* __restrict__ recs,
-                                              unsigned int cap, const int s, const int slice, unsigned char* sm_sort) {
+template <typename Src>
+__global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const int64_t* __restrict__ seg_off, Geom g, int nSl,
+                                                           int* __restrict__ table,
+                                                           typename Src::Rec* __restrict__ recs, unsigned int cap) {
     using Rec = typename Src::Rec;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_sort[];
     const int nT = g.nTiles;
     int* cur = reinterpret_cast<int*>(sm_sort);                                   // [nT + 1]
     int* wsum = cur + nT + 1;                                                     // [16] + max |value|
     Rec* buf = reinterpret_cast<Rec*>(sm_sort + (((size_t)(nT + 1 + 17) * 4 + 15) & ~(size_t)15));   // [LCAP]
+    const int s = blockIdx.y, slice = blockIdx.x;
     const int64_t b = seg_off[s], e = seg_off[s + 1];
     const int64_t n = e - b;
-    int* tab = table + (size_t)s * tstride + slice;                 // column `slice` of the segment's transposed table
+    int* tab = table + (size_t)s * (nT + 2) * nSl + slice;          // column `slice` of the segment's transposed table
     const int64_t sl_beg = (int64_t)slice * SSL;
     for (int i = threadIdx.x; i <= nT; i += SORT_THREADS) cur[i] = 0;
     if (threadIdx.x == 0) wsum[16] = 0;
     if (sl_beg >= n) {                                   // empty slice (ragged segments): all-zero column
-        for (int i = threadIdx.x; i < nT + 2; i += SORT_THREADS) st_tab<WT>(&tab[(size_t)i * nSl], 0);
+        for (int i = threadIdx.x; i < nT + 2; i += SORT_THREADS) tab[(size_t)i * nSl] = 0;
         return;
     }
     lds_barrier();
@@ -588,13 +573,13 @@ __device__ __forceinline__ void tri_sort_body(const Src& src, const int64_t* __r
     lds_barrier();
     const int total = cur[nT];
     const unsigned int base = (unsigned int)(((size_t)s * nSl + slice) * RSTRIDE);
-    for (int i = threadIdx.x; i <= nT; i += SORT_THREADS) st_tab<WT>(&tab[(size_t)i * nSl], cur[i]);     // starts inside the region
-    if (threadIdx.x == 0) st_tab<WT>(&tab[(size_t)(nT + 1) * nSl], vmax_bits);
+    for (int i = threadIdx.x; i <= nT; i += SORT_THREADS) tab[(size_t)i * nSl] = cur[i];                  // starts inside the region
+    if (threadIdx.x == 0) tab[(size_t)(nT + 1) * nSl] = vmax_bits;
     Rec* region = recs + base;
     // phase B: position = start of the tile + rank; stage in LDS (the counters are only read from here on)
     auto place = [&](const int* c, unsigned int rank, const Rec& q) __attribute__((always_inline)) {
         const int pos = *c + (int)rank;
-        if (pos < LCAP) buf[pos] = q; else if (base + (unsigned int)pos < cap) st_rec<WT>(&region[pos], q);
+        if (pos < LCAP) buf[pos] = q; else if (base + (unsigned int)pos < cap) region[pos] = q;
     };
 #pragma unroll
     for (int k = 0; k < SEPT; ++k) {
@@ -607,15 +592,7 @@ __device__ __forceinline__ void tri_sort_body(const Src& src, const int64_t* __r
     lds_barrier();
     const int staged = total < LCAP ? total : LCAP;
     for (int i = threadIdx.x; i < staged; i += SORT_THREADS)
-        if (base + (unsigned int)i < cap) st_rec<WT>(&region[i], buf[i]);          // whole, exclusively owned lines
-}
-
-template <typename Src>
-__global__ __launch_bounds__(SORT_THREADS) void tri_sort_kernel(Src src, const int64_t* __restrict__ seg_off, Geom g, int nSl,
-                                                           size_t tstride, int* __restrict__ table,
-                                                           typename Src::Rec* __restrict__ recs, unsigned int cap) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm_sort[];
-    tri_sort_body<Src, false>(src, seg_off, g, nSl, tstride, table, recs, cap, (int)blockIdx.y, (int)blockIdx.x, sm_sort);
+        if (base + (unsigned int)i < cap) store_stream(&region[i], buf[i]);        // whole, exclusively owned lines
 }
 
 // Wave64 inclusive scan / max on the DPP network (row_shr 1,2,4,8 inside the 16-lane rows, then row_bcast:15 and :31 across
@@ -748,16 +725,23 @@ __device__ __forceinline__ void splat_record(const TriRec r, const Geom& g, int 
 // is arranged for instruction count: straight-line corners (splat_record), run lookup by LDS marks instead of a per-lane
 // binary search, constant-stride write-out, no integer divisions.
 template <typename Src>
-__device__ __forceinline__ void tri_splat_body(const Src& src, const typename Src::Rec* __restrict__ recs,
-                                               const int* __restrict__ table, size_t tstride, const Geom& g, int nSl, int count_mode,
-                                               unsigned int cap, const int s, const int tile, float* __restrict__ out, int* acc32) {
+__global__ __launch_bounds__(THREADS) void tri_splat_kernel(Src src, const typename Src::Rec* __restrict__ recs,
+                                                            const int* __restrict__ table, Geom g, int nSl, int count_mode,
+                                                            unsigned int cap, int n_items, float* __restrict__ out) {
     using Rec = typename Src::Rec;
+    extern __shared__ __attribute__((aligned(16))) int acc32[];          // [C][TH][TW] ints == [C][TH/2][TW] long longs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nT = g.nTiles;
+    // XCD-aware item order: workgroup L runs on XCD L % 8; giving every XCD one contiguous eighth of the (segment, tile) items
+    // puts the neighbouring tiles of a slice - whose runs share their boundary cache lines - on the same L2, one after the other
+    const int per_xcd = (n_items + 7) >> 3;
+    const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (item >= n_items) return;
+    const int s = item / nT, tile = item - s * nT;
     const int ty = tile / g.tilesX, tx = tile - ty * g.tilesX;
     const int x_lo = tx * TW, y_lo = ty * g.TH;
-    const int* trow = table + (size_t)s * tstride + (size_t)tile * nSl;   // run starts of this tile, one per slice; ends follow
-    const int* vrow = table + (size_t)s * tstride + (size_t)(nT + 1) * nSl;   // max |value| of each slice
+    const int* trow = table + ((size_t)s * (nT + 2) + tile) * nSl;       // run starts of this tile, one per slice; ends follow
+    const int* vrow = table + ((size_t)s * (nT + 2) + nT + 1) * nSl;     // max |value| of each slice
 
     // chunk 0 of the run table: one slice per lane
     int cnt0 = 0; unsigned int beg0 = 0; float vmax = 0.f;
@@ -900,91 +884,6 @@ __device__ __forceinline__ void tri_splat_body(const Src& src, const typename Sr
     if (count_mode) run_tile(std::true_type{}); else run_tile(std::false_type{});
 }
 
-template <typename Src>
-__global__ __launch_bounds__(THREADS) void tri_splat_kernel(Src src, const typename Src::Rec* __restrict__ recs,
-                                                            const int* __restrict__ table, size_t tstride, Geom g, int nSl,
-                                                            int count_mode, unsigned int cap, int n_items, float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) int acc32[];          // [C][TH][TW] ints == [C][TH/2][TW] long longs
-    // XCD-aware item order: workgroup L runs on XCD L % 8; giving every XCD one contiguous eighth of the (segment, tile) items
-    // puts the neighbouring tiles of a slice - whose runs share their boundary cache lines - on the same L2, one after the other
-    const int per_xcd = (n_items + 7) >> 3;
-    const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if (item >= n_items) return;
-    tri_splat_body<Src>(src, recs, table, tstride, g, nSl, count_mode, cap, item / g.nTiles, item % g.nTiles, out, acc32);
-}
-
-// =================================================================================================
-// FUSED launch: sort and splat of the whole batch in ONE kernel, pipelined by chunks of G segments.
-//
-// The two kernels above want different things from the machine: the sort is bound by memory LATENCY (a wave lives ~19 us for
-// 2 048 events, mostly waiting for its column loads and rectify gathers), the splat by its 0.9 GB WRITE (floor 160 us) plus
-// the latency of its record fetch.  Back to back they cost 180 + 200 us; side by side on two streams they did not overlap
-// (round 2: 0.423 vs 0.400 ms) because 4 sort workgroups fill a CU's LDS and the two queues simply time-share the chip.
-// Here both roles live in one grid whose block order IS the schedule:
-//     sort(0) sort(1) splat(0) sort(2) splat(1) ... sort(n-1) splat(n-2) splat(n-1)        (chunk = G segments)
-// so the sort of chunk k+1 is resident next to the splat of chunk k on every CU, latency-bound work under write-bound work.
-// Dependency: every sort workgroup counts itself into done[segment] after its (write-through) stores have been acknowledged;
-// a splat workgroup spins (one lane, s_sleep) until its segment's count is nSl.  No deadlock: the hardware dispatches
-// workgroups in block-id order per XCD, and every workgroup only ever waits for workgroups with SMALLER ids, so the lowest
-// unfinished id is always running.  The spin is bounded: after ~0.3 s it gives up, raises a flag in the workspace (every other spinner then leaves at once) and writes
-// whatever is there -- a wrong result that the caller can detect instead of a hung GPU.
-// Coherence across the 8 XCD L2s: the sort's stores are write-through (st_tab / st_rec), the counter is an agent-scope atomic;
-// the splat reads with ordinary loads -- no line it touches can have been cached by its XCD before the data reached memory
-// (record regions are per slice, table rows per segment are line-aligned, and nothing reads them before the count is full).
-// =================================================================================================
-template <typename Src>
-__global__ __launch_bounds__(THREADS) void tri_fused_kernel(Src src, const int64_t* __restrict__ seg_off, Geom g, int nSl,
-                                                            size_t tstride, int* __restrict__ table,
-                                                            typename Src::Rec* __restrict__ recs, unsigned int cap, int count_mode,
-                                                            int n_seg, int G, unsigned int* __restrict__ done, float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm_fused[];
-    const int n_chunks = (n_seg + G - 1) / G;
-    const int S = ((G * nSl + 7) >> 3) << 3;               // sort blocks per chunk, padded to the XCD count
-    const int P = ((G * g.nTiles + 7) >> 3) << 3;          // splat blocks per chunk
-    int bid = (int)blockIdx.x;
-    int role, chunk, local;                                // role 0 = sort, 1 = splat
-    if (bid < S) { role = 0; chunk = 0; local = bid; }
-    else {
-        bid -= S;
-        const int per = S + P;
-        int k = bid / per;
-        if (k >= n_chunks - 1) { role = 1; chunk = n_chunks - 1; local = bid - (n_chunks - 1) * per; }
-        else {
-            const int r = bid - k * per;
-            if (r < S) { role = 0; chunk = k + 1; local = r; } else { role = 1; chunk = k; local = r - S; }
-        }
-    }
-    const int seg0 = chunk * G;
-    const int nseg_c = (n_seg - seg0 < G) ? n_seg - seg0 : G;
-    if (role == 0) {
-        if (local >= nseg_c * nSl) return;
-        const int sl = local / nSl, slice = local - sl * nSl;          // slices of one segment on consecutive blocks
-        const int s = seg0 + sl;
-        tri_sort_body<Src, true>(src, seg_off, g, nSl, tstride, table, recs, cap, s, slice, sm_fused);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's write-through stores have been acknowledged
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(&done[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    // splat: XCD-aware order inside the chunk (P is a multiple of 8, the chunk's first block id too)
-    const int n_items = nseg_c * g.nTiles;
-    const int per_xcd = (n_items + 7) >> 3;
-    const int item = (local & 7) * per_xcd + (local >> 3);
-    if (item >= n_items) return;
-    const int s = seg0 + item / g.nTiles, tile = item % g.nTiles;
-    if (threadIdx.x == 0) {
-        unsigned int spins = 0;
-        while (__hip_atomic_load(&done[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)nSl) {
-            __builtin_amdgcn_s_sleep(8);
-            ++spins;
-            if ((spins & 255u) == 0u && __hip_atomic_load(&done[n_seg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;   // someone gave up
-            if (spins > (1u << 18)) { __hip_atomic_store(&done[n_seg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        }
-    }
-    __syncthreads();
-    tri_splat_body<Src>(src, recs, table, tstride, g, nSl, count_mode, cap, s, tile, out, reinterpret_cast<int*>(sm_fused));
-}
-
 // Event histogram (a4): tiny; direct global atomics on a zeroed 2 x H x W image per segment.
 __global__ __launch_bounds__(THREADS) void hist_kernel(const int64_t* __restrict__ ev, const int64_t* __restrict__ seg_off,
                                                        int H, int W, float* __restrict__ out) {
@@ -1033,20 +932,15 @@ Geom tri_geom(int C, int H, int W, int crop_rows, int64_t max_seg_len) {
     return g;
 }
 
-// ints per segment of the transposed run table, padded to whole 128-byte lines
-size_t tri_tstride(const Geom& g, int nSl) { return oess::align_up((size_t)(g.nTiles + 2) * nSl, 32); }
-
 size_t ws_layout_tri(int64_t n_events, int n_seg, const Geom& g, int nSl, size_t* o_table, size_t* o_recs) {
-    const size_t ot = oess::align_up(256 + ((size_t)n_seg + 1) * 4, 256);      // [256, ot): done[n_seg] + error flag of the fused launch
-    const size_t orr = oess::align_up(ot + (size_t)n_seg * tri_tstride(g, nSl) * 4, 256);
+    const size_t ot = 256;
+    const size_t orr = oess::align_up(ot + (size_t)n_seg * nSl * (g.nTiles + 2) * 4, 256);
     if (o_table) *o_table = ot;
     if (o_recs) *o_recs = orr;
     const size_t slots = (size_t)n_seg * nSl * RSTRIDE;                 // fixed record region per (segment, slice)
     const size_t need = (size_t)n_events * 4;
     return orr + (slots > need ? slots : need) * sizeof(float4);
 }
-
-int g_tri_fuse_G = 4;      // segments per chunk of the fused launch; 0 = two kernels (development hook below, fixed after tuning)
 
 template <typename Src>
 int run_tri(Src src, const int64_t* seg_off, int n_seg, int64_t max_seg_len, int C, int H, int W, int crop_rows,
@@ -1074,35 +968,18 @@ int run_tri(Src src, const int64_t* seg_off, int n_seg, int64_t max_seg_len, int
     Rec* recs = (Rec*)(wb + o_recs);
     Src src_c = src;
     src_c.seg_base_index = 0;
-    const size_t tstride = tri_tstride(g, nSl);
     const size_t sort_lds = (((size_t)(g.nTiles + 1 + 17) * 4 + 15) & ~(size_t)15) + (size_t)LCAP * sizeof(Rec);
     if (sort_lds + 64 > 160 * 1024) return OESS_EINVAL;
     const size_t splat_lds = (size_t)g.C * g.TH * TW * sizeof(int);
+    OESS_HIP(hipFuncSetAttribute((const void*)&tri_sort_kernel<Src>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
+    hipLaunchKernelGGL((tri_sort_kernel<Src>), dim3(nSl, n_seg), dim3(SORT_THREADS), sort_lds, st, src_c, seg_off, g, nSl, table,
+                       recs, cap);
+    OESS_HIP(hipFuncSetAttribute((const void*)&tri_splat_kernel<Src>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)splat_lds));
     if (splat_lds < 2048) return OESS_EINVAL;             // the run lookup borrows the first 512 accumulator words
     const long long n_items = (long long)g.nTiles * n_seg;
     if (n_items > 0x7ffffff0ll) return OESS_EINVAL;
-    const int G = g_tri_fuse_G;
-    if (G > 0 && n_seg >= 3 * G && (long long)nSl * n_seg + n_items < 0x3ffffff0ll) {
-        // fused, chunk-pipelined launch (see tri_fused_kernel): needs a few chunks to have anything to overlap
-        static_assert(SORT_THREADS == THREADS, "one block size for both roles");
-        unsigned int* done = (unsigned int*)(wb + 256);
-        OESS_HIP(hipMemsetAsync(done, 0, ((size_t)n_seg + 1) * sizeof(unsigned int), st));
-        const size_t lds = sort_lds > splat_lds ? sort_lds : splat_lds;
-        OESS_HIP(hipFuncSetAttribute((const void*)&tri_fused_kernel<Src>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const int n_chunks = (n_seg + G - 1) / G;
-        const long long S = (((long long)G * nSl + 7) >> 3) << 3, P = (((long long)G * g.nTiles + 7) >> 3) << 3;
-        const long long blocks = n_chunks * (S + P);
-        hipLaunchKernelGGL((tri_fused_kernel<Src>), dim3((unsigned)blocks), dim3(THREADS), lds, st, src_c, seg_off, g, nSl, tstride,
-                           table, recs, cap, count_mode, n_seg, G, done, out);
-        OESS_HIP(hipGetLastError());
-        return OESS_OK;
-    }
-    OESS_HIP(hipFuncSetAttribute((const void*)&tri_sort_kernel<Src>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
-    hipLaunchKernelGGL((tri_sort_kernel<Src>), dim3(nSl, n_seg), dim3(SORT_THREADS), sort_lds, st, src_c, seg_off, g, nSl, tstride,
-                       table, recs, cap);
-    OESS_HIP(hipFuncSetAttribute((const void*)&tri_splat_kernel<Src>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)splat_lds));
     hipLaunchKernelGGL((tri_splat_kernel<Src>), dim3((unsigned)(((n_items + 7) >> 3) << 3)), dim3(THREADS), splat_lds, st, src_c,
-                       (const Rec*)recs, (const int*)table, tstride, g, nSl, count_mode, cap, (int)n_items, out);
+                       (const Rec*)recs, (const int*)table, g, nSl, count_mode, cap, (int)n_items, out);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }
@@ -1138,9 +1015,6 @@ int run_near(const T* events, const int64_t* seg_off, int n_seg, int64_t max_seg
 }  // namespace
 
 extern "C" {
-
-// development hook (not part of include/oess.h): A/B of the fused launch against the two-kernel path on one box
-void oess_dev_voxelizer_fuse(int G) { g_tri_fuse_G = G; }
 
 size_t oess_voxelize_workspace_bytes(int64_t n_events, int n_seg, int64_t max_seg_len, int C, int H, int W,
                                      int crop_rows) {

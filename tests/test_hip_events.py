@@ -286,51 +286,3 @@ def test_e2vid_voxel_grid_golden(golden_events):
     with pytest.raises(RuntimeError):
         iu.events_to_voxel_grid_pytorch(ev, 5, W, H, torch.device("cpu"))
 
-
-@pytest.mark.parametrize("G", [1, 2, 4])
-def test_fused_launch_equals_two_kernel_path(G):
-    """The chunk-pipelined single launch (sort of chunk k+1 resident next to the splat of chunk k, dependency by per-segment
-    completion counters, write-through stores across the XCD L2s) against the two-kernel path on the same events: ragged
-    segments incl. empty and multi-slice ones, both sources, count mode; bit-identical outputs (fixed-point accumulation is
-    order independent), plus the oracle on a few segments; repeated launches reuse the workspace."""
-    import ctypes
-    from openess_amd import _lib, hip
-    dbg = ctypes.CDLL(_lib.LIB_PATH)
-    rng = np.random.default_rng(31 + G)
-    C, H, W, crop = 5, 120, 200, 8
-    lens = [5000, 0, 1, 2500, 37, 3000, 4100, 2048, 2049, 6000, 0, 777, 4096, 1500, 9000, 3]
-    N = sum(lens)
-    off = np.concatenate([[0], np.cumsum(lens)])
-    x = rng.uniform(-2, W + 1, N).astype(np.float32)
-    y = rng.uniform(-2, H + 1, N).astype(np.float32)
-    p = rng.integers(0, 2, N).astype(np.float32)
-    t = np.empty(N, np.float32)
-    for i, n in enumerate(lens):
-        if n:
-            tt = np.sort(rng.uniform(0, 1, n)).astype(np.float32)
-            tt[0], tt[-1] = 0, 1 if n > 1 else 0
-            t[off[i]:off[i + 1]] = tt
-    xr, yr, tr, pr = synth.dsec_raw_events(N, H, W, seed=5 + G)
-    rmap = synth.rectify_map(H, W)
-    so = seg(*lens)
-    try:
-        for cm in (False, True):
-            outs, raws = [], []
-            for g in (0, G, G):
-                dbg.oess_dev_voxelizer_fuse(g)
-                outs.append(hip.voxelize_trilinear(dev(x), dev(y), dev(p), dev(t), so, C, H, W, crop_rows=crop, count_mode=cm))
-                raws.append(hip.voxelize_dsec_raw(dev(xr), dev(yr), dev(tr), dev(pr), dev(rmap[None]),
-                                                  torch.zeros(len(lens), dtype=torch.int32).cuda(), so, C, H, W, crop_rows=crop,
-                                                  count_mode=cm))
-            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
-            assert torch.equal(raws[0], raws[1]) and torch.equal(raws[1], raws[2])
-            got = outs[1].cpu().numpy()
-            for i in (0, 3, 9, 14):
-                s, e = off[i], off[i + 1]
-                ref = oe.voxelgrid_trilinear(x[s:e], y[s:e], p[s:e], t[s:e], C, H, W, count_mode=cm)[:, :H - crop]
-                if cm:
-                    assert np.array_equal(got[i * C:(i + 1) * C], ref), i
-                else:
-                    np.testing.assert_allclose(got[i * C:(i + 1) * C], ref, rtol=0, atol=ATOL)
-    finally:
-        dbg.oess_dev_voxelizer_fuse(4)

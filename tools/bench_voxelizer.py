@@ -20,12 +20,7 @@ def main():
     ap.add_argument("--raw", type=int, default=1)
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--h2d", type=int, default=0, help="1: time the pinned-host -> device copy of the raw columns with every batch")
-    ap.add_argument("--fuse", type=int, default=-1, help="development: segments per chunk of the fused launch (0 = two kernels)")
     a = ap.parse_args()
-    if a.fuse >= 0:
-        from openess_amd import _lib
-        import ctypes
-        ctypes.CDLL(_lib.LIB_PATH).oess_dev_voxelizer_fuse(a.fuse)
     C, H, W, crop, nwin, n_per, B = 5, 480, 640, 40, 20, 100000, a.B
     xs, ys, ts, ps = [], [], [], []
     for b in range(B):
@@ -70,7 +65,7 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
     alg = B * (16 * nwin * n_per + 4 * nwin * C * H * W)
-    print(f"voxelize B={B} raw={a.raw} h2d={a.h2d} fuse={a.fuse}: {ms:.3f} ms/batch  algorithmic {alg / 1e9:.3f} GB -> {alg / ms / 1e6:.1f} GB/s "
+    print(f"voxelize B={B} raw={a.raw} h2d={a.h2d}: {ms:.3f} ms/batch  algorithmic {alg / 1e9:.3f} GB -> {alg / ms / 1e6:.1f} GB/s "
           f"({alg / ms / 1e6 / 8000 * 100:.1f}% of 8 TB/s)  {B / ms * 1000:.0f} event-frames/s")
 
 
