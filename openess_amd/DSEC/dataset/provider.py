@@ -43,7 +43,7 @@ class DatasetProvider:
     def __init__(self, dataset_path, mode='train', event_representation='voxel_grid', nr_events_data=5, delta_t_per_data=20,
                  nr_events_window=-1, nr_bins_per_data=5, require_paired_data=False, normalize_event=False, separate_pol=False,
                  semseg_num_classes=11, augmentation=False, fixed_duration=False, resize=False, config_option='', pl_sources='',
-                 superpixel_sources='', skip_ratio=1, if_sam_distillation=False):
+                 superpixel_sources='', skip_ratio=1, if_sam_distillation=False, device_png=False):
         dataset_path = Path(dataset_path)
         train_path, val_path = dataset_path / 'train', dataset_path / 'test'
         assert dataset_path.is_dir(), str(dataset_path)
@@ -53,7 +53,7 @@ class DatasetProvider:
         def sequences(path, names, mode_, **kw):
             return [Sequence(child, mode_, event_representation, nr_events_data, delta_t_per_data, nr_events_window, nr_bins_per_data,
                              require_paired_data, normalize_event, separate_pol, semseg_num_classes, augmentation, fixed_duration,
-                             resize=resize, config_option=config_option, pl_sources=pl_sources, **kw)
+                             resize=resize, config_option=config_option, pl_sources=pl_sources, device_png=device_png, **kw)
                     for child in path.iterdir() if any(k in str(child) for k in names)]
         if mode == 'train':
             self.train_dataset = DSECConcat(sequences(train_path, TRAIN_SEQUENCES, 'train', superpixel_sources=superpixel_sources,

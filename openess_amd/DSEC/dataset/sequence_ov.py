@@ -27,7 +27,11 @@ class Sequence(Dataset):
     def __init__(self, seq_path, mode='train', event_representation='voxel_grid', nr_events_data=5, delta_t_per_data=20,
                  nr_events_per_data=100000, nr_bins_per_data=5, require_paired_data=False, normalize_event=False,
                  separate_pol=False, semseg_num_classes=11, augmentation=False, fixed_duration=False, remove_time_window=250,
-                 resize=False, config_option='', pl_sources='', superpixel_sources='', skip_ratio=1, if_sam_distillation=False):
+                 resize=False, config_option='', pl_sources='', superpixel_sources='', skip_ratio=1, if_sam_distillation=False,
+                 device_png=False):
+        # device_png (extension): label / pseudo-label / superpixel maps leave __getitem__ as the PNG FILE BYTES and are
+        # decoded for the whole batch on the GPU (hip.png_decode_gray8_batch in BaseTrainer.prepare_batch), flips included
+        self.device_png = bool(device_png)
         seq_path = Path(seq_path)
         assert nr_bins_per_data >= 1
         assert seq_path.is_dir()
@@ -152,23 +156,41 @@ class Sequence(Dataset):
             recon = _io.image_to_chw_float(p.split('left/')[0] + 'left/' + name)
         return file_path, frame, recon
 
+    # ---- 8-bit maps: host tensors (the reference's path) or, with device_png, the undecoded file bytes
+    def _map(self, path):
+        if self.device_png:
+            return {'png': torch.from_numpy(np.fromfile(str(path), dtype=np.uint8)), 'flip': False,
+                    'hw': (self.height - self.crop_rows, self.width)}
+        return torch.tensor(_io.load_png(str(path))).squeeze(0).long()
+
+    def _ones_map(self, like):
+        if isinstance(like, dict):
+            return torch.ones(like['hw'], dtype=torch.int64)
+        return torch.ones_like(like)
+
+    @staticmethod
+    def _flip_map(m):
+        if isinstance(m, dict):
+            return dict(m, flip=not m['flip'])
+        return torch.flip(m, [1])
+
     def __getitem__(self, index):
         label_path = self.label_pathstrings[index]
-        label_tensor = torch.from_numpy(self.get_label(label_path)).long()
+        label_tensor = self._map(label_path) if self.device_png else torch.from_numpy(self.get_label(label_path)).long()
         events = self.raw_events(index) if self.config_option in ('recon2voxel', 'frame2voxel') else None
         file_path, frame, recon = self._side_inputs(label_path)
         if self.mode == 'train':
             pl_path = file_path.replace('semantic/', self.pl_sources + '/').replace('11classes/', '')
-            pl = torch.tensor(_io.load_png(pl_path)).squeeze(0).long()
+            pl = self._map(pl_path)
         else:
-            pl = torch.ones_like(label_tensor)
+            pl = self._ones_map(label_tensor)
         if len(self.superpixel_sources) > 1:
             sp_path = file_path.replace('semantic/', self.superpixel_sources + '/').replace('11classes/', '')
             if self.superpixel_sources.split('_')[1] == 'slic':
                 sp_path = sp_path.replace('.png', '_slic_100.png')
-            superpixel = torch.tensor(_io.load_png(sp_path)).long()
+            superpixel = self._map(sp_path) if self.device_png else torch.tensor(_io.load_png(sp_path)).long()
         else:
-            superpixel = torch.ones_like(label_tensor)
+            superpixel = self._ones_map(label_tensor)
         sam_feat = torch.ones((256, 64, 64))
         opt = self.config_option
         if opt not in ('recon2voxel', 'frame2voxel', 'frame2recon', 'recon_only'):
@@ -178,14 +200,14 @@ class Sequence(Dataset):
             if random.random() >= 0.5:
                 if events is not None:
                     events['flip'] = True                                          # torch.flip(event_tensor, [2]) after voxelization
-                label_tensor = torch.flip(label_tensor, [1])
+                label_tensor = self._flip_map(label_tensor)
                 if recon is not None and opt != 'frame2voxel':
                     recon = torch.flip(recon, [2])
                 if frame is not None and opt in ('frame2voxel', 'frame2recon'):
                     frame = torch.flip(frame, [2])
                 if opt != 'recon_only':
-                    pl = torch.flip(pl, [1])
-                superpixel = torch.flip(superpixel, [1])
+                    pl = self._flip_map(pl)
+                superpixel = self._flip_map(superpixel)
                 sam_feat = torch.flip(sam_feat, [2])
             if opt == 'frame2recon':
                 if random.random() >= 0.5:

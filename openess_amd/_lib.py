@@ -85,6 +85,8 @@ SIGNATURES = {
     "oess_conv2d_fwd_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "oess_norm_tile_stats_apply_nhwc_bf16": (c_int, [c_vp, c_int, c_int, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_ll,
                                                      c_vp, c_ll, c_int, c_ll, c_vp, c_ll, c_vp]),
+    "oess_png_decode_scratch_bytes": (c_sz, [c_ll, c_int, c_int, c_int]),
+    "oess_png_decode_gray8_batch": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, c_vp]),
     "oess_norm_reduce_finalize_tile_stats": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_f,
                                                      c_vp, c_vp, c_vp, c_vp, c_vp]),
 }

@@ -10,7 +10,8 @@ from ..DSEC.dataset.provider import DatasetProvider
 def DSECEvents(dsec_dir, nr_events_data=1, delta_t_per_data=50, nr_events_window=-1, augmentation=False, mode='train',
                task='segmentation', event_representation='voxel_grid', nr_bins_per_data=5, require_paired_data=False,
                separate_pol=False, normalize_event=False, semseg_num_classes=11, fixed_duration=False, resize=False,
-               config_option='', pl_sources='', superpixel_sources='', skip_ratio=1, if_sam_distillation=False):
+               config_option='', pl_sources='', superpixel_sources='', skip_ratio=1, if_sam_distillation=False,
+               device_png=False):
     dsec_dir = Path(dsec_dir)
     assert dsec_dir.is_dir()
     provider = DatasetProvider(dsec_dir, mode, event_representation=event_representation, nr_events_data=nr_events_data,
@@ -19,7 +20,7 @@ def DSECEvents(dsec_dir, nr_events_data=1, delta_t_per_data=50, nr_events_window
                                normalize_event=normalize_event, separate_pol=separate_pol, semseg_num_classes=semseg_num_classes,
                                augmentation=augmentation, fixed_duration=fixed_duration, resize=resize, config_option=config_option,
                                pl_sources=pl_sources, superpixel_sources=superpixel_sources, skip_ratio=skip_ratio,
-                               if_sam_distillation=if_sam_distillation)
+                               if_sam_distillation=if_sam_distillation, device_png=device_png)
     return provider.get_train_dataset() if mode == 'train' else provider.get_val_dataset()
 
 
@@ -28,7 +29,7 @@ def build_from_settings(s):
               nr_events_window=s.nr_events_window_b, event_representation=s.event_representation_b,
               nr_bins_per_data=s.nr_temporal_bins_b, separate_pol=s.separate_pol_b, normalize_event=s.normalize_event_b,
               semseg_num_classes=s.semseg_num_classes, fixed_duration=s.fixed_duration_b, config_option=s.config_option,
-              pl_sources=getattr(s, 'pl_sources', ''))
+              pl_sources=getattr(s, 'pl_sources', ''), device_png=getattr(s, 'device_png_decode', False))
     train = DSECEvents(augmentation=s.data_augmentation_train, mode='train', require_paired_data=s.require_paired_data_train_b,
                        superpixel_sources=getattr(s, 'superpixel_sources', ''), skip_ratio=s.skip_ratio,
                        if_sam_distillation=getattr(s, 'if_sam_distillation', False), **kw)

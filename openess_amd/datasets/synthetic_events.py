@@ -87,7 +87,13 @@ def collate(samples):
     n = len(samples[0])
     if n not in (6, 7):
         raise ValueError(f"dataset tuples have 6 (DDD17) or 7 (DSEC) items, got {n}")
-    rest = [torch.stack([s[i] for s in samples]) for i in range(1, n - 1)]
+    def stack(i):
+        col = [s[i] for s in samples]
+        if isinstance(col[0], dict) and 'png' in col[0]:      # undecoded 8-bit maps (device_png): the files back to back
+            return {'png_bytes': torch.cat([c['png'] for c in col]), 'png_lengths': [int(c['png'].numel()) for c in col],
+                    'flip': [bool(c['flip']) for c in col], 'hw': tuple(col[0]['hw'])}
+        return torch.stack(col)
+    rest = [stack(i) for i in range(1, n - 1)]
     if n == 6:                     # DDD17 has no sam_feat (ddd17_events_loader.py:290): the batch ALWAYS carries the 7-slot layout
         rest = rest[:4] + [None]   # (first, label, frame | recon, pl, superpixel, sam_feat | None, file_paths); nothing downstream guesses
     return (batch0, *rest, [s[n - 1] for s in samples])

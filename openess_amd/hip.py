@@ -144,6 +144,38 @@ def event_histogram(events, seg_offsets, H, W):
     return out
 
 
+# ------------------------------------------------------------------------------------------ f3: PNG maps
+def png_decode_gray8_batch(files, lengths, H, W, flips=None, out=None):
+    """Decode a batch of 8-bit single-channel PNG files on the GPU.  files: uint8 1-D (device) = the files back to back;
+    lengths: host sequence of their byte lengths; flips: optional host sequence of bools (horizontal mirror per image).
+    Returns (maps int64 [n, H, W], status int32 [n] on the device: 0 = ok, else the map is all 255)."""
+    lib = _lib.load()
+    _need_gpu(files)
+    if files.dtype != torch.uint8 or files.ndim != 1 or not files.is_contiguous():
+        raise ValueError("files must be a contiguous 1-D uint8 tensor")
+    n = len(lengths)
+    if n == 0 or int(sum(lengths)) > files.numel():
+        raise ValueError("lengths do not match the byte tensor")
+    offs, scr, a, b = [0], [], 0, 0
+    for L in lengths:
+        a += int(L)
+        offs.append(a)
+        scr.append(b)
+        b += ((int(L) + 15) // 16) * 16 + H * (W + 1) + 16
+    meta = torch.tensor(offs + scr, dtype=torch.int64).to(files.device, non_blocking=True)
+    need = lib.oess_png_decode_scratch_bytes(a, n, H, W)
+    ws = _workspace(max(need, b + 256), files.device, tag=("png", torch.cuda.current_stream(files.device).cuda_stream))
+    fl = None
+    if flips is not None and any(flips):
+        fl = torch.tensor([1 if f else 0 for f in flips], dtype=torch.uint8).to(files.device, non_blocking=True)
+    if out is None:
+        out = torch.empty((n, H, W), dtype=torch.int64, device=files.device)
+    status = torch.empty(n, dtype=torch.int32, device=files.device)
+    _lib.check(lib.oess_png_decode_gray8_batch(_ptr(files), _ptr(meta), n, H, W, _ptr(fl), _ptr(out), _ptr(ws), ws.numel(),
+                                               meta[n + 1:].data_ptr(), _ptr(status), _stream()), "oess_png_decode_gray8_batch")
+    return out, status
+
+
 # ------------------------------------------------------------------------------------------ K2
 def masked_normalize(x, out=None):
     """EventPreprocessor / normalize_voxel_grid on a dense float32 tensor (whole-tensor statistics)."""

@@ -185,6 +185,12 @@ class BaseTrainer(object):
         if len(sample_batched) != 7:            # datasets.synthetic_events.collate emits the 7-slot layout for every dataset
             raise ValueError(f"prepare_batch expects collate's 7-slot batch, got {len(sample_batched)} items")
         rest = [t.to(self.device, non_blocking=True) if torch.is_tensor(t) else t for t in sample_batched[1:]]
+        for i, t in enumerate(rest):            # undecoded 8-bit PNG maps (device_png): one batched GPU decode per slot, flips included
+            if isinstance(t, dict) and 'png_bytes' in t:
+                maps, status = hip.png_decode_gray8_batch(t['png_bytes'].to(self.device, non_blocking=True), t['png_lengths'],
+                                                          t['hw'][0], t['hw'][1], t['flip'])
+                rest[i] = maps
+                self.png_status = status        # device tensor, non-zero = that map was filled with the ignore index (inspect off the hot path)
         ds = self._voxel_ds[split]
         if isinstance(first, dict) and 'events_list' in first:            # DDD17: int64 [N,4] rows per sample
             first = ds.voxelize_batch(first['events_list'], self.device, flips=first.get('flip'))
@@ -219,7 +225,8 @@ class BaseTrainer(object):
         S = None
         if sp is not None and getattr(s, 'if_spatial_contrastive', False):
             sps = getattr(s, 'superpixel_size', 100)          # host-side row count: no device sync in the step
-            S = int((sample_batched[4] + torch.arange(sample_batched[4].shape[0])[:, None, None] * sps).max()) + 1
+            if torch.is_tensor(sample_batched[4]):
+                S = int((sample_batched[4] + torch.arange(sample_batched[4].shape[0])[:, None, None] * sps).max()) + 1
         return (first, *rest, S)
 
     # ------------------------------------------------------------------ loops (base_trainer_ov.py:358-448)

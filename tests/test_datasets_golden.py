@@ -310,3 +310,34 @@ def test_train_py_on_real_dataset_layout(dataset, dsec_root, ddd17_root, tmp_pat
     assert trainer.step_count == n_train // 2 and 'Epoch_0.pt' in os.listdir(str(tmp_path))
     trainer.valEpochs()
     assert 0.0 <= float(trainer.last_val_metrics['miou']) <= 100.0
+
+
+@pytest.mark.gpu
+def test_dsec_device_png_decode_equals_host_path(dsec_root):
+    """with device_png the loader ships the label / pseudo-label / superpixel PNG files undecoded and
+    BaseTrainer.prepare_batch decodes the batch on the GPU (flips included): the tensors the step receives are bit-identical to
+    the host path's (PIL in the loader = the reference), with and without augmentation."""
+    import torch
+    from openess_amd import hip
+    from openess_amd.datasets.DSEC_events_loader import DSECEvents
+    from openess_amd.datasets.synthetic_events import collate
+    for aug in (False, True):
+        kw = dict(dsec_dir=dsec_root, **COMMON, mode='train', config_option='frame2voxel', superpixel_sources='sp_sam_rgb',
+                  augmentation=aug, fixed_duration=False, skip_ratio=1)
+        host, dev = DSECEvents(**kw), DSECEvents(**kw, device_png=True)
+        assert len(host) == len(dev)
+        idx = list(range(min(len(host), 6)))
+        items = []
+        for ds in (host, dev):
+            random.seed(5)
+            torch.manual_seed(5)
+            items.append(collate([ds[i] for i in idx]))
+        flipped = 0
+        for slot in (1, 3, 4):                                    # label, pseudo-label, superpixel
+            want, got = items[0][slot], items[1][slot]
+            assert isinstance(got, dict) and 'png_bytes' in got
+            maps, st = hip.png_decode_gray8_batch(got['png_bytes'].cuda(), got['png_lengths'], got['hw'][0], got['hw'][1], got['flip'])
+            assert int(st.abs().sum()) == 0
+            assert torch.equal(maps.cpu(), want)
+            flipped += sum(got['flip'])
+        assert (flipped > 0) == aug or not aug
