@@ -194,7 +194,7 @@ def pmc_traffic(timeout_s=420):
 
 # ------------------------------------------------------------------------------------------------ the step
 class Workload:
-    def __init__(self, name, rank, world, device, inputs, wavefront=False):
+    def __init__(self, name, rank, world, device, inputs, wavefront=False, force_buckets=False):
         from openess_amd.training.ddp import GradAllReduce, broadcast_module_states
         from openess_amd.training.pretrain_step import PretrainStep
         self.name, self.device, self.world = name, device, world
@@ -211,7 +211,8 @@ class Workload:
                                  online_teacher=self.online_teacher, wavefront=wavefront)
         if world > 1:      # identical initial weights on every rank
             broadcast_module_states(self.step.models_dict.values())
-        self.reducer = GradAllReduce([p for m in self.step.models_dict.values() for p in m.parameters()], world)
+        # force_buckets: launched by torch.distributed.run with ONE rank -> the whole bucket / hook / RCCL all-reduce path still runs
+        self.reducer = GradAllReduce([p for m in self.step.models_dict.values() for p in m.parameters()], world, force_buckets=force_buckets)
         self.voxels = [torch.empty((B, NWIN * C, H_NET, W_SENSOR), dtype=torch.float32, device=device)]
 
     def voxelize(self, ev, out):
@@ -413,12 +414,15 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # a 1-rank launch through torch.distributed.run (RANK / MASTER_PORT in the environment) also initialises RCCL and keeps the
+    # gradient reducer active: the collective path is exercised on a single GPU (tools/final_run.sh)
+    launched = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     inputs = make_inputs(rank, device)
-    wl = Workload(a.workload, rank, world, device, inputs)
+    wl = Workload(a.workload, rank, world, device, inputs, force_buckets=launched and world == 1)
     if a.child:
         wl.timed(a.steps, a.warmup)
         return
@@ -450,6 +454,9 @@ def main():
                                       f"batch {B}/GPU, random-init weights", "global_batch": world * B,
                           "parallelism": f"dp{world}"},
                "roofline": roof}
+        if launched:
+            out["rccl"] = {"initialised": True, "world": world, "reducer_active": bool(wl.reducer.active),
+                           "buckets": len(wl.reducer.buckets), "bucket_bytes": wl.reducer.exposed_bytes()}
     # ---- ingest-inclusive rate of the same workload (all ranks take part: the reducer is a collective)
     if extras:
         n_in = max(10, a.steps // 4)
@@ -509,7 +516,7 @@ def main():
             except Exception as e:      # the baseline must never cost the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 

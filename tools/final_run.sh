@@ -1,13 +1,16 @@
 # Round-end measurement set on the GPU box (run through gpurun from the repo root); results land in gpurun_out/fin/.
-# Everything under profiles/ is copied from here (tools/collect_profiles.py).
+# Everything under profiles/ is copied from here (tools/collect_profiles.py <round>).
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
+export HSA_ENABLE_IPC_MODE_LEGACY=0
 O=gpurun_out/fin
 rm -rf $O; mkdir -p $O
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest_gpu.txt
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
-timeout 900 python bench.py > $O/bench.txt 2>&1
+timeout 1200 python bench.py > $O/bench.txt 2>&1
+# RCCL call path with ONE rank (the box has one GPU): torch.distributed.run -> nccl process group -> bucketed all-reduce per step
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --no-pmc --no-extras > $O/bench_torchrun_world1.txt 2>&1
 for wl in frame2voxel_pixel_distill frame2voxel_full frame2recon_full; do
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -o step -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-extras --workload $wl > $O/prof_$wl.txt 2>&1
 done
@@ -19,6 +22,11 @@ for r in 1 0; do
 done
 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_mfma -o p -- python bench.py --child --steps 1 --warmup 1 > $O/pmc_mfma.txt 2>&1
 python tools/mfma_util.py $O/pmc_mfma $O/mfma_util.json > $O/mfma_util.txt 2>&1 || true
+timeout 600 bash tools/pmc_traffic.sh "python tools/bench_voxelizer.py --raw 1 --iters 5" "tri_sort|tri_splat" > $O/voxelizer_pmc.txt 2>&1
+{ timeout 300 python tools/bench_train_loop.py; timeout 300 python tools/bench_train_loop.py --no-prefetch; } > $O/train_loop.txt 2>&1
+timeout 300 python tools/bench_png.py > $O/png.txt 2>&1
+timeout 300 python tools/bench_stage.py deeplab_fwd --breakdown > $O/deeplab_breakdown.txt 2>&1
+timeout 300 python tools/bench_segmean.py > $O/segmean.txt 2>&1 || true
 find $O -name "*_kernel_trace.csv" -delete
 find $O -name "*counter_collection.csv" -size +8M -delete
 find $O -name "*.csv" -size +20M -delete
