@@ -4,6 +4,7 @@
 // All are single-pass-over-HBM streaming kernels: 16-byte loads per lane, wave-shuffle + LDS block
 // reductions, one global atomic per (workgroup, accumulator).  No MFMA (integer / byte / fp32 work).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 #include "oess.h"
@@ -293,44 +294,52 @@ __global__ __launch_bounds__(SEGV_THREADS) void segmean_fwd_vec_kernel(const voi
         }
     };
     constexpr int U = 8;
-    for (int64_t p = g_beg; p < g_end; p += U) {
-        float v[U][CPL];
-        int64_t id[U];
+    // Software-pipelined: the U row loads (and ids) of iteration i+1 are issued BEFORE iteration i is walked.  Without it an
+    // iteration was "issue U loads, wait for all of them, walk U pixels" -- one memory latency per 8 pixels of every lane
+    // group, which is why the bf16 features (half the bytes per pixel) took exactly as long as the fp32 ones.
+    using RawRow = typename std::conditional<BF16, uint4, float4>::type;
+    RawRow cur_r[U], nxt_r[U];
+    int64_t cur_id[U], nxt_id[U];
+    auto issue = [&](int64_t p, RawRow (&r)[U], int64_t (&id)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t pu = p + u;
             const bool ok = pu < g_end;
-            id[u] = ok ? ids[pu] : cur;
-            if (ok) {
-                if constexpr (BF16) {
-                    union { uint4 q4; uint16_t h[8]; } r;
-                    r.q4 = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(feat) + pu * Cf + sub * 8);
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) v[u][c] = bf16_to_f32(r.h[c]);
-                } else {
-                    const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(feat) + pu * Cf + sub * 4);
-                    v[u][0] = r.x; v[u][1] = r.y; v[u][2] = r.z; v[u][3] = r.w;
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < CPL; ++c) v[u][c] = 0.f;
-            }
+            id[u] = ok ? ids[pu] : (int64_t)-1;
+            const int64_t pc = ok ? pu : (g_end > g_beg ? g_end - 1 : p_beg);          // clamped: always a valid row of this chunk
+            if constexpr (BF16) r[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(feat) + pc * Cf + sub * 8);
+            else r[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(feat) + pc * Cf + sub * 4);
         }
+    };
+    if (g_beg < g_end) issue(g_beg, cur_r, cur_id);
+    for (int64_t p = g_beg; p < g_end; p += U) {
+        if (p + U < g_end) issue(p + U, nxt_r, nxt_id);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (p + u < g_end) {
-                if (id[u] != cur) {
+                float v[CPL];
+                if constexpr (BF16) {
+                    union { uint4 q4; uint16_t h[8]; } r;
+                    r.q4 = cur_r[u];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] = bf16_to_f32(r.h[c]);
+                } else {
+                    v[0] = cur_r[u].x; v[1] = cur_r[u].y; v[2] = cur_r[u].z; v[3] = cur_r[u].w;
+                }
+                if (cur_id[u] != cur) {
                     flush();
-                    cur = id[u];
+                    cur = cur_id[u];
 #pragma unroll
                     for (int c = 0; c < CPL; ++c) run[c] = 0.f;
                     run_n = 0;
                 }
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) run[c] += v[u][c];
+                for (int c = 0; c < CPL; ++c) run[c] += v[c];
                 run_n += 1;
             }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { cur_r[u] = nxt_r[u]; cur_id[u] = nxt_id[u]; }
     }
     flush();
     __syncthreads();
