@@ -113,10 +113,11 @@ int oess_masked_normalize_slice_f32(const float* in, float* out, int B, int Ctot
  * ------------------------------------------------------------------------------------------ */
 int oess_segment_mean_fwd(const void* feat, int is_bf16, const int64_t* ids, int64_t P, int64_t pixels_per_sample,
                           int superpixel_size, int Cf, int S, float* k, float* count, oess_stream_t stream);
-/* grad_feat[p, :] = grad_k[id(p), :] / (count[id(p)] + 1e-6)  (float32 or bf16 output) */
+/* grad_feat[p, :] = grad_k[id(p), :] / (count[id(p)] + 1e-6)  (float32 or bf16 output).  workspace (nullable): S * Cf *
+ * sizeof(output element) bytes, 16-byte aligned: the S x Cf quotients are then formed once and the per-pixel pass is a row gather. */
 int oess_segment_mean_bwd(const float* grad_k, const float* count, const int64_t* ids, int64_t P,
                           int64_t pixels_per_sample, int superpixel_size, int Cf, int S,
-                          void* grad_feat, int is_bf16, oess_stream_t stream);
+                          void* grad_feat, int is_bf16, void* workspace, size_t workspace_bytes, oess_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K9  TaskLoss = DiceLoss + CrossEntropyLoss(ignore_index) forward and backward.

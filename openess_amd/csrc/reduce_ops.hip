@@ -391,6 +391,38 @@ __global__ __launch_bounds__(THREADS) void segmean_bwd_kernel(const float* __res
     }
 }
 
+// Backward with the divisions hoisted: every pixel of a superpixel receives the SAME row gk[id] / (count[id] + 1e-6), so the
+// S x Cf quotients (IEEE divides, ~25 instructions each with correctly-rounded division) are formed once per call -- already
+// rounded to the output dtype -- and the per-pixel pass is a pure row gather: one 16-byte load from the (L2-resident) table and
+// one non-temporal 16-byte store per lane.  The per-pixel form above spent ~100 VALU instructions per 8 bytes written.
+template <bool BF16>
+__global__ __launch_bounds__(THREADS) void segmean_bwd_table_kernel(const float* __restrict__ gk, const float* __restrict__ count, int S,
+                                                                    int Cf, void* __restrict__ table) {
+    const int64_t n = (int64_t)S * Cf;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS) {
+        const float q = gk[i] / __fadd_rn(count[i / Cf], 1e-6f);
+        if (BF16) reinterpret_cast<uint16_t*>(table)[i] = f32_to_bf16(q); else reinterpret_cast<float*>(table)[i] = q;
+    }
+}
+
+// lanes per pixel = row bytes / 16; blockIdx.y = sample; out-of-table ids give zero rows
+__global__ __launch_bounds__(THREADS) void segmean_bwd_gather_kernel(const uint4* __restrict__ table, const int64_t* __restrict__ ids,
+                                                                     int64_t pps, int sps, int lpp, int S, uint4* __restrict__ gfeat) {
+    typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
+    const int rows = THREADS / lpp;
+    const int lane_c = threadIdx.x % lpp, row = threadIdx.x / lpp;
+    if (row >= rows) return;
+    const int64_t b = blockIdx.y;
+    const int64_t id_off = b * (int64_t)sps;
+    for (int64_t q = (int64_t)blockIdx.x * rows + row; q < pps; q += (int64_t)gridDim.x * rows) {
+        const int64_t p = b * pps + q;
+        const int64_t gid = ids[p] + id_off;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (gid >= 0 && gid < S) v = table[gid * lpp + lane_c];
+        __builtin_nontemporal_store(u32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_nt*>(gfeat + p * lpp + lane_c));
+    }
+}
+
 // ------------------------------------------------------------------------------------------ K9
 template <bool BF16>
 __device__ __forceinline__ float load_logit(const void* base, int64_t idx) {
@@ -648,12 +680,31 @@ int oess_segment_mean_fwd(const void* feat, int is_bf16, const int64_t* ids, int
 
 int oess_segment_mean_bwd(const float* grad_k, const float* count, const int64_t* ids, int64_t P,
                           int64_t pixels_per_sample, int superpixel_size, int Cf, int S, void* grad_feat, int is_bf16,
-                          oess_stream_t stream) {
+                          void* workspace, size_t workspace_bytes, oess_stream_t stream) {
     if (!grad_k || !count || !ids || !grad_feat || P <= 0 || pixels_per_sample <= 0 || Cf <= 0 || (Cf & 3) || S <= 0)
         return OESS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if ((Cf >> 2) > THREADS || P % pixels_per_sample != 0) return OESS_EINVAL;
     const int64_t nb = P / pixels_per_sample;
+    {   // quotient table + row gather when the rows are whole 16-byte lanes and the caller passed the table's scratch
+        const size_t row_bytes = (size_t)Cf * (is_bf16 ? 2 : 4);
+        const int lpp = (int)(row_bytes / 16);
+        if (workspace && workspace_bytes >= (size_t)S * row_bytes && (row_bytes & 15) == 0 && lpp >= 1 && lpp <= THREADS &&
+            ((uintptr_t)workspace & 15) == 0 && ((uintptr_t)grad_feat & 15) == 0) {
+            const unsigned tg = stream_grid((int64_t)S * Cf, THREADS);
+            if (is_bf16) hipLaunchKernelGGL(segmean_bwd_table_kernel<true>, dim3(tg), dim3(THREADS), 0, st, grad_k, count, S, Cf, workspace);
+            else hipLaunchKernelGGL(segmean_bwd_table_kernel<false>, dim3(tg), dim3(THREADS), 0, st, grad_k, count, S, Cf, workspace);
+            const int rows = THREADS / lpp;
+            int64_t gx = (pixels_per_sample + (int64_t)rows * 8 - 1) / ((int64_t)rows * 8);
+            const int64_t capx = (8192 + nb - 1) / nb;
+            if (gx > capx) gx = capx;
+            if (gx < 1) gx = 1;
+            hipLaunchKernelGGL(segmean_bwd_gather_kernel, dim3((unsigned)gx, (unsigned)nb), dim3(THREADS), 0, st, (const uint4*)workspace, ids,
+                               pixels_per_sample, superpixel_size, lpp, S, (uint4*)grad_feat);
+            OESS_HIP(hipGetLastError());
+            return OESS_OK;
+        }
+    }
     const int rows = THREADS / (Cf >> 2);
     int64_t gx = (pixels_per_sample + (int64_t)rows * 4 - 1) / ((int64_t)rows * 4);
     const int64_t capx = (16384 + nb - 1) / nb;

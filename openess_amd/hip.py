@@ -228,8 +228,10 @@ class _SegmentMean(torch.autograd.Function):
         P, Cf, pps, sps, S, dtype = ctx.meta
         gk = gk.contiguous().float()
         gfeat = torch.empty((P, Cf), dtype=dtype, device=gk.device)
+        table = torch.empty((S, Cf), dtype=dtype, device=gk.device)          # gk / (count + 1e-6), formed once per call
         _lib.check(lib.oess_segment_mean_bwd(_ptr(gk), _ptr(cnt), _ptr(ids), P, pps, sps, Cf, S, _ptr(gfeat),
-                                             int(dtype == torch.bfloat16), _stream()), "oess_segment_mean_bwd")
+                                             int(dtype == torch.bfloat16), _ptr(table), table.numel() * table.element_size(),
+                                             _stream()), "oess_segment_mean_bwd")
         return gfeat, None, None, None, None
 
 
