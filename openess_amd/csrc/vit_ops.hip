@@ -4,7 +4,7 @@
 //   * multi-head self attention softmax(Q K^T / sqrt(d)) V for head dimension 64 from the fused in_proj output
 //     [B, L, 3C] (nn.MultiheadAttention's packed q | k | v layout), fp32 online softmax.
 // The attention is an MFMA flash-attention kernel (a first VALU version, 4 lanes per query, took 16-18 ms per tower forward
-// against 1.25 ms and has been removed).
+// and has been removed; the round-2 MFMA kernel with 32-key tiles, two barriers per tile and transposed V stores took 1.26 ms).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -94,28 +94,34 @@ __global__ __launch_bounds__(THREADS) void layernorm_vec_kernel(const uint16_t* 
 
 // ---------------------------------------------------------------------------------------------
 // MFMA flash attention for head dimension 64 (v_mfma_f32_32x32x16_bf16).
-// A wave owns 32 queries; per tile of 32 keys it computes the TRANSPOSED score tile S^T = K Q^T (4 MFMAs), so a lane
-// (query column q = lane & 31, half hi = lane >> 5) holds 16 scores of ITS query in registers:
-// keys K(e) = (e & 3) + 8 (e >> 2) + 4 hi.  The online-softmax max / sum are then register reductions plus one
-// cross-half shuffle.  P^T needs no data movement to become the B operand of O^T = V^T P^T (4 MFMAs): MFMA k-slot
-// (kk, hi, j) is simply DEFINED as key (j & 3) + 8 (2 kk + (j >> 2)) + 4 hi - the lane's own registers 8 kk .. 8 kk + 7 -
-// and the V tile is stored in LDS transposed with its key axis permuted the same way.
-// LDS pitches (72 / 40 elements) make both fragment reads conflict-free ds_read_b128.
+// A wave owns 32 queries; per tile of 64 keys it computes the TRANSPOSED score tiles S^T = K Q^T (2 x 4 MFMAs), so a lane
+// (query column q = lane & 31, half hi = lane >> 5) holds 2 x 16 scores of ITS query in registers; the online-softmax max /
+// sum are register reductions plus one cross-half shuffle.  P^T then has to be the B operand of O^T = V^T P^T (2 x 4 MFMAs),
+// whose k-slot j of lane (q, hi) is key 16 ks + 8 hi + j.  Instead of shuffling the scores into that order, the K tile is
+// stored in LDS with its rows PERMUTED (key bits 2 and 3 swapped inside each 32-key block): score register e = 8 kk + j of
+// lane (q, hi) is then key 32 sb + 16 kk + 8 hi + j, exactly the lane's own k-slots -- P^T needs no data movement.
+// The V tile stays row-major [key][d]; its transposed A fragments come from ds_read_b64_tr_b16 (semantics in conv_wgrad.hip),
+// so nothing is transposed on the store side (round 2 stored V^T with eight 2-byte LDS writes per thread and key tile).
+// Two LDS stages: the next tile's K / V rows travel HBM -> registers under the MFMAs and are parked in the other stage, ONE
+// barrier per 64 keys (round 2: two per 32 keys).  LDS pitches 144 B (K, ds_read_b128) and 192 B (V, transposing reads).
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) short abf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short abf16x4_t;
 typedef __attribute__((ext_vector_type(16))) float af32x16_t;
 constexpr int AQ = 128;                  // queries per workgroup (4 waves x 32)
-constexpr int KP = 72, VP = 40;          // LDS pitches in elements
+constexpr int AK = 64;                   // keys per tile
+constexpr int KPB = 144, VPB = 192;      // LDS row pitches in bytes
+constexpr int KST = AK * KPB, VST = AK * VPB;
 
-__device__ __forceinline__ int vt_pos(int key) {          // LDS column of a key inside the permuted V^T tile
-    const int hi = (key >> 2) & 1, low = key & 3, g = key >> 3;
-    return (g >> 1) * 16 + hi * 8 + low + 4 * (g & 1);
+__device__ __forceinline__ abf16x4_t att_tr_read(uint32_t lds_addr) {
+    abf16x4_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
+    return v;
 }
 
 __global__ __launch_bounds__(THREADS) void attention_d64_mfma_kernel(const uint16_t* __restrict__ qkv, int64_t qs, int B, int L,
                                                                      int heads, float scale, uint16_t* __restrict__ out, int64_t os) {
-    __shared__ __attribute__((aligned(16))) uint16_t lk[32 * KP];
-    __shared__ __attribute__((aligned(16))) uint16_t lvt[64 * VP];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * KST + 2 * VST];          // [K stage 0][K stage 1][V stage 0][V stage 1]
     const int C = heads * 64;
     const int qblocks = (L + AQ - 1) / AQ;
     int bid = blockIdx.x;
@@ -137,69 +143,96 @@ __global__ __launch_bounds__(THREADS) void attention_d64_mfma_kernel(const uint1
 #pragma unroll
     for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
     float m = -INFINITY, l = 0.f;
-    // staging lanes: thread -> (key row, 8-channel chunk)
+    // staging: thread -> rows (tid >> 3) and (tid >> 3) + 32 of the tile, 16-byte chunk tid & 7
     const int srow = threadIdx.x >> 3, sch = threadIdx.x & 7;
-    uint4 kreg = make_uint4(0u, 0u, 0u, 0u), vreg = kreg;
+    // LDS row of key r of a 32-key block: bits 2 and 3 of r swapped (see header)
+    const int prow = (srow & ~12) | ((srow & 4) << 1) | ((srow & 8) >> 1);
+    uint4 kreg[2], vreg[2];
     auto gload = [&](int k0) {
-        const int kj = k0 + srow;
-        kreg = make_uint4(0u, 0u, 0u, 0u); vreg = kreg;
-        if (kj < L) {
-            const uint16_t* rp = base + (int64_t)kj * qs + sch * 8;
-            kreg = *reinterpret_cast<const uint4*>(rp + C);
-            vreg = *reinterpret_cast<const uint4*>(rp + 2 * C);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kj = k0 + srow + 32 * i;
+            kreg[i] = make_uint4(0u, 0u, 0u, 0u); vreg[i] = kreg[i];
+            if (kj < L) {
+                const uint16_t* rp = base + (int64_t)kj * qs + sch * 8;
+                kreg[i] = *reinterpret_cast<const uint4*>(rp + C);
+                vreg[i] = *reinterpret_cast<const uint4*>(rp + 2 * C);
+            }
         }
     };
-    gload(0);
-    for (int k0 = 0; k0 < L; k0 += 32) {
-        __syncthreads();                                    // previous tile fully consumed
-        *reinterpret_cast<uint4*>(&lk[srow * KP + sch * 8]) = kreg;
-        {
-            union { uint4 q; uint16_t hh[8]; } u;
-            u.q = vreg;
-            const int pc = vt_pos(srow);
+    auto park = [&](int stage) {
+        unsigned char* lk = lds + stage * KST;
+        unsigned char* lv = lds + 2 * KST + stage * VST;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) lvt[(sch * 8 + i) * VP + pc] = u.hh[i];
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<uint4*>(lk + (prow + 32 * i) * KPB + sch * 16) = kreg[i];
+            *reinterpret_cast<uint4*>(lv + (srow + 32 * i) * VPB + sch * 16) = vreg[i];
         }
-        __syncthreads();
-        if (k0 + 32 < L) gload(k0 + 32);                    // next tile's global loads fly under this tile's MFMAs
-        // S^T = K Q^T
-        af32x16_t st;
+    };
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+    // transposing-read lane geometry (conv_wgrad.hip): 16-lane group g4: columns 16 (g4 & 1) + 4 (li & 3), rows 8 (g4 >> 1) + (li >> 2)
+    const int g4 = lane >> 4, li = lane & 15;
+    const uint32_t tr_off = (uint32_t)(((g4 >> 1) * 8 + (li >> 2)) * VPB + ((g4 & 1) * 16 + (li & 3) * 4) * 2);
+    const int ntiles = (L + AK - 1) / AK;
+    gload(0);
+    park(0);
+    __syncthreads();
+    if (ntiles > 1) gload(AK);
+    for (int it = 0; it < ntiles; ++it) {
+        const int k0 = it * AK, stage = it & 1;
+        const unsigned char* lk = lds + stage * KST;
+        const uint32_t lv = lds0 + 2 * KST + stage * VST;
+        // S^T = K Q^T for the two 32-key blocks of the tile
+        af32x16_t st[2];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) st[e] = 0.f;
+        for (int sb = 0; sb < 2; ++sb) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const abf16x8_t kf = *reinterpret_cast<const abf16x8_t*>(&lk[qcol * KP + 16 * kk + 8 * hi]);   // row = key (lane & 31)
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st, 0, 0, 0);
+            for (int e = 0; e < 16; ++e) st[sb][e] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const abf16x8_t kf = *reinterpret_cast<const abf16x8_t*>(lk + (32 * sb + qcol) * KPB + (16 * kk + 8 * hi) * 2);
+                st[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[sb], 0, 0, 0);
+            }
         }
         float tmax = -INFINITY;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-            if (key >= L) st[e] = -INFINITY;
-            tmax = fmaxf(tmax, st[e]);
-        }
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = k0 + 32 * sb + 16 * (e >> 3) + 8 * hi + (e & 7);       // permuted K rows: register e is this key
+                if (key >= L) st[sb][e] = -INFINITY;
+                tmax = fmaxf(tmax, st[sb][e]);
+            }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m, tmax);
         const float resc = __expf((m - m_new) * scale);
-        float p[16];
         float ps = 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { p[e] = __expf((st[e] - m_new) * scale); ps += p[e]; }
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { st[sb][e] = __expf((st[sb][e] - m_new) * scale); ps += st[sb][e]; }
         l = l * resc + ps;                                  // per-half partial sum; halves are combined at the end
         m = m_new;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { o0[e] *= resc; o1[e] *= resc; }
-        // O^T += V^T P^T
+        // O^T += V^T P^T: k-step ks covers keys 16 ks .. 16 ks + 15 of the tile = registers 8 (ks & 1) .. + 7 of block ks >> 1
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int ks = 0; ks < 4; ++ks) {
             union { abf16x8_t v; uint32_t w[4]; } pf;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pf.w[j] = pack_bf16x2(p[8 * kk + 2 * j], p[8 * kk + 2 * j + 1]);
-            const abf16x8_t v0 = *reinterpret_cast<const abf16x8_t*>(&lvt[qcol * VP + 16 * kk + 8 * hi]);          // d = lane & 31
-            const abf16x8_t v1 = *reinterpret_cast<const abf16x8_t*>(&lvt[(32 + qcol) * VP + 16 * kk + 8 * hi]);   // d = 32 + (lane & 31)
+            for (int j = 0; j < 4; ++j) pf.w[j] = pack_bf16x2(st[ks >> 1][8 * (ks & 1) + 2 * j], st[ks >> 1][8 * (ks & 1) + 2 * j + 1]);
+            const uint32_t vb = lv + (uint32_t)(16 * ks) * VPB + tr_off;
+            abf16x4_t a0l = att_tr_read(vb), a0h = att_tr_read(vb + 4 * VPB);                 // d = lane & 31
+            abf16x4_t a1l = att_tr_read(vb + 64), a1h = att_tr_read(vb + 64 + 4 * VPB);       // d = 32 + (lane & 31)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0l), "+v"(a0h), "+v"(a1l), "+v"(a1h) :: "memory");
+            const abf16x8_t v0 = __builtin_shufflevector(a0l, a0h, 0, 1, 2, 3, 4, 5, 6, 7);
+            const abf16x8_t v1 = __builtin_shufflevector(a1l, a1h, 0, 1, 2, 3, 4, 5, 6, 7);
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf.v, o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf.v, o1, 0, 0, 0);
         }
+        if (it + 1 < ntiles) park(stage ^ 1);              // the other stage was last read in iteration it - 1: every wave is past it
+        __syncthreads();
+        if (it + 2 < ntiles) gload(k0 + 2 * AK);           // flies under the next tile's MFMAs
     }
     l += __shfl_xor(l, 32, 64);
     if (qi < L) {
