@@ -141,8 +141,8 @@ __device__ __forceinline__ void finalize_one(double S, double Q, int i, int c, b
     }
 }
 
-// Fixed-order reduction of stats_kernel's partials part[chunks][2][N] (N = G*C) in double.  block = 32 columns x 8 chunk lanes;
-// lane tl adds chunks tl, tl+8, ... in order, the 8 lane sums are added 0..7: the result does not depend on scheduling.
+// Fixed-order reduction of stats_kernel's partials part[chunks][2][N] (N = G*C) in double.  block = 16 columns x 16 chunk lanes;
+// lane tl adds chunks tl, tl+16, ... in order, the 16 lane sums are added 0..15: the result does not depend on scheduling.
 // FIN = false: o1[N] = sum, o2[N] = second sum (backward: d(beta), d(gamma) / the InstanceNorm sums).
 // FIN = true : mean / rstd / scale / shift (+ running statistics when G == 1), E[x^2] - E[x]^2 in double.
 template <bool FIN>
@@ -152,21 +152,25 @@ __global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __res
                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
                                                               float momentum, float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                               float* __restrict__ scale, float* __restrict__ shift) {
-    __shared__ double red[8][32][2];
-    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    // 16 columns x 16 chunk lanes per block (a 512-chunk table is 32 iterations of two loads per lane, unrolled by 4; with 8
+    // chunk lanes x 32 columns it was 64 dependent-latency iterations: 12 us per call, 60 calls per frame2recon step)
+    __shared__ double red[16][16][2];
+    const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
     const int64_t N = (int64_t)G * C;
-    const int64_t i = (int64_t)blockIdx.x * 32 + cl;
+    const int64_t i = (int64_t)blockIdx.x * 16 + cl;
     double s1 = 0.0, s2 = 0.0;
-    if (i < N)
-        for (int t = tl; t < chunks; t += 8) {
+    if (i < N) {
+#pragma unroll 4
+        for (int t = tl; t < chunks; t += 16) {
             s1 += (double)part[((int64_t)t * 2) * N + i];
             s2 += (double)part[((int64_t)t * 2 + 1) * N + i];
         }
+    }
     red[tl][cl][0] = s1; red[tl][cl][1] = s2;
     __syncthreads();
     if (tl != 0 || i >= N) return;
 #pragma unroll
-    for (int k = 1; k < 8; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }
+    for (int k = 1; k < 16; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }
     if (!FIN) { o1[i] = (float)s1; o2[i] = (float)s2; return; }
     finalize_one(s1, s2, (int)i, (int)(i % C), running_mean != nullptr && G == 1, count, eps, gamma, beta, running_mean, running_var,
                  momentum, mean_out, rstd_out, scale, shift);
@@ -635,7 +639,7 @@ int oess_norm_stats_nhwc_bf16(const void* x, long long x_pix_stride, int G, long
     const int chunks = launch_stats<0>(st, x, x_pix_stride, nullptr, 0, nullptr, nullptr, 0, G, pixels_per_group, C, partials,
                                        partials_bytes);
     if (!chunks) return OESS_EINVAL;
-    hipLaunchKernelGGL(partials_reduce_kernel<false>, dim3((unsigned)(((int64_t)G * C + 31) / 32)), dim3(256), 0, st, partials, chunks, G,
+    hipLaunchKernelGGL(partials_reduce_kernel<false>, dim3((unsigned)(((int64_t)G * C + 15) / 16)), dim3(256), 0, st, partials, chunks, G,
                        C, sum, sumsq, 1.f, 0.f, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
@@ -652,7 +656,7 @@ int oess_norm_stats_finalize_nhwc_bf16(const void* x, long long x_pix_stride, in
     const int chunks = launch_stats<0>(st, x, x_pix_stride, nullptr, 0, nullptr, nullptr, 0, G, pixels_per_group, C, partials,
                                        partials_bytes);
     if (!chunks) return OESS_EINVAL;
-    hipLaunchKernelGGL(partials_reduce_kernel<true>, dim3((unsigned)(((int64_t)G * C + 31) / 32)), dim3(256), 0, st, partials, chunks, G,
+    hipLaunchKernelGGL(partials_reduce_kernel<true>, dim3((unsigned)(((int64_t)G * C + 15) / 16)), dim3(256), 0, st, partials, chunks, G,
                        C, nullptr, nullptr, (float)pixels_per_group, eps, gamma, beta, running_mean, running_var, momentum, mean, rstd,
                        scale, shift);
     OESS_HIP(hipGetLastError());
@@ -723,7 +727,7 @@ int oess_instnorm_bwd_nhwc_bf16(const void* x, long long x_pix_stride, const voi
     const int chunks = launch_stats<1>(st, x, x_pix_stride, dy, dy_pix_stride, mean, rstd, relu, G, pixels_per_group, C, partials,
                                        partials_bytes);
     if (!chunks) return OESS_EINVAL;
-    hipLaunchKernelGGL(partials_reduce_kernel<false>, dim3((unsigned)(((int64_t)G * C + 31) / 32)), dim3(256), 0, st, partials, chunks, G,
+    hipLaunchKernelGGL(partials_reduce_kernel<false>, dim3((unsigned)(((int64_t)G * C + 15) / 16)), dim3(256), 0, st, partials, chunks, G,
                        C, s1, s2, 1.f, 0.f, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(in_bwd_apply_kernel, apply_grid(pixels_per_group, G, C), dim3(THREADS), 0, st,
                        (const uint16_t*)x, (int64_t)x_pix_stride, (const uint16_t*)dy, (int64_t)dy_pix_stride, mean, rstd, s1,
@@ -746,7 +750,7 @@ int oess_batchnorm_bwd_nhwc_bf16(const void* x, long long x_pix_stride, const vo
     const int chunks = launch_stats<1>(st, x, x_pix_stride, dy, dy_pix_stride, mean, rstd, relu, 1, pixels, C, partials, partials_bytes,
                                        y_out, y_pix_stride);
     if (!chunks) return OESS_EINVAL;
-    hipLaunchKernelGGL(partials_reduce_kernel<false>, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, st, partials, chunks, 1, C, dbeta,
+    hipLaunchKernelGGL(partials_reduce_kernel<false>, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, st, partials, chunks, 1, C, dbeta,
                        dgamma, 1.f, 0.f, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(in_bwd_apply_kernel, apply_grid(pixels, 1, C), dim3(THREADS), 0, st, (const uint16_t*)x,
                        (int64_t)x_pix_stride, (const uint16_t*)dy, (int64_t)dy_pix_stride, mean, rstd, dbeta, dgamma, relu,
