@@ -47,6 +47,38 @@ def test_workspace_query_and_argument_validation():
     assert lib.oess_confusion_accumulate(None, None, 10, 11, 255, None, None) == -22
 
 
+def test_round3_entry_points_validate_arguments_on_the_host():
+    """Size queries and argument checks of the entry points added in round 3 (no launches)."""
+    from openess_amd import _lib
+    lib = _lib.load()
+    # split-K scratch: wanted by the ASPP geometry at the BASELINE size, not by an ordinary layer or a tiny map
+    assert lib.oess_conv2d_fwd_workspace_bytes(8, 28, 40, 2048, 256, 3, 3, 1, 12, 12, 1, 0) >= 2 * 8960 * 256 * 4
+    assert lib.oess_conv2d_fwd_workspace_bytes(8, 110, 160, 64, 256, 1, 1, 1, 0, 1, 1, 0) == 0
+    assert lib.oess_conv2d_fwd_workspace_bytes(0, 28, 40, 2048, 256, 3, 3, 1, 12, 12, 1, 0) == 0
+    assert lib.oess_norm_partials_bytes(1, 140800, 256, 0) > 0 and lib.oess_norm_partials_bytes(0, 10, 8, 0) == 0
+    assert lib.oess_png_decode_scratch_bytes(24 * 7000, 24, 440, 640) >= 24 * 440 * 641
+    assert lib.oess_png_decode_gray8_batch(None, None, 1, 8, 8, None, None, None, 0, None, None, None) == -22
+    assert lib.oess_norm_tile_stats_apply_nhwc_bf16(None, 70, 256, 8960.0, 1e-5, None, None, None, None, 0.1, None, None, None, 256,
+                                                    None, 0, 1, 8960, None, 256, None) == -22
+    assert lib.oess_norm_stats_finalize_nhwc_bf16(None, 64, 1, 100, 64, 1e-5, None, None, None, None, 0.1, None, None, None, None,
+                                                  None, 0, None) == -22
+
+
+def test_collate_keeps_undecoded_png_maps_as_one_byte_stream():
+    """device_png (SURVEY 8f-3): collate concatenates the per-sample file bytes of a slot and keeps lengths / flips / size;
+    every other slot stacks as before and the batch keeps the 7-slot layout."""
+    import torch
+    from openess_amd.datasets.synthetic_events import collate
+    def sample(i):
+        png = {'png': torch.arange(5 + i, dtype=torch.uint8), 'flip': bool(i & 1), 'hw': (4, 6)}
+        return (torch.zeros(3, 4, 6), png, torch.ones(3, 4, 6), png, torch.zeros(4, 6, dtype=torch.int64), torch.ones(2), f"p{i}")
+    b = collate([sample(0), sample(1), sample(2)])
+    assert len(b) == 7 and b[0].shape == (3, 3, 4, 6) and b[6] == ["p0", "p1", "p2"]
+    assert b[1]['png_lengths'] == [5, 6, 7] and b[1]['flip'] == [False, True, False] and b[1]['hw'] == (4, 6)
+    assert b[1]['png_bytes'].numel() == 18 and torch.equal(b[3]['png_bytes'], b[1]['png_bytes'])
+    assert b[4].shape == (3, 4, 6)
+
+
 def test_product_path_refuses_cpu_tensors():
     import torch
     from openess_amd import hip
