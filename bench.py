@@ -348,6 +348,22 @@ def stage_rooflines(wl, rank, device):
     st["voxelizer_structured_events"] = _hbm(_ev_time(lambda: wl.voxelize(ev_s, out)), VOX_BYTES,
                                              "same, 70 % of the events on 200 moving edges (SURVEY 8d locality variant)")
     del ev_s
+    # the same events through VoxelGrid.convert's OWN interface (fp32 x, y, p, t columns, rectification and time normalisation
+    # done by the caller as in the reference): the 16 B/event the algorithmic figure of SURVEY 8d counts are what it reads
+    try:
+        n_ev = wl.ev["x"].numel()
+        rm = wl.ev["maps"][0][wl.ev["y"].long(), wl.ev["x"].long()]
+        xf, yf, pf = rm[:, 0].contiguous(), rm[:, 1].contiguous(), wl.ev["p"].float()
+        tt = wl.ev["t"].view(-1, N_PER)
+        d = (tt - tt[:, :1]).double().float()
+        tf = (d / d[:, -1:]).reshape(-1).contiguous()
+        st["voxelizer_f32_interface"] = _hbm(_ev_time(lambda: hip.voxelize_trilinear(xf, yf, pf, tf, wl.ev["seg"], C, H_SENSOR, W_SENSOR, crop_rows=CROP,
+                                                                                     out=out.view(B * NWIN * C, H_NET, W_SENSOR))), VOX_BYTES,
+                                                "VoxelGrid.convert's interface: fp32 x', y', p, t_norm columns (16 B/event) already rectified / normalised by the "
+                                                "caller; no rectify gather in the kernel")
+        del rm, xf, yf, pf, tf, d
+    except Exception as e:
+        st["voxelizer_f32_interface"] = {"error": repr(e)[:200]}
     # K7 superpixel scatter-mean, forward and backward, the reference's fp32 features and this pipeline's bf16 features
     ids_rand = torch.randint(0, 256, (B, H_NET // 8, W_SENSOR // 8), device=device).repeat_interleave(8, 1).repeat_interleave(8, 2)
     for dt, tag in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):

@@ -161,18 +161,27 @@ class _ConvBNTrainFn(torch.autograd.Function):
         part = torch.empty((tiles, 2, Cout), dtype=torch.float32, device=x.device)
         y = hip.conv2d_nhwc(xn, pw.packed, None, Cout, k, k, stride, pad, dil, tile_stats=part)          # raw conv output (kept)
         st = torch.empty((4, Cout), dtype=torch.float32, device=x.device)                                  # mean, rstd, scale, shift
-        sc = hip._stats_scratch(Cout, x.device)
-        hip._lib.check(lib.oess_norm_reduce_finalize_tile_stats(part.data_ptr(), tiles, Cout, sc.buf64.data_ptr(), sc.tickets.data_ptr(),
-                                                                float(M), float(eps), gamma.data_ptr(), beta.data_ptr(),
-                                                                running_mean.data_ptr(), running_var.data_ptr(), float(momentum),
-                                                                st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(),
-                                                                hip._stream()), "oess_norm_reduce_finalize_tile_stats")
         out = torch.empty((B, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
         rn = None if residual is None else nhwc(residual)
         rps = 0 if rn is None else hip._nhwc_geom(rn)[4]
-        hip._lib.check(lib.oess_norm_apply_nhwc_bf16(y.data_ptr(), Cout, st[2].data_ptr(), st[3].data_ptr(),
-                                                     None if rn is None else rn.data_ptr(), rps, int(relu), 1, M, Cout, out.data_ptr(),
-                                                     Cout, hip._stream()), "oess_norm_apply_nhwc_bf16")
+        if tiles <= 320 and Cout % 64 == 0:
+            # small map: statistics (fixed order, double) + apply in ONE launch; mean / rstd are kept for the backward
+            hip._lib.check(lib.oess_norm_tile_stats_apply_nhwc_bf16(part.data_ptr(), tiles, Cout, float(M), float(eps), gamma.data_ptr(),
+                                                                    beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
+                                                                    float(momentum), st[0].data_ptr(), st[1].data_ptr(), y.data_ptr(), Cout,
+                                                                    None if rn is None else rn.data_ptr(), rps, int(relu), M,
+                                                                    out.data_ptr(), Cout, hip._stream()),
+                           "oess_norm_tile_stats_apply_nhwc_bf16")
+        else:
+            sc = hip._stats_scratch(Cout, x.device)
+            hip._lib.check(lib.oess_norm_reduce_finalize_tile_stats(part.data_ptr(), tiles, Cout, sc.buf64.data_ptr(), sc.tickets.data_ptr(),
+                                                                    float(M), float(eps), gamma.data_ptr(), beta.data_ptr(),
+                                                                    running_mean.data_ptr(), running_var.data_ptr(), float(momentum),
+                                                                    st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(),
+                                                                    hip._stream()), "oess_norm_reduce_finalize_tile_stats")
+            hip._lib.check(lib.oess_norm_apply_nhwc_bf16(y.data_ptr(), Cout, st[2].data_ptr(), st[3].data_ptr(),
+                                                         None if rn is None else rn.data_ptr(), rps, int(relu), 1, M, Cout, out.data_ptr(),
+                                                         Cout, hip._stream()), "oess_norm_apply_nhwc_bf16")
         ctx.save_for_backward(x, weight, gamma, y, st, out if relu else None)
         ctx.meta = (pw, k, stride, pad, dil, relu, residual is not None)
         return from_nhwc(out)
