@@ -365,7 +365,8 @@ int oess_conv2d_wgrad_bf16(const void* x, long long x_pix_stride, int B, int H, 
  * GPU-side decode of 8-bit single-channel PNG maps: pseudo-labels, superpixel ids, ground-truth labels.
  * Replaces np.array(Image.open(path)) + torch.tensor(...).long() [+ torch.flip(..., [1])] of
  * DSEC/dataset/sequence_ov.py:340-358,366-372 and datasets/ddd17_events_loader.py:228-262 for a whole batch:
- *   files    the n_images PNG files back to back (bytes as read from disk), offsets[n_images + 1] their byte offsets (device)
+ *   files    the n_images PNG files back to back (bytes as read from disk), offsets[n_images + 1] their byte offsets (device),
+ *            total_file_bytes = offsets[n_images] (host copy: sizes the scratch check)
  *   flip     optional uint8[n_images]: 1 = mirror the map horizontally (the loader's flip augmentation)
  *   out      int64 [n_images][H][W] (the dtype the trainers index with)
  *   scratch  oess_png_decode_scratch_bytes(total bytes, n_images, H, W); scratch_offsets[n_images] (device): byte offset of image
@@ -376,9 +377,9 @@ int oess_conv2d_wgrad_bf16(const void* x, long long x_pix_stride, int B, int H, 
  *            stored / fixed / dynamic DEFLATE blocks, all five PNG filters.  Exact (integer work): equals PIL's array.
  * ------------------------------------------------------------------------------------------ */
 size_t oess_png_decode_scratch_bytes(long long total_file_bytes, int n_images, int H, int W);
-int oess_png_decode_gray8_batch(const uint8_t* files, const int64_t* offsets, int n_images, int H, int W, const uint8_t* flip,
-                                int64_t* out, void* scratch, size_t scratch_bytes, const int64_t* scratch_offsets, int* status,
-                                oess_stream_t stream);
+int oess_png_decode_gray8_batch(const uint8_t* files, const int64_t* offsets, long long total_file_bytes, int n_images, int H, int W,
+                                const uint8_t* flip, int64_t* out, void* scratch, size_t scratch_bytes, const int64_t* scratch_offsets,
+                                int* status, oess_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -86,7 +86,7 @@ SIGNATURES = {
     "oess_norm_tile_stats_apply_nhwc_bf16": (c_int, [c_vp, c_int, c_int, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_ll,
                                                      c_vp, c_ll, c_int, c_ll, c_vp, c_ll, c_vp]),
     "oess_png_decode_scratch_bytes": (c_sz, [c_ll, c_int, c_int, c_int]),
-    "oess_png_decode_gray8_batch": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, c_vp]),
+    "oess_png_decode_gray8_batch": (c_int, [c_vp, c_vp, c_ll, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, c_vp]),
     "oess_norm_reduce_finalize_tile_stats": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_f,
                                                      c_vp, c_vp, c_vp, c_vp, c_vp]),
 }

@@ -297,17 +297,18 @@ size_t oess_png_decode_scratch_bytes(long long total_file_bytes, int n_images, i
     return (size_t)total_file_bytes + (size_t)n_images * (16 + (size_t)H * (W + 1) + 16) + (size_t)(n_images + 1) * 8 + 256;
 }
 
-int oess_png_decode_gray8_batch(const uint8_t* files, const int64_t* offsets, int n_images, int H, int W, const uint8_t* flip,
-                                int64_t* out, void* scratch, size_t scratch_bytes, const int64_t* scratch_offsets, int* status,
-                                oess_stream_t stream) {
-    if (!files || !offsets || !out || !scratch || !scratch_offsets || !status || n_images <= 0 || H <= 0 || W <= 0 || W > 16384)
+int oess_png_decode_gray8_batch(const uint8_t* files, const int64_t* offsets, long long total_file_bytes, int n_images, int H, int W,
+                                const uint8_t* flip, int64_t* out, void* scratch, size_t scratch_bytes, const int64_t* scratch_offsets,
+                                int* status, oess_stream_t stream) {
+    if (!files || !offsets || !out || !scratch || !scratch_offsets || !status || n_images <= 0 || H <= 0 || W <= 0 || W > 16384 ||
+        total_file_bytes <= 0)
         return OESS_EINVAL;
+    if (scratch_bytes < oess_png_decode_scratch_bytes(total_file_bytes, n_images, H, W)) return OESS_ENOMEM;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(png_inflate_kernel, dim3(n_images), dim3(64), 0, st, files, offsets, H, W, (uint8_t*)scratch, scratch_offsets, status);
     hipLaunchKernelGGL(png_unfilter_kernel, dim3(n_images), dim3(64), (size_t)2 * W, st, (const uint8_t*)scratch, scratch_offsets, offsets, H, W,
                        flip, out, status);
     OESS_HIP(hipGetLastError());
-    (void)scratch_bytes;
     return OESS_OK;
 }
 

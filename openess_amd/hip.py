@@ -171,7 +171,7 @@ def png_decode_gray8_batch(files, lengths, H, W, flips=None, out=None):
     if out is None:
         out = torch.empty((n, H, W), dtype=torch.int64, device=files.device)
     status = torch.empty(n, dtype=torch.int32, device=files.device)
-    _lib.check(lib.oess_png_decode_gray8_batch(_ptr(files), _ptr(meta), n, H, W, _ptr(fl), _ptr(out), _ptr(ws), ws.numel(),
+    _lib.check(lib.oess_png_decode_gray8_batch(_ptr(files), _ptr(meta), a, n, H, W, _ptr(fl), _ptr(out), _ptr(ws), ws.numel(),
                                                meta[n + 1:].data_ptr(), _ptr(status), _stream()), "oess_png_decode_gray8_batch")
     return out, status
 

@@ -57,7 +57,7 @@ def test_round3_entry_points_validate_arguments_on_the_host():
     assert lib.oess_conv2d_fwd_workspace_bytes(0, 28, 40, 2048, 256, 3, 3, 1, 12, 12, 1, 0) == 0
     assert lib.oess_norm_partials_bytes(1, 140800, 256, 0) > 0 and lib.oess_norm_partials_bytes(0, 10, 8, 0) == 0
     assert lib.oess_png_decode_scratch_bytes(24 * 7000, 24, 440, 640) >= 24 * 440 * 641
-    assert lib.oess_png_decode_gray8_batch(None, None, 1, 8, 8, None, None, None, 0, None, None, None) == -22
+    assert lib.oess_png_decode_gray8_batch(None, None, 100, 1, 8, 8, None, None, None, 0, None, None, None) == -22
     assert lib.oess_norm_tile_stats_apply_nhwc_bf16(None, 70, 256, 8960.0, 1e-5, None, None, None, None, 0.1, None, None, None, 256,
                                                     None, 0, 1, 8960, None, 256, None) == -22
     assert lib.oess_norm_stats_finalize_nhwc_bf16(None, 64, 1, 100, 64, 1e-5, None, None, None, None, 0.1, None, None, None, None,
