@@ -27,6 +27,8 @@
 #include "oess_common.h"
 
 namespace {
+#include <type_traits>
+#include <utility>
 using namespace oess;
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;     // 8 bf16 = 4 VGPRs (MFMA A/B operand)
@@ -992,6 +994,226 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a) {
 }
 
 // =================================================================================================
+// 5x5 / stride-2 / pad-2 convolutions with a 2-D INPUT HALO in LDS (conv5x5s2_halo_kernel): E2VID's three encoder
+// ConvLayers (e2vid/model/unet.py: 32->64 @440x640, 64->128 @220x320, 128->256 @110x160, 20 launches each per step).
+//
+// In the implicit GEMM every (tap, channel chunk) K-slab fetches its own im2col block, so an input pixel travels L2 -> LDS
+// 25 / 4 = 6.25 times per output-channel tile.  Here a workgroup owns an 8 x 16 patch of output pixels x 64 output channels
+// and keeps the 19 x 35 input pixels under it (32 channels = 64 bytes each) in LDS for all 25 taps: 5.2 input pixels per
+// output pixel instead of 25, and tiles of 128 x 64 instead of 128 x 128 (4 400 / 2 200 / 1 120 workgroups on the three
+// layers instead of 550-1 100 tiles that quantise badly over the 512 slots).
+// Stride 2 would make the 16 lanes of a fragment-read phase touch only every second 64-byte block (half the banks), so the
+// halo is stored as TWO COLUMN-PARITY PLANES: plane p holds input columns 2 xi + p, and tap column s reads plane s & 1 at
+// xi = px + (s >> 1) -- consecutive output pixels are consecutive blocks again.  Block (p, hy, xi) keeps its four 16-byte
+// chunks at slot = chunk ^ (((xi >> 2) & 1) | (((hy >> 1) & 1) << 1)); a fragment row r of an M-tile is the pixel
+// (py = 2 i + ((r >> 3) & 1), px = (r & 7) + 8 (r >> 4)), so a phase (16 lanes) = 8 pixels x 2 patch rows = 4 lanes in each
+// of the 4 bank quarters with 4 different slots: conflict-free.  Weights: one (tap, 32-channel) slab of 64 rows x 64 bytes
+// per tap in a 6-deep LDS-DMA ring (5 slabs = ~1.5 us of taps in flight), slot = chunk ^ ((row >> 2) & 3).
+// Four waves, each a 64-pixel x 32-channel wave tile (fragments of the next k-step in flight under the current MFMAs); LDS 44 KB
+// halo + 24 KB ring = 68 KB -> two workgroups per CU = two waves per SIMD from DIFFERENT workgroups, so one workgroup's halo
+// fetch and epilogue run under the other's K loop (with two-wave workgroups, one wave per SIMD, the three phases of a tile
+// simply added up: 130 us on the 32->64 layer, 92 us with the epilogue compiled out, against 118 us for the im2col kernel).
+// Channel chunks (Cin = 64 / 128) reload the halo; the weight ring runs on across the chunk boundary.
+// =================================================================================================
+constexpr int S2_PH = 8, S2_PW = 16;                                 // output patch
+constexpr int S2_HH = 2 * S2_PH + 3, S2_XW = 18;                     // 19 halo rows; 18 blocks per plane row (35 columns)
+constexpr int S2_BLOCKS = 2 * S2_HH * S2_XW;                         // 684 blocks of 64 bytes
+constexpr int S2_HINSTR = (S2_BLOCKS + 63) / 64;                     // 11 wave-level DMA instructions (16 blocks each) per wave, 4 waves
+constexpr int S2_HALO_BYTES = S2_HINSTR * 4 * 1024;                  // 45 056
+constexpr int S2_RING = 6, S2_SLAB = 64 * 64;
+constexpr int S2_LDS = S2_HALO_BYTES + S2_RING * S2_SLAB;            // 69 632
+constexpr int S2_IMG_PITCH = 72;                                     // bf16 output image [128 pixels][64 + 8]
+
+template <typename F, int... Is>
+__device__ __forceinline__ void s2_for_taps(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+
+__global__ __launch_bounds__(256, 2) void conv5x5s2_halo_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nwg = a.tiles_m * a.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % a.tiles_n;
+    int patch = bid / a.tiles_n;
+    const int tiles_x = (a.Wo + S2_PW - 1) / S2_PW, tiles_y = (a.Ho + S2_PH - 1) / S2_PH;
+    const int ox0 = (patch % tiles_x) * S2_PW; patch /= tiles_x;
+    const int oy0 = (patch % tiles_y) * S2_PH;
+    const int b = patch / tiles_y;
+    const int n0 = tile_n * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                         // wave tile: patch rows 4 wm .. 4 wm + 3 (64 pixels) x channels 32 wn .. + 31
+    const int nchunks = a.Cin >> 5;
+    const int NS = nchunks * 25;                                     // weight slabs of this tile
+
+    const long long in_bytes = (((long long)a.B * a.H * a.W - 1) * a.in_pix_stride + a.Cin) * 2;
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7ffffff0, 0x00020000);
+
+    // ---- halo DMA geometry: lane (block lb = lane >> 2, slot = lane & 3) of instruction i writes block u = (wave*11 + i)*16 + lb
+    unsigned hoff[S2_HINSTR];
+#pragma unroll
+    for (int i = 0; i < S2_HINSTR; ++i) {
+        const int u = (wave * S2_HINSTR + i) * 16 + (lane >> 2), slot = lane & 3;
+        const int p = u / (S2_HH * S2_XW), rem = u - p * (S2_HH * S2_XW);
+        const int hy = rem / S2_XW, xi = rem - hy * S2_XW;
+        const int hx = 2 * xi + p;
+        const int f = ((xi >> 2) & 1) | (((hy >> 1) & 1) << 1);
+        const int iy = 2 * oy0 - 2 + hy, ix = 2 * ox0 - 2 + hx;
+        const bool ok = u < S2_BLOCKS && hx < 2 * S2_PW + 3 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        hoff[i] = ok ? (unsigned)((((long long)b * a.H + iy) * a.W + ix) * a.in_pix_stride * 2 + ((slot ^ f) << 4)) : 0x80000000u;
+    }
+    // ---- weight DMA geometry: this wave writes rows wave*16 + (lane >> 2) of every slab
+    unsigned boff;
+    {
+        const int row = wave * 16 + (lane >> 2), slot = lane & 3;
+        boff = (unsigned)(((n0 + row) * a.Kpad + ((slot ^ ((row >> 2) & 3)) << 3)) * 2);
+    }
+    auto issue_halo = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < S2_HINSTR; ++i) {
+            const unsigned voff = hoff[i] == 0x80000000u ? 0x80000000u : hoff[i] + (unsigned)(cc * 64);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(smem + (wave * S2_HINSTR + i) * 1024),
+                                                     16, voff, 0, 0, 0);
+        }
+    };
+    // slab s = (chunk, tap) -> ring buffer `buf`; slabs beyond the tile are dummy (out-of-range source = zero fill) so that
+    // the number of DMA instructions in flight is the same at every tap
+    auto issue_w = [&](int s, int buf) {
+        const int cc = s / 25, tap = s - cc * 25;
+        const unsigned voff = s < NS ? boff + (unsigned)((tap * a.Cin + cc * 32) * 2) : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(smem + S2_HALO_BYTES + buf * S2_SLAB + wave * 1024),
+                                                 16, voff, 0, 0, 0);
+    };
+
+    // accumulators: acc[i] = channels (rows) x pixels (columns) of M-tile i -- operands swapped, so that a lane holds four
+    // CONSECUTIVE channels of one pixel and the epilogue writes 8-byte pieces
+    f32x16_t acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+
+    // ---- fragment addresses.  slot << 4 = (ks << 5) ^ ((half ^ f) << 4): the lane part ((half ^ f) << 4) is folded into one base
+    //      register per (M-tile, s >> 1, parity of r >> 1) -- 12 registers -- the tap's block offset is an instruction immediate
+    //      and k-step 1 flips bit 5 (bases are multiples of 64 bytes + the slot bits, so the XOR never carries)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    const int r31 = lane & 31, half = lane >> 5;
+    const int a_px = (r31 & 7) + 8 * (r31 >> 4);
+    uint32_t va[2][3][2], vb;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int py = 4 * wm + 2 * i + ((r31 >> 3) & 1);
+#pragma unroll
+        for (int sv = 0; sv < 3; ++sv)
+#pragma unroll
+            for (int rp = 0; rp < 2; ++rp) {
+                const int f = (((a_px + sv) >> 2) & 1) | (((py + rp) & 1) << 1);
+                va[i][sv][rp] = lds0 + (uint32_t)((2 * py * S2_XW + a_px) * 64 + ((half ^ f) << 4));
+            }
+    }
+    {
+        const int n = wn * 32 + r31;
+        vb = lds0 + (uint32_t)(S2_HALO_BYTES + n * 64 + ((half ^ ((n >> 2) & 3)) << 4));
+    }
+
+#define S2_READ(FA, FB, R_, S_, KS_, BUF_)                                                                              \
+    {                                                                                                                   \
+        constexpr int blk_ = ((((S_) & 1) * S2_HH + (R_)) * S2_XW + ((S_) >> 1)) * 64;                                   \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                   \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(FA[i]) : "v"(va[i][(S_) >> 1][((R_) >> 1) & 1] ^ (uint32_t)((KS_) << 5)), "n"(blk_) : "memory"); \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(FB) : "v"((vb ^ (uint32_t)((KS_) << 5)) + (uint32_t)((BUF_) * S2_SLAB)) : "memory");  \
+    }
+#define S2_MMA(FA, FB)                                                                                                  \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                   \
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB, FA[i], acc[i], 0, 0, 0);                               \
+    }
+#define S2_WAIT(N_, FA, FB) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(FA[0]), "+v"(FA[1]), "+v"(FB) : "n"(N_) : "memory");
+
+#pragma unroll
+    for (int s = 0; s < S2_RING - 1; ++s) issue_w(s, s);
+    int sg = 0, buf = 0;                                             // global slab index and its ring buffer
+    for (int cc = 0; cc < nchunks; ++cc) {
+        if (cc > 0) __builtin_amdgcn_s_barrier();                    // every wave is done with the previous chunk's halo
+        issue_halo(cc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                // halo and every slab issued so far are in LDS
+        bf16x8_t fa0[2], fb0, fa1[2], fb1;
+        S2_READ(fa0, fb0, 0, 0, 0, buf)
+        // the 25 taps, unrolled with compile-time (r, s): tap offsets are instruction immediates
+        s2_for_taps([&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value, r = t / 5, s = t - r * 5;
+            if (t > 0) {
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");     // slab sg + 1 has landed (3 younger slabs may be in flight)
+                __builtin_amdgcn_s_barrier();                        // ... for every wave; the buffer of slab sg - 1 is free
+            }
+            const int nb = buf + 1 == S2_RING ? 0 : buf + 1;         // buffer of slab sg + 1
+            issue_w(sg + S2_RING - 1, buf == 0 ? S2_RING - 1 : buf - 1);
+            __builtin_amdgcn_s_setprio(3);
+            S2_READ(fa1, fb1, r, s, 1, buf)
+            S2_WAIT(3, fa0, fb0)
+            S2_MMA(fa0, fb0)
+            if constexpr (t < 24) {
+                constexpr int r2 = (t + 1) / 5, s2 = (t + 1) - r2 * 5;
+                S2_READ(fa0, fb0, r2, s2, 0, nb)
+                S2_WAIT(3, fa1, fb1)
+            } else {
+                S2_WAIT(0, fa1, fb1)
+            }
+            S2_MMA(fa1, fb1)
+            __builtin_amdgcn_s_setprio(0);
+            ++sg; buf = nb;
+        }, std::make_integer_sequence<int, 25>{});
+    }
+#undef S2_READ
+#undef S2_MMA
+#undef S2_WAIT
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // dummy tail slabs have been written (ring region only)
+    __syncthreads();
+
+    // ---- epilogue: bias + activation -> bf16 image [128 pixels][64 channels] in LDS (8-byte pieces: a lane holds channels
+    //      32 wn + 8 q + 4 half + {0..3} of pixel r31 of each M-tile) -> 16-byte row stores
+    uint16_t* img = reinterpret_cast<uint16_t*>(smem);
+    {
+        float bq[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bq[q][k] = a.bias ? a.bias[n0 + wn * 32 + 8 * q + 4 * half + k] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int py = 4 * wm + 2 * i + ((r31 >> 3) & 1);
+            uint16_t* dst = img + (py * S2_PW + a_px) * S2_IMG_PITCH + wn * 32 + 4 * half;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[k] = acc[i][q * 4 + k] + bq[q][k];
+                    if (a.relu) v[k] = fmaxf(v[k], 0.0f);
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(dst + 8 * q) = o;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + k * 256, pl = idx >> 3, c = idx & 7;
+        const int oy = oy0 + (pl >> 4), ox = ox0 + (pl & 15);
+        if (oy < a.Ho && ox < a.Wo)
+            *reinterpret_cast<uint4*>(a.out + (((long long)b * a.Ho + oy) * a.Wo + ox) * a.out_pix_stride + n0 + c * 8) =
+                *reinterpret_cast<const uint4*>(img + pl * S2_IMG_PITCH + c * 8);
+    }
+}
+
+// =================================================================================================
 // v4: BK = 32 slabs in a 4-deep LDS ring (same 64 KB per workgroup, still 2 workgroups per CU).
 // The 2-stage BK = 64 kernel has ONE slab in flight per workgroup and must hide the whole L2 -> LDS round trip
 // (~1.0-1.3 us under load) behind one slab of MFMAs (0.54 us when two workgroups share the CU): it is latency bound
@@ -1432,7 +1654,7 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
                              (const void*)&conv_fwd_dma_kernel<128, 128, 2, false, 1>, (const void*)&conv_fwd_dma_kernel<128, 128, 2, true, 1>,
                              (const void*)&conv3x3_halo_kernel<0>, (const void*)&conv3x3_halo_kernel<1>,
                              (const void*)&conv_fwd_dma_kernel<256, 256, 2, true>,
-                             (const void*)&conv_fwd_dma32_kernel<128, true, 0, 3>};
+                             (const void*)&conv_fwd_dma32_kernel<128, true, 0, 3>, (const void*)&conv5x5s2_halo_kernel};
         for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attrs_set = true;
     }
@@ -1482,6 +1704,16 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
         if (bn == 128) hipLaunchKernelGGL(conv_fwd_kernel<128>, grid, block, lds, st, a);
         else if (bn == 64) hipLaunchKernelGGL(conv_fwd_kernel<64>, grid, block, lds, st, a);
         else hipLaunchKernelGGL(conv_fwd_kernel<32>, grid, block, lds, st, a);
+        OESS_HIP(hipGetLastError());
+        return OESS_OK;
+    }
+    // (1b) 5x5 stride-2 pad-2 layers (E2VID's encoder ConvLayers): 2-D input halo in LDS, 8 x 16-pixel x 64-channel tiles
+    if (!lstm && R == 5 && S == 5 && stride == 2 && pad == 2 && dil == 1 && (Cin & 31) == 0 && (Cout & 63) == 0 && !tile_stats &&
+        !residual && !out_f32 && relu != 2 && (out_pix_stride & 7) == 0 && (((uintptr_t)out_bf16) & 15) == 0 && a.Kpad >= 25 * Cin) {
+        if (want_workspace) return OESS_OK;
+        a.tiles_n = Cout / 64;
+        a.tiles_m = B * ((a.Ho + S2_PH - 1) / S2_PH) * ((a.Wo + S2_PW - 1) / S2_PW);
+        hipLaunchKernelGGL(conv5x5s2_halo_kernel, dim3(a.tiles_m * a.tiles_n), dim3(256), S2_LDS, st, a);
         OESS_HIP(hipGetLastError());
         return OESS_OK;
     }

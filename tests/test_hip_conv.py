@@ -56,6 +56,38 @@ def test_conv_fwd_matches_torch(case):
     np.testing.assert_allclose(y32.cpu().numpy(), ref.clamp_min(0).cpu().numpy(), rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("geom", [(2, 440, 640, 32, 64),      # E2VID encoder 0 at the DSEC size (patches ragged in y: 220 = 27.5 x 8)
+                                  (2, 220, 320, 64, 128),     # encoder 1: two channel chunks, two output-channel tiles
+                                  (2, 110, 160, 128, 256),    # encoder 2: four chunks (100 weight slabs through the 6-deep ring)
+                                  (3, 37, 51, 32, 64),        # odd sizes: ragged patches in x and y, Ho = 19, Wo = 26
+                                  (1, 9, 7, 96, 192)])        # map smaller than one patch, three chunks, three channel tiles
+def test_conv5x5_stride2_halo_kernel(geom):
+    """5x5 / stride 2 / pad 2 (E2VID's encoder ConvLayers, e2vid/model/unet.py): the 2-D input-halo kernel against the fp32
+    convolution of the same operands: plain, bias + ReLU into a channel slice of a wider buffer (the ConvLSTM's cat(x, h)
+    buffer takes the encoder output that way), bit-repeatable."""
+    from openess_amd import hip
+    B, H, W, Cin, Cout = geom
+    torch.manual_seed(sum(geom))
+    x = torch.randn(B, H, W, Cin, device="cuda").bfloat16()
+    w = torch.randn(Cout, Cin, 5, 5, device="cuda") / np.sqrt(Cin * 25)
+    bias = torch.randn(Cout, device="cuda")
+    packed = hip.pack_conv_weight(w)
+    ref = ref_conv(x, w, None, 2, 2, 1)
+    y = hip.conv2d_nhwc(x, packed, None, Cout, 5, 5, 2, 2, 1)
+    assert y.shape == ref.shape
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=1e-2)
+    Ho, Wo = ref.shape[1], ref.shape[2]
+    buf = torch.full((B, Ho, Wo, 2 * Cout + 64), 7.0, device="cuda", dtype=torch.bfloat16)
+    y2 = hip.conv2d_nhwc(x, packed, bias, Cout, 5, 5, 2, 2, 1, relu=True, out=buf[..., 64:64 + Cout])
+    np.testing.assert_allclose(y2.float().cpu().numpy(), (ref + bias).clamp_min(0).cpu().numpy(), rtol=1e-2, atol=1e-2)
+    assert float((buf[..., :64] - 7).abs().max()) == 0 and float((buf[..., 64 + Cout:] - 7).abs().max()) == 0
+    assert torch.equal(y, hip.conv2d_nhwc(x, packed, None, Cout, 5, 5, 2, 2, 1))
+    # a strided input view (channel slice of a wider tensor) is read in place
+    wide = torch.randn(B, H, W, Cin + 32, device="cuda").bfloat16()
+    y3 = hip.conv2d_nhwc(wide[..., 32:], packed, None, Cout, 5, 5, 2, 2, 1)
+    np.testing.assert_allclose(y3.float().cpu().numpy(), ref_conv(wide[..., 32:], w, None, 2, 2, 1).cpu().numpy(), rtol=1e-2, atol=1e-2)
+
+
 def test_conv_small_cout_f32_logits_and_residual():
     from openess_amd import hip
     torch.manual_seed(7)
