@@ -272,8 +272,8 @@ def voxelize_raw_batch(batch0, device, rectify_map, C, H, W, crop_rows, nwin):
     seg_map = batch0.get('seg_map')
     if seg_map is None:
         seg_map = torch.zeros(B * nwin, dtype=torch.int32)
-    dev = {k: batch0[k].to(device, non_blocking=True) for k in ('x', 'y', 't', 'p')}
-    vox = hip.voxelize_dsec_raw(dev['x'], dev['y'], dev['t'], dev['p'], rmaps, seg_map.to(device, non_blocking=True), seg, C, H, W,
+    dev = {k: hip.h2d_async(batch0[k], device) for k in ('x', 'y', 't', 'p')}
+    vox = hip.voxelize_dsec_raw(dev['x'], dev['y'], dev['t'], dev['p'], rmaps, hip.h2d_async(seg_map, device), seg, C, H, W,
                                 crop_rows=crop_rows)
     vox = vox.view(B, nwin * C, H - crop_rows, W)
     flips = batch0.get('flip')

@@ -71,6 +71,20 @@ struct ConvArgs {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
+// 16-byte store of a finished output row piece.  OESS_OUT_STORE: 0 = plain (write-back in the XCD's L2), 1 = non-temporal,
+// 2 = agent scope (write-through).  The end of a kernel writes the XCD L2s' dirty lines back before the next kernel of the
+// stream may start (8 non-coherent L2s): the fewer dirty lines a kernel leaves, the shorter the gap behind it.
+#define OESS_OUT_STORE 0
+__device__ __forceinline__ void out_store16(void* p, uint4 v) {
+#if OESS_OUT_STORE == 1
+    __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(p));
+#elif OESS_OUT_STORE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(u32x4_t{v.x, v.y, v.z, v.w}) : "memory");
+#else
+    *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
+
 // threads per workgroup of the LDS-DMA kernel by tile height: 64- and 128-row tiles 4 waves, 256-row tiles 8 waves
 constexpr int conv_tile_threads(int bmx) { return bmx == 256 ? 512 : 256; }
 
@@ -207,7 +221,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
             u.q4 = pack_bf16x8(f);
         }
         if (full) {
-            *reinterpret_cast<uint4*>(dst) = u.q4;      // (nontemporal stores measured 5-8 % slower here)
+            out_store16(dst, u.q4);
         } else {                                   // ragged channel tail (Cout % 8 != 0)
 #pragma unroll
             for (int q = 0; q < 8; ++q) if (n + q < a.Cout) dst[q] = u.h[q];
@@ -311,7 +325,7 @@ __device__ __forceinline__ void lstm_epilogue(const ConvArgs& a, f32x16_t (&acc)
             const int row = idx / (HC / 4), c4 = idx - row * (HC / 4);
             const int m = m0 + row;
             const float* sp = lc + row * CP + c4 * 4;
-            if (m < a.M) *reinterpret_cast<float4*>(a.lstm_cell + (long long)m * C + hc0 + c4 * 4) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+            if (m < a.M) out_store16(a.lstm_cell + (long long)m * C + hc0 + c4 * 4, make_uint4(__float_as_uint(sp[0]), __float_as_uint(sp[1]), __float_as_uint(sp[2]), __float_as_uint(sp[3])));
         }
         const uint32_t* lhv = reinterpret_cast<const uint32_t*>(lh);
 #pragma unroll
@@ -319,7 +333,7 @@ __device__ __forceinline__ void lstm_epilogue(const ConvArgs& a, f32x16_t (&acc)
             const int row = idx / (HC / 8), c8 = idx - row * (HC / 8);
             const int m = m0 + row;
             const uint32_t* sp = lhv + row * (HP / 2) + c8 * 4;
-            if (m < a.M) *reinterpret_cast<uint4*>(a.lstm_h + (long long)m * a.lstm_h_stride + hc0 + c8 * 8) = make_uint4(sp[0], sp[1], sp[2], sp[3]);
+            if (m < a.M) out_store16(a.lstm_h + (long long)m * a.lstm_h_stride + hc0 + c8 * 8, make_uint4(sp[0], sp[1], sp[2], sp[3]));
         }
         return;
     }
@@ -1208,8 +1222,8 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_halo_kernel(ConvArgs a) {
         const int idx = tid + k * 256, pl = idx >> 3, c = idx & 7;
         const int oy = oy0 + (pl >> 4), ox = ox0 + (pl & 15);
         if (oy < a.Ho && ox < a.Wo)
-            *reinterpret_cast<uint4*>(a.out + (((long long)b * a.Ho + oy) * a.Wo + ox) * a.out_pix_stride + n0 + c * 8) =
-                *reinterpret_cast<const uint4*>(img + pl * S2_IMG_PITCH + c * 8);
+            out_store16(a.out + (((long long)b * a.Ho + oy) * a.Wo + ox) * a.out_pix_stride + n0 + c * 8,
+                        *reinterpret_cast<const uint4*>(img + pl * S2_IMG_PITCH + c * 8));
     }
 }
 

@@ -23,6 +23,17 @@ def _need_gpu(*tensors):
             raise RuntimeError("openess_amd HIP path needs CUDA/HIP tensors (no CPU fallback)")
 
 
+def h2d_async(t, device):
+    """Host tensor -> device; small ones without a device synchronisation: an upload from PAGEABLE memory blocks the host until the
+    stream has drained (a full synchronisation per call -- one at the top of every training step for the segment offsets of
+    the voxelizer); staged through pinned memory it is an ordinary stream-ordered copy."""
+    if t.is_cuda:
+        return t
+    if not t.is_pinned() and t.numel() * t.element_size() <= (1 << 20):
+        t = t.pin_memory()            # large pageable tensors (a loader without pin_memory=True) keep the runtime's own staging
+    return t.to(device, non_blocking=True)
+
+
 _WS_CACHE = {}
 
 
@@ -64,7 +75,7 @@ def voxelize_trilinear(x, y, p, t, seg_offsets, C, H, W, crop_rows=0, count_mode
     if n_ev > x.numel():
         raise ValueError("seg_offsets exceed the event arrays")
     if dev is None:
-        dev = host.to(x.device, non_blocking=True)
+        dev = h2d_async(host, x.device)
     if out is None:
         out = torch.empty((n_seg * C, H - crop_rows, W), dtype=torch.float32, device=x.device)
     nbytes = lib.oess_voxelize_workspace_bytes(x.numel(), n_seg, max_len, C, H, W, crop_rows)
@@ -88,7 +99,7 @@ def voxelize_dsec_raw(x, y, t_us, p, rectify_maps, seg_map, seg_offsets, C, H, W
     if n_ev > x.numel():
         raise ValueError("seg_offsets exceed the event arrays")
     if dev is None:
-        dev = host.to(x.device, non_blocking=True)
+        dev = h2d_async(host, x.device)
     seg_map = seg_map.to(torch.int32)
     if seg_map.numel() != n_seg:
         raise ValueError("seg_map needs one entry per segment")
@@ -113,7 +124,7 @@ def voxelize_nearest(events, seg_offsets, nbins, H, W, crop_rows=0, separate_pol
     if n_ev > events.shape[0]:
         raise ValueError("seg_offsets exceed the event array")
     if dev is None:
-        dev = host.to(events.device, non_blocking=True)
+        dev = h2d_async(host, events.device)
     ch = 2 * nbins if separate_pol else nbins
     if out is None:
         out = torch.empty((n_seg * ch, H - crop_rows, W), dtype=torch.float32, device=events.device)
@@ -137,7 +148,7 @@ def event_histogram(events, seg_offsets, H, W):
         raise ValueError("events must be contiguous int64 [N x 4]")
     host, dev, n_seg, max_len, _ = _seg_info(seg_offsets)
     if dev is None:
-        dev = host.to(events.device, non_blocking=True)
+        dev = h2d_async(host, events.device)
     out = torch.empty((n_seg * 2, H, W), dtype=torch.float32, device=events.device)
     _lib.check(lib.oess_event_histogram_i64(_ptr(events), _ptr(dev), n_seg, max_len, H, W, _ptr(out), _stream()),
                "oess_event_histogram_i64")
@@ -162,12 +173,12 @@ def png_decode_gray8_batch(files, lengths, H, W, flips=None, out=None):
         offs.append(a)
         scr.append(b)
         b += ((int(L) + 15) // 16) * 16 + H * (W + 1) + 16
-    meta = torch.tensor(offs + scr, dtype=torch.int64).to(files.device, non_blocking=True)
+    meta = h2d_async(torch.tensor(offs + scr, dtype=torch.int64), files.device)
     need = lib.oess_png_decode_scratch_bytes(a, n, H, W)
     ws = _workspace(max(need, b + 256), files.device, tag=("png", torch.cuda.current_stream(files.device).cuda_stream))
     fl = None
     if flips is not None and any(flips):
-        fl = torch.tensor([1 if f else 0 for f in flips], dtype=torch.uint8).to(files.device, non_blocking=True)
+        fl = h2d_async(torch.tensor([1 if f else 0 for f in flips], dtype=torch.uint8), files.device)
     if out is None:
         out = torch.empty((n, H, W), dtype=torch.int64, device=files.device)
     status = torch.empty(n, dtype=torch.int32, device=files.device)

@@ -184,10 +184,10 @@ class BaseTrainer(object):
         first = sample_batched[0]
         if len(sample_batched) != 7:            # datasets.synthetic_events.collate emits the 7-slot layout for every dataset
             raise ValueError(f"prepare_batch expects collate's 7-slot batch, got {len(sample_batched)} items")
-        rest = [t.to(self.device, non_blocking=True) if torch.is_tensor(t) else t for t in sample_batched[1:]]
+        rest = [hip.h2d_async(t, self.device) if torch.is_tensor(t) else t for t in sample_batched[1:]]
         for i, t in enumerate(rest):            # undecoded 8-bit PNG maps (device_png): one batched GPU decode per slot, flips included
             if isinstance(t, dict) and 'png_bytes' in t:
-                maps, status = hip.png_decode_gray8_batch(t['png_bytes'].to(self.device, non_blocking=True), t['png_lengths'],
+                maps, status = hip.png_decode_gray8_batch(hip.h2d_async(t['png_bytes'], self.device), t['png_lengths'],
                                                           t['hw'][0], t['hw'][1], t['flip'])
                 rest[i] = maps
                 self.png_status = status        # device tensor, non-zero = that map was filled with the ignore index (inspect off the hot path)
@@ -214,13 +214,13 @@ class BaseTrainer(object):
                 offs.extend([base + per * (i + 1) for i in range(nwin)])
             seg = torch.tensor(offs, dtype=torch.int64)
             B = len(counts)
-            dev = {k: first[k].to(self.device, non_blocking=True) for k in ('x', 'y', 't', 'p')}
+            dev = {k: hip.h2d_async(first[k], self.device) for k in ('x', 'y', 't', 'p')}
             seg_map = torch.zeros(B * nwin, dtype=torch.int32, device=self.device)
             vox = hip.voxelize_dsec_raw(dev['x'], dev['y'], dev['t'], dev['p'], self.rectify_maps, seg_map, seg, C, H, W,
                                         crop_rows=crop)
             first = vox.view(B, nwin * C, H - crop, W)
         else:
-            first = first.to(self.device, non_blocking=True)
+            first = hip.h2d_async(first, self.device)
         sp = rest[3] if len(rest) > 3 and torch.is_tensor(rest[3]) else None
         S = None
         if sp is not None and getattr(s, 'if_spatial_contrastive', False):

@@ -13,6 +13,11 @@ from .. import _lib
 CHUNK = 65536
 
 
+def step_key(plist):
+    """Identity of a launch group inside a param group: the parameters it updates."""
+    return tuple(id(p) for p in plist)
+
+
 class AdamW(torch.optim.AdamW):
     def _hip_ok(self, group, params):
         return (not group.get('amsgrad', False) and not group.get('maximize', False) and not group.get('capturable', False)
@@ -57,8 +62,20 @@ class AdamW(torch.optim.AdamW):
                     #                            hand its block to the `table` / `chunks` uploads below)
                     rows.append((p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel()))
                     cmap.extend((ti, c) for c in range((p.numel() + CHUNK - 1) // CHUNK))
-                table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev, non_blocking=True)
-                chunks = torch.from_numpy(np.asarray(cmap, dtype=np.int32)).to(dev, non_blocking=True)
+                # pointer table on the device: re-used while the pointers repeat (parameters and state never move, and the
+                # caching allocator hands backward the same gradient blocks step after step); a changed table is staged through
+                # PINNED memory -- an upload from pageable memory blocks the host until the stream has drained, i.e. it would
+                # put a full device synchronisation at the end of every training step
+                key = (id(group), step_key(plist))
+                cached = self._tables.get(key) if hasattr(self, '_tables') else None
+                if cached is None or cached[0] != rows:
+                    if not hasattr(self, '_tables'):
+                        self._tables = {}
+                    table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).pin_memory().to(dev, non_blocking=True)
+                    chunks = torch.from_numpy(np.asarray(cmap, dtype=np.int32)).pin_memory().to(dev, non_blocking=True)
+                    self._tables[key] = (rows, table, chunks)
+                else:
+                    _, table, chunks = cached
                 bc1 = 1.0 - beta1 ** step
                 bc2_sqrt = math.sqrt(1.0 - beta2 ** step)
                 _lib.check(lib.oess_adamw_multi_f32(table.data_ptr(), len(rows), chunks.data_ptr(), len(cmap), CHUNK, lr,
