@@ -353,7 +353,7 @@ int oess_layernorm_bf16(const void* x, long long x_row_stride, int64_t rows, int
 int oess_attention_d64_bf16(const void* qkv, long long qkv_row_stride, int B, int L, int heads, float scale, void* out,
                             long long out_row_stride, oess_stream_t stream);
 
-/* Weight gradient of oess_conv2d_fwd_bf16's convolution: dW (OIHW fp32, ACCUMULATED into: zero it first)
+/* Weight gradient of oess_conv2d_fwd_bf16's convolution: dW (OIHW fp32, every element WRITTEN: no pre-zeroing)
  * from x (NHWC bf16, Cin_x >= Cin channels present, Cin_x % 8 == 0) and dy (NHWC bf16, Cout % 8 == 0).
  * Replaces the weight half of ATen's convolution_backward behind nn.Conv2d (models/style_networks.py:252-289). */
 int oess_conv2d_wgrad_bf16(const void* x, long long x_pix_stride, int B, int H, int W, int Cin_x, const void* dy,

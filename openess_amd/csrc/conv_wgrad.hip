@@ -186,7 +186,7 @@ __global__ __launch_bounds__(WG) void conv_wgrad_kernel(WgradArgs a) {
         }
 }
 
-// dW[co][ci][r][s] (+)= sum over splits of part[split][co][(r,s,ci)]
+// dW[co][ci][r][s] = sum over splits of part[split][co][(r,s,ci)]
 // Threads walk the PARTIAL layout (kq = (r,s,ci) contiguous): the `splits` reads per element are coalesced and independent
 // (unrolled by 4); the one write per element is the scattered side.  (Walking the OIHW layout made every read of a 3x3 layer a
 // Cin-strided gather: 22-25 us per launch for a few MB, 60 launches per frame2recon step.)
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
             s2 += p[(size_t)(k + 2) * sstride]; s3 += p[(size_t)(k + 3) * sstride];
         }
         for (; k < splits; ++k) s0 += p[(size_t)k * sstride];
-        dw[((size_t)co * Cin + ci) * RS + tp] += (s0 + s1) + (s2 + s3);
+        dw[((size_t)co * Cin + ci) * RS + tp] = (s0 + s1) + (s2 + s3);
     }
 }
 

@@ -1001,7 +1001,7 @@ def conv2d_wgrad(x, gy, Cout, Cin, R, S, stride=1, pad=0, dil=1):
     _, Ho, Wo, Cg, gps = _nhwc_geom(gy)
     if Cg != Cout:
         raise ValueError("gy channel count != Cout")
-    dw = torch.zeros((Cout, Cin, R, S), dtype=torch.float32, device=x.device)
+    dw = torch.empty((Cout, Cin, R, S), dtype=torch.float32, device=x.device)
     ws = _workspace(256 << 20, x.device, tag="wgrad")
     _lib.check(lib.oess_conv2d_wgrad_bf16(_ptr(x), xps, B, H, W, Cin_x, _ptr(gy), gps, Cout, Cin, R, S, stride, pad, dil,
                                           _ptr(dw), _ptr(ws), ws.numel(), _stream()), "oess_conv2d_wgrad_bf16")
