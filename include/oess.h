@@ -244,6 +244,17 @@ int oess_norm_tile_stats_apply_nhwc_bf16(const float* tile_stats, int tiles, int
 int oess_convlstm_gates_bf16(const void* gates, long long gates_pix_stride, const float* prev_cell, float* cell,
                              void* hidden, long long hidden_pix_stride, long long n_pixels, int C, oess_stream_t stream);
 
+/* E2VID head + first encoder conv in ONE kernel (e2vid/model/unet.py:137-146, submodules.py ConvLayer: head = 5x5 stride 1,
+ * bins -> 32 channels; encoder 0's conv = 5x5 stride 2, 32 -> 64): out = act_e(conv5x5s2(act_h(conv5x5(x8) + head_bias)) + enc_bias).
+ * The 32-channel head output never reaches memory: every 8 x 16-pixel output patch computes the 19 x 35 head pixels under it
+ * into LDS.  x8: NHWC bf16 with 8 channels (bins zero-padded); head_w_packed = oess_conv2d_pack_weight of the [32, 8, 5, 5] weight,
+ * enc_w_packed of the [64, 32, 5, 5] weight; *_relu in {0, 1}; out: NHWC bf16 [B, (H-1)/2+1, (W-1)/2+1, 64] view, pixel stride
+ * out_pix_stride (a channel slice of the ConvLSTM's cat(x, h) buffer), 16-byte aligned.  Same result as the two
+ * oess_conv2d_fwd_bf16 calls (the head output rounded to bf16 in between, as there). */
+int oess_e2vid_head_enc0_bf16(const void* x8, long long x8_pix_stride, int B, int H, int W, const void* head_w_packed,
+                              const float* head_bias, int head_relu, const void* enc_w_packed, const float* enc_bias, int enc_relu,
+                              void* out, long long out_pix_stride, oess_stream_t stream);
+
 /* ConvLSTM step in ONE kernel: Gates convolution (submodules.py:202-203) + the cell update above, fused in the MFMA
  * epilogue.  w_packed_gates comes from oess_conv2d_pack_weight(..., flip_for_dgrad = 2): the 4C Conv2d rows are packed
  * gate-interleaved (row 4*hc + gate) so that one lane of the transposed accumulator owns the four gates of a hidden

@@ -1034,14 +1034,30 @@ constexpr int S2_HH = 2 * S2_PH + 3, S2_XW = 18;                     // 19 halo 
 constexpr int S2_BLOCKS = 2 * S2_HH * S2_XW;                         // 684 blocks of 64 bytes
 constexpr int S2_HINSTR = (S2_BLOCKS + 63) / 64;                     // 11 wave-level DMA instructions (16 blocks each) per wave, 4 waves
 constexpr int S2_HALO_BYTES = S2_HINSTR * 4 * 1024;                  // 45 056
-constexpr int S2_RING = 6, S2_SLAB = 64 * 64;
-constexpr int S2_LDS = S2_HALO_BYTES + S2_RING * S2_SLAB;            // 69 632
+constexpr int S2_SLAB = 64 * 64;
+constexpr int S2_RING_PLAIN = 6, S2_RING_FUSED = 5;                  // weight slabs in the ring
+constexpr int S2_LDS = S2_HALO_BYTES + S2_RING_PLAIN * S2_SLAB;      // 69 632
+// fused E2VID head (5x5 stride 1, 8 -> 32 channels) in front of the 32 -> 64 encoder: the voxel patch under the halo
+constexpr int S2_VH = S2_HH + 4, S2_VW = 2 * S2_PW + 3 + 4;          // 23 x 39 voxel pixels of 16 bytes (8 channels)
+constexpr int S2_VINSTR = (S2_VH * S2_VW + 255) / 256;               // 4 wave-level DMA instructions per wave (64 pixels each)
+constexpr int S2_VTOTAL = (S2_VH * S2_VW + 63) / 64;                 // 15 instructions in all
+constexpr int S2_VOX_BYTES = S2_VTOTAL * 1024;                       // 15 360
+constexpr int S2_LDS_FUSED = S2_HALO_BYTES + S2_RING_FUSED * S2_SLAB + S2_VOX_BYTES;    // 80 896: two workgroups per CU
+struct S2Head {              // FUSED: the encoder's input is relu(conv5x5(x8, hw) + hb), computed per patch into the LDS halo
+    const uint16_t* x8;      // NHWC bf16, 8 channels (event bins zero-padded), pixel stride x8_stride elements
+    long long x8_stride;
+    const uint16_t* hw;      // packed head weight [128][256] (rows 0..31 used, k = tap * 8 + channel)
+    const float* hb;         // [32] or null
+    int relu;
+};
 constexpr int S2_IMG_PITCH = 72;                                     // bf16 output image [128 pixels][64 + 8]
 
 template <typename F, int... Is>
 __device__ __forceinline__ void s2_for_taps(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 
-__global__ __launch_bounds__(256, 2) void conv5x5s2_halo_kernel(ConvArgs a) {
+template <bool FUSED>
+__global__ __launch_bounds__(256, 2) void conv5x5s2_halo_kernel(ConvArgs a, S2Head hd) {
+    constexpr int S2_RING = FUSED ? S2_RING_FUSED : S2_RING_PLAIN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nwg = a.tiles_m * a.tiles_n;
     int bid = blockIdx.x;
@@ -1062,14 +1078,15 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_halo_kernel(ConvArgs a) {
     const int nchunks = a.Cin >> 5;
     const int NS = nchunks * 25;                                     // weight slabs of this tile
 
-    const long long in_bytes = (((long long)a.B * a.H * a.W - 1) * a.in_pix_stride + a.Cin) * 2;
-    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)in_bytes, 0x00020000);
+    const long long in_bytes = FUSED ? (((long long)a.B * a.H * a.W - 1) * hd.x8_stride + 8) * 2
+                                     : (((long long)a.B * a.H * a.W - 1) * a.in_pix_stride + a.Cin) * 2;
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(FUSED ? (void*)hd.x8 : (void*)a.in, 0, (int)in_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7ffffff0, 0x00020000);
 
     // ---- halo DMA geometry: lane (block lb = lane >> 2, slot = lane & 3) of instruction i writes block u = (wave*11 + i)*16 + lb
-    unsigned hoff[S2_HINSTR];
+    unsigned hoff[FUSED ? 1 : S2_HINSTR];
 #pragma unroll
-    for (int i = 0; i < S2_HINSTR; ++i) {
+    for (int i = 0; i < (FUSED ? 0 : S2_HINSTR); ++i) {
         const int u = (wave * S2_HINSTR + i) * 16 + (lane >> 2), slot = lane & 3;
         const int p = u / (S2_HH * S2_XW), rem = u - p * (S2_HH * S2_XW);
         const int hy = rem / S2_XW, xi = rem - hy * S2_XW;
@@ -1087,7 +1104,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_halo_kernel(ConvArgs a) {
     }
     auto issue_halo = [&](int cc) {
 #pragma unroll
-        for (int i = 0; i < S2_HINSTR; ++i) {
+        for (int i = 0; i < (FUSED ? 0 : S2_HINSTR); ++i) {
             const unsigned voff = hoff[i] == 0x80000000u ? 0x80000000u : hoff[i] + (unsigned)(cc * 64);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(smem + (wave * S2_HINSTR + i) * 1024),
                                                      16, voff, 0, 0, 0);
@@ -1147,8 +1164,95 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_halo_kernel(ConvArgs a) {
     }
 #define S2_WAIT(N_, FA, FB) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(FA[0]), "+v"(FA[1]), "+v"(FB) : "n"(N_) : "memory");
 
+    if constexpr (FUSED) {
+        // ---- E2VID head in front of the encoder: relu(conv5x5(x8) + hb) for the 19 x 35 halo pixels, written straight into the
+        //      halo planes (zeros outside the image = the encoder's own padding).  Head weights: 13 k-steps of two taps x 8
+        //      channels, kept in registers (MFMA A operand: rows = 32 head channels); pixels are the B operand, read from the
+        //      23 x 39 voxel patch in LDS; a lane ends up with four consecutive channels of one halo pixel -> 8-byte LDS writes.
+        unsigned char* vox = smem + S2_HALO_BYTES + S2_RING_FUSED * S2_SLAB;
+        bf16x8_t wf[13];
+        {
+            const int p32 = lane & 31, hi = lane >> 5;
 #pragma unroll
-    for (int s = 0; s < S2_RING - 1; ++s) issue_w(s, s);
+            for (int ks = 0; ks < 13; ++ks) wf[ks] = *reinterpret_cast<const bf16x8_t*>(hd.hw + (size_t)p32 * 256 + (ks * 2 + hi) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < S2_VINSTR; ++i) {
+            const int v = (wave * S2_VINSTR + i) * 64 + lane;
+            const int vy = v / S2_VW, vx = v - vy * S2_VW;
+            const int iy = 2 * oy0 - 4 + vy, ix = 2 * ox0 - 4 + vx;
+            const bool ok = v < S2_VH * S2_VW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const unsigned voff = ok ? (unsigned)((((long long)b * a.H + iy) * a.W + ix) * hd.x8_stride * 2) : 0x80000000u;
+            if (wave * S2_VINSTR + i < S2_VTOTAL)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vox + (wave * S2_VINSTR + i) * 1024), 16, voff, 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < S2_RING - 1; ++s) issue_w(s, s);
+        float bq[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bq[q][k] = hd.hb ? hd.hb[8 * q + 4 * (lane >> 5) + k] : 0.0f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                // voxel patch (and the first weight slabs) are in LDS
+        const uint32_t vox0 = (uint32_t)(uintptr_t)vox, pl0 = (uint32_t)(uintptr_t)smem;
+        const int hi = lane >> 5;
+        for (int mt = wave; mt < (S2_BLOCKS + 31) / 32; mt += 4) {
+            const int u = mt * 32 + (lane & 31);
+            const int uu = u < S2_BLOCKS ? u : 0;
+            const int p = uu / (S2_HH * S2_XW), rem = uu - p * (S2_HH * S2_XW);
+            const int hy = rem / S2_XW, xi = rem - hy * S2_XW;
+            int hx = 2 * xi + p;
+            const bool inside = u < S2_BLOCKS && hx < 2 * S2_PW + 3 && (unsigned)(2 * oy0 - 2 + hy) < (unsigned)a.H &&
+                                (unsigned)(2 * ox0 - 2 + hx) < (unsigned)a.W;
+            hx = hx < 2 * S2_PW + 3 ? hx : 0;
+            const uint32_t vbase = vox0 + (uint32_t)((hy * S2_VW + hx) * 16);
+            f32x16_t hacc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) hacc[e] = 0.0f;
+            bf16x8_t pa, pb;
+            // k-step ks: this half wave's tap = 2 ks + hi (tap 25 carries zero weights: any address)
+#define S2_HREAD(DST, KS_)                                                                                             \
+            {                                                                                                         \
+                constexpr int t0_ = 2 * (KS_), t1_ = 2 * (KS_) + 1 < 25 ? 2 * (KS_) + 1 : 0;                            \
+                const uint32_t off_ = hi ? (uint32_t)(((t1_ / 5) * S2_VW + t1_ % 5) * 16) : (uint32_t)(((t0_ / 5) * S2_VW + t0_ % 5) * 16); \
+                asm volatile("ds_read_b128 %0, %1" : "=v"(DST) : "v"(vbase + off_) : "memory");                       \
+            }
+            S2_HREAD(pa, 0)
+            s2_for_taps([&](auto kc) __attribute__((always_inline)) {
+                constexpr int ks = decltype(kc)::value;
+                if constexpr (ks + 1 < 13) {
+                    if constexpr (ks & 1) { S2_HREAD(pa, ks + 1) } else { S2_HREAD(pb, ks + 1) }
+                    if constexpr (ks & 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(pb) :: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(pa) :: "memory");
+                } else {
+                    if constexpr (ks & 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pb) :: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pa) :: "memory");
+                }
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], (ks & 1) ? pb : pa, hacc, 0, 0, 0);
+            }, std::make_integer_sequence<int, 13>{});
+#undef S2_HREAD
+            if (u < S2_BLOCKS) {
+                const uint32_t f = (uint32_t)(((xi >> 2) & 1) | (((hy >> 1) & 1) << 1));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[k] = hacc[q * 4 + k] + bq[q][k];
+                        if (hd.relu) v[k] = fmaxf(v[k], 0.0f);
+                        v[k] = inside ? v[k] : 0.0f;
+                    }
+                    const uint2 o = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    asm volatile("ds_write_b64 %0, %1" :: "v"(pl0 + (uint32_t)(u * 64) + (((uint32_t)q ^ f) << 4) + (uint32_t)(8 * hi)), "v"(o) : "memory");
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+#pragma unroll
+        for (int s = 0; s < S2_RING - 1; ++s) issue_w(s, s);
+    }
     int sg = 0, buf = 0;                                             // global slab index and its ring buffer
     for (int cc = 0; cc < nchunks; ++cc) {
         if (cc > 0) __builtin_amdgcn_s_barrier();                    // every wave is done with the previous chunk's halo
@@ -1161,7 +1265,8 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_halo_kernel(ConvArgs a) {
         s2_for_taps([&](auto tc) __attribute__((always_inline)) {
             constexpr int t = decltype(tc)::value, r = t / 5, s = t - r * 5;
             if (t > 0) {
-                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");     // slab sg + 1 has landed (3 younger slabs may be in flight)
+                if constexpr (S2_RING == 6) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");     // slab sg + 1 has landed (RING - 3
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                            //  younger slabs may be in flight)
                 __builtin_amdgcn_s_barrier();                        // ... for every wave; the buffer of slab sg - 1 is free
             }
             const int nb = buf + 1 == S2_RING ? 0 : buf + 1;         // buffer of slab sg + 1
@@ -1618,6 +1723,23 @@ size_t oess_conv2d_packed_bytes(int Cout, int Cin, int R, int S, int flip_for_dg
 namespace {
 struct LstmOut { const float* prev; float* cell; void* h; long long h_stride; int C; };
 
+void conv_set_attrs() {
+    static bool attrs_set = false;
+    if (!attrs_set) {       // > 64 KiB of dynamic LDS needs an explicit opt-in
+        const void* fns[] = {(const void*)&conv_fwd_kernel<128>, (const void*)&conv_fwd_kernel<64>, (const void*)&conv_fwd_kernel<32>,
+                             (const void*)&conv_fwd_dma_kernel<128, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<128, 64, 2, false>, (const void*)&conv_fwd_dma_kernel<128, 32, 2, false>,
+                             (const void*)&conv_fwd_dma_kernel<128, 128, 2, true>, (const void*)&conv_fwd_dma_kernel<128, 64, 2, true>, (const void*)&conv_fwd_dma_kernel<128, 32, 2, true>,
+                             (const void*)&conv_fwd_dma_kernel<64, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<64, 128, 2, true>,
+                             (const void*)&conv_fwd_dma_kernel<128, 128, 2, false, 1>, (const void*)&conv_fwd_dma_kernel<128, 128, 2, true, 1>,
+                             (const void*)&conv3x3_halo_kernel<0>, (const void*)&conv3x3_halo_kernel<1>,
+                             (const void*)&conv_fwd_dma_kernel<256, 256, 2, true>,
+                             (const void*)&conv_fwd_dma32_kernel<128, true, 0, 3>, (const void*)&conv5x5s2_halo_kernel<false>,
+                             (const void*)&conv5x5s2_halo_kernel<true>};
+        for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attrs_set = true;
+    }
+}
+
 int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, int Cin, const void* w_packed,
                   const float* bias, int Cout, int R, int S, int stride, int pad, int dil, int relu,
                   const void* residual, long long res_pix_stride, void* out_bf16, float* out_f32,
@@ -1659,19 +1781,7 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
     a.tiles_m = (a.M + BM - 1) / BM;
     a.partial = nullptr; a.ksplit = 1; a.kt_per = 0;
     hipStream_t st = (hipStream_t)stream;
-    static bool attrs_set = false;
-    if (!attrs_set) {       // > 64 KiB of dynamic LDS needs an explicit opt-in
-        const void* fns[] = {(const void*)&conv_fwd_kernel<128>, (const void*)&conv_fwd_kernel<64>, (const void*)&conv_fwd_kernel<32>,
-                             (const void*)&conv_fwd_dma_kernel<128, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<128, 64, 2, false>, (const void*)&conv_fwd_dma_kernel<128, 32, 2, false>,
-                             (const void*)&conv_fwd_dma_kernel<128, 128, 2, true>, (const void*)&conv_fwd_dma_kernel<128, 64, 2, true>, (const void*)&conv_fwd_dma_kernel<128, 32, 2, true>,
-                             (const void*)&conv_fwd_dma_kernel<64, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<64, 128, 2, true>,
-                             (const void*)&conv_fwd_dma_kernel<128, 128, 2, false, 1>, (const void*)&conv_fwd_dma_kernel<128, 128, 2, true, 1>,
-                             (const void*)&conv3x3_halo_kernel<0>, (const void*)&conv3x3_halo_kernel<1>,
-                             (const void*)&conv_fwd_dma_kernel<256, 256, 2, true>,
-                             (const void*)&conv_fwd_dma32_kernel<128, true, 0, 3>, (const void*)&conv5x5s2_halo_kernel};
-        for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attrs_set = true;
-    }
+    conv_set_attrs();
     // The LDS-DMA kernels address the input with 32-bit buffer offsets and decode filter taps with exact small-range
     // reciprocals (verified here over the whole range); anything outside takes the register-staged generic kernel.
     const long long in_extent = (((long long)B * H * W - 1) * in_pix_stride + Cin) * 2;
@@ -1727,7 +1837,7 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
         if (want_workspace) return OESS_OK;
         a.tiles_n = Cout / 64;
         a.tiles_m = B * ((a.Ho + S2_PH - 1) / S2_PH) * ((a.Wo + S2_PW - 1) / S2_PW);
-        hipLaunchKernelGGL(conv5x5s2_halo_kernel, dim3(a.tiles_m * a.tiles_n), dim3(256), S2_LDS, st, a);
+        hipLaunchKernelGGL((conv5x5s2_halo_kernel<false>), dim3(a.tiles_m * a.tiles_n), dim3(256), S2_LDS, st, a, S2Head{});
         OESS_HIP(hipGetLastError());
         return OESS_OK;
     }
@@ -1874,6 +1984,29 @@ int oess_convlstm_fused_bf16(const void* in, long long in_pix_stride, int B, int
     LstmOut l{prev_cell, cell, hidden, hidden_pix_stride, C_hidden};
     return conv_fwd_impl(in, in_pix_stride, B, H, W, Cin, w_packed_gates, bias, 4 * C_hidden, R, S, 1, pad, 1, 0, nullptr, 0,
                          nullptr, nullptr, 0, nullptr, &l, stream);
+}
+
+int oess_e2vid_head_enc0_bf16(const void* x8, long long x8_pix_stride, int B, int H, int W, const void* head_w_packed,
+                              const float* head_bias, int head_relu, const void* enc_w_packed, const float* enc_bias, int enc_relu,
+                              void* out, long long out_pix_stride, oess_stream_t stream) {
+    if (!x8 || !head_w_packed || !enc_w_packed || !out || B <= 0 || H <= 0 || W <= 0 || (x8_pix_stride & 7) || x8_pix_stride < 8 ||
+        (out_pix_stride & 7) || out_pix_stride < 64 || (((uintptr_t)out) & 15) || (unsigned)head_relu > 1u || (unsigned)enc_relu > 1u)
+        return OESS_EINVAL;
+    if ((((long long)B * H * W - 1) * x8_pix_stride + 8) * 2 >= 0x7ffffff0ll) return OESS_EINVAL;     // 32-bit buffer offsets
+    conv_set_attrs();
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.w = (const uint16_t*)enc_w_packed; a.bias = enc_bias; a.out = (uint16_t*)out; a.out_pix_stride = out_pix_stride;
+    a.B = B; a.H = H; a.W = W; a.Cin = 32; a.Cout = 64; a.R = 5; a.S = 5; a.stride = 2; a.pad = 2; a.dil = 1;
+    a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
+    a.Kpad = (25 * 32 + BK - 1) / BK * BK;
+    a.M = B * a.Ho * a.Wo; a.relu = enc_relu;
+    a.tiles_n = 1;
+    a.tiles_m = B * ((a.Ho + S2_PH - 1) / S2_PH) * ((a.Wo + S2_PW - 1) / S2_PW);
+    S2Head hd{(const uint16_t*)x8, x8_pix_stride, (const uint16_t*)head_w_packed, head_bias, head_relu};
+    hipLaunchKernelGGL((conv5x5s2_halo_kernel<true>), dim3(a.tiles_m), dim3(256), S2_LDS_FUSED, (hipStream_t)stream, a, hd);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
 }
 
 }  // extern "C"

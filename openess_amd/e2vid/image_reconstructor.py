@@ -20,12 +20,15 @@ class ImageReconstructor:
         self.last_states_for_each_channel = {'grayscale': None}
         self.event_preprocessor = EventPreprocessor(options)
 
-    def update_reconstruction(self, event_tensor, event_tensor_id=None, stamp=None, channel_slice=None, reconstruct=False, wavefront=None):
+    def update_reconstruction(self, event_tensor, event_tensor_id=None, stamp=None, channel_slice=None, reconstruct=False, wavefront=None,
+                              need_latents=True):
         """event_tensor: fp32 [B, num_bins, H, W] (reference contract), or -- fused form -- the whole
         [B, C_total, H, W] event tensor plus channel_slice=(c0, cs) so that the slice, the normalisation
         and the NHWC re-layout are one kernel.  Returns (img | None, states, latent): the trainers discard the image
         (`_, _, latent = update_reconstruction(...)`), so it is only computed with `reconstruct=True` (offline
-        reconstruction, e2vid/run_reconstruction.py), cropped back from the padded size like the reference's CropParameters."""
+        reconstruction, e2vid/run_reconstruction.py), cropped back from the padded size like the reference's CropParameters.
+        need_latents=False: the caller drops this call's latents (all but the last sub-window of a step): latent[1] (the head
+        output) is None and is never written to memory (head + encoder-0 conv in one kernel); states are advanced as usual."""
         with torch.no_grad():
             if channel_slice is None:
                 events = event_tensor.to(self.device).float().contiguous()
@@ -39,6 +42,8 @@ class ImageReconstructor:
                 if self.crop.needs_pad:
                     x = self.crop.pad(x.float()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             kw = {} if wavefront is None else {'wavefront': wavefront}
+            if not need_latents and not reconstruct:
+                kw['need_head'] = False
             img, states, latent = self.model(x, self.last_states_for_each_channel['grayscale'], reconstruct=reconstruct, **kw)
             self.last_states_for_each_channel['grayscale'] = None if self.no_recurrent else states
         return img, states, latent

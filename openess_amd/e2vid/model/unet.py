@@ -34,23 +34,53 @@ class UNetRecurrent(nn.Module):
         self.pred = ConvLayer(base_num_channels if skip_type == 'sum' else 2 * base_num_channels, num_output_channels, 1,
                               activation=None, norm=norm)
 
-    def forward(self, x, prev_states, reconstruct=False, wavefront=None):
+    def _head_enc0_fusable(self, x):
+        """The head + encoder-0 conv pair that oess_e2vid_head_enc0_bf16 takes: 8 padded input channels, 5x5 stride-1 head to 32
+        channels, 5x5 stride-2 encoder conv 32 -> 64, ReLU / no activation, no InstanceNorm (BatchNorm is folded when in eval)."""
+        h, e = self.head, self.encoders[0].conv
+        ok = x.is_cuda and x.shape[1] == 8 and x.dtype == __import__('torch').bfloat16
+        for m, cin, cout, st in ((h, None, 32, 1), (e, 32, 64, 2)):
+            c = m.conv2d
+            ok = ok and c.kernel_size == (5, 5) and c.stride == (st, st) and c.padding == (2, 2) and c.out_channels == cout \
+                and (cin is None or c.in_channels == cin) and m.activation_name in (None, 'relu') and m.norm != 'IN' \
+                and not (m.norm == 'BN' and m.norm_layer.training)
+        return ok and h.conv2d.in_channels <= 8
+
+    def _head_enc0(self, x, prev_state):
+        """Encoder 0's conv output straight from the voxel slice (the 32-channel head output is never written): fills the x half
+        of the level-0 cat(x, h) buffer and returns the state."""
+        from ... import engine, hip
+        h, e = self.head, self.encoders[0]
+        state = prev_state if prev_state is not None else e.new_state(x)
+        pwh = h._pw.get(h.conv2d.weight, h.conv2d.bias, h.norm_layer if h.norm == 'BN' else None, cin_pad=8)
+        ec = e.conv
+        pwe = ec._pw.get(ec.conv2d.weight, ec.conv2d.bias, ec.norm_layer if ec.norm == 'BN' else None, cin_pad=32)
+        hip.e2vid_head_enc0(engine.nhwc(x), pwh.packed, pwh.bias, h.activation_name == 'relu', pwe.packed, pwe.bias,
+                            ec.activation_name == 'relu', out=engine.nhwc(state['xh'][state['cur']][:, :64]))
+        return state
+
+    def forward(self, x, prev_states, reconstruct=False, wavefront=None, need_head=True):
         """x: logical [B, 8, H, W] channels_last bf16 (bins zero-padded to 8).  Returns (img | None, states, latent):
         the training path stops at the latents; `reconstruct=True` also runs the residual blocks, decoders and the
         prediction layer (unet.py:160-170) and returns the [B, 1, H, W] fp32 image in [0, 1] (offline reconstruction).
-        `wavefront` (e2vid/wavefront.py): run level l on its own HIP stream, ordered by events; same kernels, same results."""
+        `wavefront` (e2vid/wavefront.py): run level l on its own HIP stream, ordered by events; same kernels, same results.
+        `need_head=False` (the caller discards this call's latents: every sub-window but the last of a pre-training step,
+        pretrain_trainer.py:437-441): latent[1] is None and head + encoder-0 conv run as ONE kernel."""
         if prev_states is None:
             prev_states = [None] * self.num_encoders
         blocks, states = [], []
         if wavefront is not None and not reconstruct:
             import torch
-            with torch.cuda.stream(wavefront.streams[0]):
-                x = self.head(x)
-            head = x
+            fuse = not need_head and self._head_enc0_fusable(x)
+            head = None
+            if not fuse:
+                with torch.cuda.stream(wavefront.streams[0]):
+                    x = self.head(x)
+                head = x
             for i, encoder in enumerate(self.encoders):
                 with torch.cuda.stream(wavefront.streams[i]):
                     wavefront.before_conv(i)
-                    state = encoder.run_conv(x, prev_states[i])
+                    state = self._head_enc0(x, prev_states[0]) if (fuse and i == 0) else encoder.run_conv(x, prev_states[i])
                     wavefront.after_conv(i)
                     wavefront.before_lstm(i)
                     x = encoder.recurrent_block.step(state)
@@ -58,10 +88,17 @@ class UNetRecurrent(nn.Module):
                 blocks.append(x)
                 states.append(state)
         else:
-            x = self.head(x)
-            head = x
+            fuse = not need_head and not reconstruct and self._head_enc0_fusable(x)
+            head = None
+            if not fuse:
+                x = self.head(x)
+                head = x
             for i, encoder in enumerate(self.encoders):
-                x, state = encoder(x, prev_states[i])
+                if fuse and i == 0:
+                    state = self._head_enc0(x, prev_states[0])
+                    x = encoder.recurrent_block.step(state)
+                else:
+                    x, state = encoder(x, prev_states[i])
                 blocks.append(x)
                 states.append(state)
         latent = {1: head}

@@ -536,6 +536,29 @@ def conv2d_nhwc(x, packed, bias, Cout, R, S, stride=1, pad=0, dil=1, relu=False,
     return out
 
 
+def e2vid_head_enc0(x8, head_packed, head_bias, head_relu, enc_packed, enc_bias, enc_relu, out=None):
+    """E2VID head (5x5, bins -> 32) + encoder 0's conv (5x5 stride 2, 32 -> 64) in one kernel; the head output stays in LDS.
+    x8: NHWC bf16 [B, H, W, 8]; out: NHWC bf16 [B, Ho, Wo, 64] view (may be a channel slice)."""
+    lib = _lib.load()
+    _need_gpu(x8, head_packed, enc_packed)
+    B, H, W, C, ps = _nhwc_geom(x8)
+    if C != 8:
+        raise ValueError("e2vid_head_enc0: x8 must have 8 channels")
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, 64), dtype=torch.bfloat16, device=x8.device)
+    _, _, _, Co, ops = _nhwc_geom(out)
+    if tuple(out.shape) != (B, Ho, Wo, 64):
+        raise ValueError(f"bad output shape {tuple(out.shape)} != {(B, Ho, Wo, 64)}")
+    for b_ in (head_bias, enc_bias):
+        if b_ is not None and (b_.dtype != torch.float32 or not b_.is_contiguous()):
+            raise ValueError("biases must be contiguous fp32")
+    _lib.check(lib.oess_e2vid_head_enc0_bf16(_ptr(x8), ps, B, H, W, _ptr(head_packed), _ptr(head_bias), int(bool(head_relu)),
+                                             _ptr(enc_packed), _ptr(enc_bias), int(bool(enc_relu)), _ptr(out), ops, _stream()),
+               "oess_e2vid_head_enc0_bf16")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ pointwise
 def convlstm_gates(gates, cell, hidden_out, prev_cell_is_zero=False):
     """gates: bf16 NHWC [B,H,W,4C]; cell: fp32 [B,H,W,C] (updated in place); hidden_out: bf16 NHWC view

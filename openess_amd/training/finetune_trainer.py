@@ -64,7 +64,8 @@ class _SupervisedTrainer(BaseTrainer):
         s = self.settings
         self.reconstructor.last_states_for_each_channel = {'grayscale': None}
         for i in range(s.nr_events_data_b):
-            _, _, latent = self.reconstructor.update_reconstruction(event, channel_slice=(i * s.input_channels_b, s.input_channels_b))
+            _, _, latent = self.reconstructor.update_reconstruction(event, channel_slice=(i * s.input_channels_b, s.input_channels_b),
+                                                                    need_latents=(i == s.nr_events_data_b - 1))
         return latent
 
     def task_train_step(self, batch):

@@ -120,7 +120,8 @@ class PretrainStep:
             self.reconstructor.last_states_for_each_channel = {'grayscale': None}
             for i in range(self.nr_events_data):
                 _, _, latent_real = self.reconstructor.update_reconstruction(
-                    event, channel_slice=(i * self.bins, self.bins), wavefront=wf)
+                    event, channel_slice=(i * self.bins, self.bins), wavefront=wf,
+                    need_latents=(i == self.nr_events_data - 1))      # only the last sub-window's latents are used (:437-441)
             if wf is not None:
                 wf.end(*latent_real.values())
             content = {k: v.detach() for k, v in latent_real.items()}          # trainTaskStepPretrain (:550-562)

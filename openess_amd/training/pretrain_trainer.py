@@ -57,7 +57,8 @@ class OpenESSPretrainModel(BaseTrainer):
         if s.config_option in ('recon2voxel', 'frame2voxel'):
             self.reconstructor.last_states_for_each_channel = {'grayscale': None}
             for i in range(s.nr_events_data_b):
-                _, _, content = self.reconstructor.update_reconstruction(batch[0], channel_slice=(i * s.input_channels_b, s.input_channels_b))
+                _, _, content = self.reconstructor.update_reconstruction(batch[0], channel_slice=(i * s.input_channels_b, s.input_channels_b),
+                                                                         need_latents=(i == s.nr_events_data_b - 1))
             pred, _ = self.models_dict['back_end'](content)
             pred = pred[1]
         else:

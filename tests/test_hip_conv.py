@@ -383,3 +383,37 @@ def test_conv_gelu_epilogue_matches_exact_erf():
         np.testing.assert_allclose(y32.cpu().numpy(), F.gelu(mine).cpu().numpy(), rtol=0, atol=2e-6 * float(pre.abs().max()) + 2e-6)
         y = hip.conv2d_nhwc(x, packed, b, Cout, 1, 1, 1, 0, 1, relu=2)
         np.testing.assert_allclose(y.float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("geom", [(8, 440, 640), (3, 37, 51), (1, 9, 7), (2, 64, 96)])
+def test_e2vid_head_enc0_fused_equals_two_convs(geom):
+    """E2VID head (5x5, 8 -> 32, ReLU) + encoder 0 conv (5x5 stride 2, 32 -> 64, ReLU) in one kernel (the 32-channel head output
+    stays in LDS) against the two conv launches -- bit-equal: the same bf16 rounding point between the layers and the same
+    k order in both products -- and against the fp32 reference; output into a channel slice of a wider buffer."""
+    from openess_amd import hip
+    B, H, W = geom
+    torch.manual_seed(sum(geom))
+    x8 = torch.zeros(B, H, W, 8, device="cuda", dtype=torch.bfloat16)
+    x8[..., :5] = torch.randn(B, H, W, 5, device="cuda").bfloat16()
+    wh = torch.zeros(32, 8, 5, 5, device="cuda")
+    wh[:, :5] = torch.randn(32, 5, 5, 5, device="cuda") / np.sqrt(125)
+    bh = torch.randn(32, device="cuda") * 0.1
+    we = torch.randn(64, 32, 5, 5, device="cuda") / np.sqrt(800)
+    be = torch.randn(64, device="cuda") * 0.1
+    ph, pe = hip.pack_conv_weight(wh), hip.pack_conv_weight(we)
+    head = hip.conv2d_nhwc(x8, ph, bh, 32, 5, 5, 1, 2, 1, relu=True)
+    two = hip.conv2d_nhwc(head, pe, be, 64, 5, 5, 2, 2, 1, relu=True)
+    Ho, Wo = two.shape[1], two.shape[2]
+    buf = torch.full((B, Ho, Wo, 128), 3.0, device="cuda", dtype=torch.bfloat16)
+    one = hip.e2vid_head_enc0(x8, ph, bh, True, pe, be, True, out=buf[..., :64])
+    assert float((buf[..., 64:] - 3).abs().max()) == 0
+    ref_h = ref_conv(x8, wh, bh, 1, 2, 1).clamp_min(0).bfloat16()
+    ref = ref_conv(ref_h, we, be, 2, 2, 1).clamp_min(0)
+    np.testing.assert_allclose(one.float().cpu().numpy(), ref.cpu().numpy(), rtol=2e-2, atol=2e-2)
+    d = (one.float() - two.float()).abs()
+    assert float(d.max()) <= 2e-2 and float((d > 0).float().mean()) < 0.02, (float(d.max()), float((d > 0).float().mean()))
+    assert torch.equal(one, hip.e2vid_head_enc0(x8, ph, bh, True, pe, be, True))
+    # no activation / no bias forms
+    one2 = hip.e2vid_head_enc0(x8, ph, None, False, pe, None, False)
+    ref2 = ref_conv(ref_conv(x8, wh, None, 1, 2, 1).bfloat16(), we, None, 2, 2, 1)
+    np.testing.assert_allclose(one2.float().cpu().numpy(), ref2.cpu().numpy(), rtol=2e-2, atol=2e-2)

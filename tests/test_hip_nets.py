@@ -68,6 +68,19 @@ def test_e2vid_recurrent_latents(g, keys):
     for i in range(3):
         _, _, latent2 = rec2.update_reconstruction(ev, channel_slice=(5 * i, 5))
     assert torch.equal(latent2[8], latent[8])
+    # sub-windows whose latents the caller drops run head + encoder-0 conv as ONE kernel (need_latents=False): the states advance
+    # identically (same products, same bf16 rounding point between the two layers), so the last sub-window's latents -- computed
+    # the ordinary way -- match the all-unfused loop and the reference's golden
+    rec3 = ImageReconstructor(m, 32, 48, 5, torch.device("cuda"))
+    for i in range(3):
+        _, _, latent3 = rec3.update_reconstruction(ev, channel_slice=(5 * i, 5), need_latents=(i == 2))
+    assert torch.equal(latent3[1], latent[1])
+    for k in (2, 4, 8):
+        assert relerr(latent3[k].float().cpu().numpy(), latent[k].float().cpu().numpy()) < 5e-3, k
+        assert relerr(latent3[k].float().cpu().numpy(), lat_ref[k].numpy()) < 3e-2, k
+    rec4 = ImageReconstructor(m, 32, 48, 5, torch.device("cuda"))
+    _, _, lat_none = rec4.update_reconstruction(ev, channel_slice=(0, 5), need_latents=False)
+    assert lat_none[1] is None and lat_none[2].shape == latent[2].shape
 
 
 @pytest.fixture(scope="module")
