@@ -268,6 +268,10 @@ int oess_convlstm_fused_bf16(const void* in, long long in_pix_stride, int B, int
                              oess_stream_t stream);
 
 /* Statistics of a channel slice without the apply pass (first half of K2): stats = {sum, sumsq, nnz, -}. */
+/* ... and of n_slices consecutive Cs-channel slices in ONE launch (the 20 sub-windows of a pre-training sample are known up
+ * front, pretrain_trainer.py:437-441): stats[4 z ..] = {sum, sumsq, nnz, -} of in[:, z*Cs : (z+1)*Cs]. */
+int oess_masked_stats_slices_f32(const float* in, int B, int Ctot, int Cs, int n_slices, int64_t HW, double* stats,
+                                 oess_stream_t stream);
 int oess_masked_stats_slice_f32(const float* in, int B, int Ctot, int c0, int Cs, int64_t HW, double* stats,
                                 oess_stream_t stream);
 /* EventPreprocessor apply (e2vid/utils/inference_utils.py:80-85) fused with the NCHW fp32 -> NHWC bf16

@@ -65,6 +65,7 @@ SIGNATURES = {
     "oess_nce_loss_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "oess_adamw_multi_f32": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_d, c_d, c_d, c_d, c_d, c_d, c_d, c_vp]),
     "oess_masked_stats_slice_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp]),
+    "oess_masked_stats_slices_f32": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp]),
     "oess_event_slice_to_nhwc8_bf16": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_ll, c_vp, c_int, c_vp, c_vp]),
     "oess_norm_partials_bytes": (c_sz, [c_int, c_ll, c_int, c_int]),
     "oess_norm_stats_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_ll, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),

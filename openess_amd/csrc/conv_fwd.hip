@@ -1197,54 +1197,71 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_halo_kernel(ConvArgs a, S2He
         __builtin_amdgcn_s_barrier();                                // voxel patch (and the first weight slabs) are in LDS
         const uint32_t vox0 = (uint32_t)(uintptr_t)vox, pl0 = (uint32_t)(uintptr_t)smem;
         const int hi = lane >> 5;
-        for (int mt = wave; mt < (S2_BLOCKS + 31) / 32; mt += 4) {
-            const int u = mt * 32 + (lane & 31);
-            const int uu = u < S2_BLOCKS ? u : 0;
-            const int p = uu / (S2_HH * S2_XW), rem = uu - p * (S2_HH * S2_XW);
-            const int hy = rem / S2_XW, xi = rem - hy * S2_XW;
-            int hx = 2 * xi + p;
-            const bool inside = u < S2_BLOCKS && hx < 2 * S2_PW + 3 && (unsigned)(2 * oy0 - 2 + hy) < (unsigned)a.H &&
-                                (unsigned)(2 * ox0 - 2 + hx) < (unsigned)a.W;
-            hx = hx < 2 * S2_PW + 3 ? hx : 0;
-            const uint32_t vbase = vox0 + (uint32_t)((hy * S2_VW + hx) * 16);
-            f32x16_t hacc;
+        // two M-tiles (64 halo pixels) per pass: two independent accumulators, two reads in flight under two MFMAs
+        static_assert(((S2_BLOCKS + 31) / 32) % 2 == 0, "M-tiles are taken in pairs");
+        for (int pr = wave; pr < (S2_BLOCKS + 31) / 64; pr += 4) {
+            int uu_[2], hy_[2], xi_[2];
+            bool inside_[2];
+            uint32_t vbase[2];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) hacc[e] = 0.0f;
-            bf16x8_t pa, pb;
+            for (int z = 0; z < 2; ++z) {
+                const int u = (2 * pr + z) * 32 + (lane & 31);
+                uu_[z] = u;
+                const int uu = u < S2_BLOCKS ? u : 0;
+                const int p = uu / (S2_HH * S2_XW), rem = uu - p * (S2_HH * S2_XW);
+                const int hy = rem / S2_XW, xi = rem - hy * S2_XW;
+                int hx = 2 * xi + p;
+                inside_[z] = u < S2_BLOCKS && hx < 2 * S2_PW + 3 && (unsigned)(2 * oy0 - 2 + hy) < (unsigned)a.H &&
+                             (unsigned)(2 * ox0 - 2 + hx) < (unsigned)a.W;
+                hx = hx < 2 * S2_PW + 3 ? hx : 0;
+                hy_[z] = hy; xi_[z] = xi;
+                vbase[z] = vox0 + (uint32_t)((hy * S2_VW + hx) * 16);
+            }
+            f32x16_t hacc[2];
+#pragma unroll
+            for (int z = 0; z < 2; ++z)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) hacc[z][e] = 0.0f;
+            bf16x8_t pa[2], pb[2];
             // k-step ks: this half wave's tap = 2 ks + hi (tap 25 carries zero weights: any address)
 #define S2_HREAD(DST, KS_)                                                                                             \
             {                                                                                                         \
                 constexpr int t0_ = 2 * (KS_), t1_ = 2 * (KS_) + 1 < 25 ? 2 * (KS_) + 1 : 0;                            \
                 const uint32_t off_ = hi ? (uint32_t)(((t1_ / 5) * S2_VW + t1_ % 5) * 16) : (uint32_t)(((t0_ / 5) * S2_VW + t0_ % 5) * 16); \
-                asm volatile("ds_read_b128 %0, %1" : "=v"(DST) : "v"(vbase + off_) : "memory");                       \
+                asm volatile("ds_read_b128 %0, %1" : "=v"(DST[0]) : "v"(vbase[0] + off_) : "memory");                  \
+                asm volatile("ds_read_b128 %0, %1" : "=v"(DST[1]) : "v"(vbase[1] + off_) : "memory");                  \
             }
             S2_HREAD(pa, 0)
             s2_for_taps([&](auto kc) __attribute__((always_inline)) {
                 constexpr int ks = decltype(kc)::value;
                 if constexpr (ks + 1 < 13) {
                     if constexpr (ks & 1) { S2_HREAD(pa, ks + 1) } else { S2_HREAD(pb, ks + 1) }
-                    if constexpr (ks & 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(pb) :: "memory");
-                    else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(pa) :: "memory");
+                    if constexpr (ks & 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(pb[0]), "+v"(pb[1]) :: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(pa[0]), "+v"(pa[1]) :: "memory");
                 } else {
-                    if constexpr (ks & 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pb) :: "memory");
-                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pa) :: "memory");
+                    if constexpr (ks & 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pb[0]), "+v"(pb[1]) :: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pa[0]), "+v"(pa[1]) :: "memory");
                 }
-                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], (ks & 1) ? pb : pa, hacc, 0, 0, 0);
+#pragma unroll
+                for (int z = 0; z < 2; ++z)
+                    hacc[z] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], (ks & 1) ? pb[z] : pa[z], hacc[z], 0, 0, 0);
             }, std::make_integer_sequence<int, 13>{});
 #undef S2_HREAD
-            if (u < S2_BLOCKS) {
-                const uint32_t f = (uint32_t)(((xi >> 2) & 1) | (((hy >> 1) & 1) << 1));
+#pragma unroll
+            for (int z = 0; z < 2; ++z) {
+                if (uu_[z] >= S2_BLOCKS) continue;
+                const uint32_t f = (uint32_t)(((xi_[z] >> 2) & 1) | (((hy_[z] >> 1) & 1) << 1));
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float v[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        v[k] = hacc[q * 4 + k] + bq[q][k];
+                        v[k] = hacc[z][q * 4 + k] + bq[q][k];
                         if (hd.relu) v[k] = fmaxf(v[k], 0.0f);
-                        v[k] = inside ? v[k] : 0.0f;
+                        v[k] = inside_[z] ? v[k] : 0.0f;
                     }
                     const uint2 o = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                    asm volatile("ds_write_b64 %0, %1" :: "v"(pl0 + (uint32_t)(u * 64) + (((uint32_t)q ^ f) << 4) + (uint32_t)(8 * hi)), "v"(o) : "memory");
+                    asm volatile("ds_write_b64 %0, %1" :: "v"(pl0 + (uint32_t)(uu_[z] * 64) + (((uint32_t)q ^ f) << 4) + (uint32_t)(8 * hi)), "v"(o) : "memory");
                 }
             }
         }
@@ -1265,8 +1282,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_halo_kernel(ConvArgs a, S2He
         s2_for_taps([&](auto tc) __attribute__((always_inline)) {
             constexpr int t = decltype(tc)::value, r = t / 5, s = t - r * 5;
             if (t > 0) {
-                if constexpr (S2_RING == 6) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");     // slab sg + 1 has landed (RING - 3
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                            //  younger slabs may be in flight)
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(S2_RING - 3) : "memory");     // slab sg + 1 has landed (RING - 3 younger slabs may be in flight)
                 __builtin_amdgcn_s_barrier();                        // ... for every wave; the buffer of slab sg - 1 is free
             }
             const int nb = buf + 1 == S2_RING ? 0 : buf + 1;         // buffer of slab sg + 1

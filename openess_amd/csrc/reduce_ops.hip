@@ -48,7 +48,10 @@ __global__ __launch_bounds__(THREADS) void norm_stats_kernel(const float* __rest
                                                              int64_t in_stride, int64_t in_off, int vec,
                                                              double* __restrict__ stats) {
     double acc[3] = {0.0, 0.0, 0.0};
-    const float* src = in + in_off + (int64_t)blockIdx.y * in_stride;
+    // blockIdx.z = slice of a multi-slice launch (oess_masked_stats_slices_f32): slice z starts z * L floats further and
+    // accumulates into stats[4 z ..]
+    const float* src = in + in_off + (int64_t)blockIdx.z * L + (int64_t)blockIdx.y * in_stride;
+    stats += 4 * blockIdx.z;
     const int64_t tid = (int64_t)blockIdx.x * THREADS + threadIdx.x, nthr = (int64_t)gridDim.x * THREADS;
     if (vec) {
         // four 16-byte loads in flight per lane; accumulation stays in double (the reference sums in float64-exact order
@@ -617,6 +620,22 @@ int oess_masked_stats_slice_f32(const float* in, int B, int Ctot, int c0, int Cs
     const int vec = ((L & 3) == 0) && ((in_stride & 3) == 0) && ((in_off & 3) == 0) && (((uintptr_t)in & 15) == 0);
     if (B > 65535) return OESS_EINVAL;
     hipLaunchKernelGGL(norm_stats_kernel, norm_grid(L, B, vec), dim3(THREADS), 0, st, in, L, (int64_t)B, in_stride, in_off, vec, stats);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_masked_stats_slices_f32(const float* in, int B, int Ctot, int Cs, int n_slices, int64_t HW, double* stats,
+                                 oess_stream_t stream) {
+    if (!in || !stats || B <= 0 || Ctot <= 0 || Cs <= 0 || n_slices <= 0 || (int64_t)n_slices * Cs > Ctot || HW <= 0 || B > 65535 ||
+        n_slices > 65535)
+        return OESS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    OESS_HIP(hipMemsetAsync(stats, 0, (size_t)n_slices * 4 * sizeof(double), st));
+    const int64_t L = (int64_t)Cs * HW, in_stride = (int64_t)Ctot * HW;
+    const int vec = ((L & 3) == 0) && ((in_stride & 3) == 0) && (((uintptr_t)in & 15) == 0);
+    dim3 grid = norm_grid(L, B, vec);
+    grid.z = (unsigned)n_slices;
+    hipLaunchKernelGGL(norm_stats_kernel, grid, dim3(THREADS), 0, st, in, L, (int64_t)B, in_stride, (int64_t)0, vec, stats);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }

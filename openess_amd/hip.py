@@ -34,6 +34,11 @@ def h2d_async(t, device):
     return t.to(device, non_blocking=True)
 
 
+def _bump(t):
+    """A kernel wrote `t` through its raw pointer: tell autograd / version-keyed caches."""
+    torch.autograd.graph.increment_version(t)
+
+
 _WS_CACHE = {}
 
 
@@ -83,6 +88,7 @@ def voxelize_trilinear(x, y, p, t, seg_offsets, C, H, W, crop_rows=0, count_mode
     _lib.check(lib.oess_voxelize_trilinear_f32(_ptr(x), _ptr(y), _ptr(p), _ptr(t), _ptr(dev), n_seg, max_len, C, H, W,
                                                crop_rows, int(count_mode), _ptr(out), _ptr(ws), ws.numel(), _stream()),
                "oess_voxelize_trilinear_f32")
+    _bump(out)
     return out
 
 
@@ -111,6 +117,7 @@ def voxelize_dsec_raw(x, y, t_us, p, rectify_maps, seg_map, seg_offsets, C, H, W
                                           _ptr(seg_map), rectify_maps.shape[0], _ptr(dev), n_seg, max_len, C, H, W,
                                           crop_rows, int(count_mode), _ptr(out), _ptr(ws), ws.numel(), _stream()),
                "oess_voxelize_dsec_raw")
+    _bump(out)
     return out
 
 
@@ -593,9 +600,33 @@ def convlstm_fused(xh, packed_gates, bias, cell, hidden_out, k, pad, prev_cell_i
     return hidden_out
 
 
+_SLICE_STATS = {}
+
+
+def masked_stats_slices(events, cs, refresh=False):
+    """{sum, sumsq, nnz, -} of every cs-channel slice of a contiguous fp32 [B, Ctot, H, W] tensor in ONE launch -> float64
+    [Ctot // cs, 4].  Cached per (storage, version, shape); `refresh` recomputes (slice 0 of a sub-window loop always does, so
+    that a tensor rewritten through a raw pointer without a version bump cannot be served stale statistics)."""
+    lib = _lib.load()
+    B, Ct, H, W = events.shape
+    key = (events.device.index, torch.cuda.current_stream(events.device).cuda_stream)
+    tag = (events.data_ptr(), events._version, tuple(events.shape), cs)
+    hit = _SLICE_STATS.get(key)
+    if hit is not None and hit[0] == tag and not refresh:
+        return hit[1]
+    n = Ct // cs
+    stats = torch.empty((n, 4), dtype=torch.float64, device=events.device)
+    _lib.check(lib.oess_masked_stats_slices_f32(_ptr(events), B, Ct, cs, n, H * W, _ptr(stats), _stream()),
+               "oess_masked_stats_slices_f32")
+    _SLICE_STATS[key] = (tag, stats)
+    return stats
+
+
 def event_slice_to_nhwc8(events, c0, cs, normalize=True, out=None):
     """events: contiguous fp32 [B, Ctot, H, W]; returns logical [B, 8, H, W] channels_last bf16 holding the
-    (optionally EventPreprocessor-normalised) slice events[:, c0:c0+cs], zero padded to 8 channels."""
+    (optionally EventPreprocessor-normalised) slice events[:, c0:c0+cs], zero padded to 8 channels.
+    When the tensor is a whole number of cs-channel slices (the sub-windows of one sample) the statistics of ALL slices are
+    formed by one launch at the first request and reused for the others."""
     lib = _lib.load()
     _need_gpu(events)
     if events.dtype != torch.float32 or not events.is_contiguous() or events.ndim != 4:
@@ -604,7 +635,9 @@ def event_slice_to_nhwc8(events, c0, cs, normalize=True, out=None):
     if out is None:
         out = torch.empty((B, H, W, 8), dtype=torch.bfloat16, device=events.device)
     stats = None
-    if normalize:
+    if normalize and Ct > cs and Ct % cs == 0 and c0 % cs == 0:
+        stats = masked_stats_slices(events, cs, refresh=(c0 == 0))[c0 // cs]
+    elif normalize:
         stats = torch.empty(4, dtype=torch.float64, device=events.device)
         _lib.check(lib.oess_masked_stats_slice_f32(_ptr(events), B, Ct, c0, cs, H * W, _ptr(stats), _stream()),
                    "oess_masked_stats_slice_f32")

@@ -286,3 +286,26 @@ def test_e2vid_voxel_grid_golden(golden_events):
     with pytest.raises(RuntimeError):
         iu.events_to_voxel_grid_pytorch(ev, 5, W, H, torch.device("cpu"))
 
+
+
+@pytest.mark.gpu
+def test_masked_stats_slices_equal_per_slice_and_track_rewrites():
+    """oess_masked_stats_slices_f32 (all sub-window slices in one launch) == oess_masked_stats_slice_f32 per slice, through the
+    product wrapper: event_slice_to_nhwc8 over the 4 slices of a tensor equals the per-slice path bit for bit, also after the
+    tensor has been rewritten in place (slice 0 always refreshes the cached statistics)."""
+    import torch
+    from openess_amd import hip
+    torch.manual_seed(5)
+    B, n, cs, H, W = 2, 4, 5, 24, 40
+    ev = torch.randn(B, n * cs, H, W, device="cuda")
+    ev[ev.abs() < 0.8] = 0.0
+    for rep in range(2):
+        outs = [hip.event_slice_to_nhwc8(ev, i * cs, cs).clone() for i in range(n)]
+        for i in range(n):
+            single = hip.event_slice_to_nhwc8(ev[:, i * cs:(i + 1) * cs].contiguous(), 0, cs)
+            assert torch.equal(outs[i], single), (rep, i)
+        st = hip.masked_stats_slices(ev, cs).cpu().numpy()
+        for i in range(n):
+            sl = ev[:, i * cs:(i + 1) * cs].double()
+            np.testing.assert_allclose(st[i, :3], [float(sl.sum()), float((sl * sl).sum()), float((sl != 0).sum())], rtol=1e-12)
+        ev.view(-1)[::2].mul_(1.7)                                     # in-place rewrite between the two passes
