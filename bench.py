@@ -512,7 +512,7 @@ def main():
             import contextlib
             import bench_train_loop
             with contextlib.redirect_stdout(sys.stderr):        # the trainer logs to stdout; this script's stdout is ONE JSON line
-                out["train_loop"] = bench_train_loop.measure(batches=24, workers=6, prefetch=True)
+                out["train_loop"] = bench_train_loop.measure(batches=24, workers=10, prefetch=True)
             out["train_loop"]["vs_headline"] = round(out["train_loop"]["value"] / out["value"], 3)
         except Exception as e:      # never cost the headline
             out["train_loop"] = {"error": repr(e)[:300]}
