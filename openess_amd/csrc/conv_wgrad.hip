@@ -186,6 +186,188 @@ __global__ __launch_bounds__(WG) void conv_wgrad_kernel(WgradArgs a) {
         }
 }
 
+// =================================================================================================
+// 128-row tiles, LDS-DMA form.  Same tile, same K-step (64 output pixels of one output row), same partial layout as
+// conv_wgrad_kernel<128>; what changes is how the two operand tiles reach LDS and how the fragments are read:
+//  * both tiles travel HBM/L2 -> LDS by `buffer_load_dwordx4 ... lds` (out-of-range offsets write the zero padding), into a
+//    2-stage ring, ONE raw barrier per K-step, the next step's fetch issued right behind it (the register-staged form paid
+//    8 ds_write_b128 per thread and two __syncthreads per step: its LDS write port time alone, 32 KB at ~79 B/clk, was 0.8 of
+//    the step's MFMA time);
+//  * rows are 256 bytes with no skew (a wave-level DMA instruction fills four whole rows); chunk c of pixel row r lives at slot
+//    c ^ ((r & 3) << 2), which makes the 32 lanes of a ds_read_b64_tr_b16 group (4 rows x 4 chunks) hit all 64 banks once;
+//  * fragments of k-step ks + 1 are read under the MFMAs of k-step ks.
+// LDS 2 x 32 KB -> two workgroups per CU.
+// =================================================================================================
+// TMV = 128 / 64 / 32 output channels per tile as in conv_wgrad_kernel (2 x 2 waves of 64 x 64 / 32 x 64, 1 x 4 waves of 32 x 32):
+// the dY tile keeps its 256-byte rows, lanes whose chunk lies beyond TMV channels fetch nothing (zero fill).
+template <int TMV>
+__global__ __launch_bounds__(WG, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
+    constexpr int WAVES_M = (TMV == 32) ? 1 : 2, WAVES_N = 4 / WAVES_M;
+    constexpr int WMV = TMV / WAVES_M, WNV = TN / WAVES_N;
+    constexpr int MT = WMV / 32, NT = WNV / 32;
+    constexpr int ROWB = 256, TILE_B = KP * ROWB, STAGE_B = 2 * TILE_B;         // A tile + B tile per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tile = blockIdx.x;
+    const int tile_n = tile % a.tiles_n, tile_m = tile / a.tiles_n;
+    const int co0 = tile_m * TMV, kk0 = tile_n * TN;
+    const int split = blockIdx.y;
+    const int row_beg = split * a.rows_per_split;
+    int row_end = row_beg + a.rows_per_split;
+    if (row_end > a.rows_total) row_end = a.rows_total;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    const long long x_bytes = (((long long)a.B * a.H * a.W - 1) * a.xps + a.Cin_x) * 2;
+    const long long d_bytes = (((long long)a.B * a.Ho * a.Wo - 1) * a.dps + a.Cout) * 2;
+    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)d_bytes, 0x00020000);
+
+    // ---- DMA roles: instruction i of this wave fills pixel rows (wave*4 + i)*4 + (lane >> 4), slot = lane & 15
+    const int slot = lane & 15, lr = lane >> 4;
+    const int csrc = slot ^ (lr << 2);                       // (row & 3) == lr for every row this lane fills
+    const int a_co = co0 + csrc * 8;
+    const bool a_ok = a_co < a.Cout && csrc * 8 < TMV;
+    const int kk = kk0 + csrc * 8;
+    const int tap = kk / a.Cin_x, ci0 = kk - tap * a.Cin_x;
+    const bool b_ok = kk < a.Kdim;
+    const int r = tap / a.S, s = tap - r * a.S;
+    const int dyo = r * a.dil - a.pad, dxo = s * a.dil - a.pad;
+    // K-steps walk the split's output pixels in FLAT order, 64 at a time across row (and image) boundaries: a step is always
+    // full except the split's last one (one-row steps waste 37 % of the loads and MFMAs on 80- and 40-pixel-wide maps).
+    // Each lane carries the (image, row, column) of its four pixel rows and advances them by 64 pixels per step.
+    const long long pix_beg = (long long)row_beg * a.Wo, pix_end = (long long)row_end * a.Wo;
+    const int nsteps = (int)((pix_end - pix_beg + KP - 1) / KP);
+    int pb[4], py[4], px[4];
+    long long left[4];                                       // pixels from this lane's pixel row to the end of the split
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pr = (wave * 4 + i) * 4 + lr;
+        const long long p = pix_beg + pr;
+        const long long row = p / a.Wo;
+        px[i] = (int)(p - row * a.Wo);
+        pb[i] = (int)(row / a.Ho);
+        py[i] = (int)(row - (long long)pb[i] * a.Ho);
+        left[i] = pix_end - p;
+    }
+
+    auto issue = [&](int step) {
+        unsigned char* st = smem + (step & 1) * STAGE_B;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool pv = left[i] > 0;
+            const int ox = px[i], oy_ = py[i], b_ = pb[i];
+            const unsigned va = (pv && a_ok) ? (unsigned)(((((long long)b_ * a.Ho + oy_) * a.Wo + ox) * a.dps + a_co) * 2) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (__attribute__((address_space(3))) void*)(st + (wave * 4 + i) * 1024), 16, va, 0, 0, 0);
+            const int iy = oy_ * a.stride + dyo, ix = ox * a.stride + dxo;
+            const bool ok = pv && b_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const unsigned vb = ok ? (unsigned)(((((long long)b_ * a.H + iy) * a.W + ix) * a.xps + ci0) * 2) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(st + TILE_B + (wave * 4 + i) * 1024), 16, vb, 0, 0, 0);
+            // advance this pixel row by one K-step
+            left[i] -= KP;
+            px[i] += KP;
+            while (px[i] >= a.Wo) {
+                px[i] -= a.Wo;
+                if (++py[i] == a.Ho) { py[i] = 0; ++pb[i]; }
+            }
+        }
+    };
+
+    f32x16_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // ---- tr-read geometry (file header): 16-lane group g4, row = 8*(g4>>1) + (li>>2), column = 16*(g4&1) + 4*(li&3)
+    const int g4 = lane >> 4, li = lane & 15;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    const uint32_t tr_row = (uint32_t)((g4 >> 1) * 8 + (li >> 2));
+    const int tr_col = (g4 & 1) * 16 + (li & 3) * 4;         // element column inside a 32-wide sub-tile
+    const uint32_t sw = (uint32_t)(((li >> 2) & 3) << 2);     // (row & 3) << 2: rows are ks*16 + tr_row (+4)
+    uint32_t offA[MT], offB[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int col = wm * WMV + i * 32 + tr_col;          // element column of the A tile (co)
+        offA[i] = tr_row * ROWB + ((((uint32_t)col >> 3) ^ sw) << 4) + (uint32_t)((col & 7) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = wn * WNV + j * 32 + tr_col;          // element column of the B tile (kk)
+        offB[j] = (uint32_t)TILE_B + tr_row * ROWB + ((((uint32_t)col >> 3) ^ sw) << 4) + (uint32_t)((col & 7) * 2);
+    }
+#define OESS_WTR(DST, ADDR) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(DST) : "v"(ADDR) : "memory")
+#define OESS_WREAD(AL, AH, BL, BH, KS)                                                                               \
+    {                                                                                                               \
+        const uint32_t kb_ = stage_ + (uint32_t)((KS) * 16 * ROWB);                                                 \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) { OESS_WTR(AL[i], kb_ + offA[i]); OESS_WTR(AH[i], kb_ + offA[i] + 4 * ROWB); } \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) { OESS_WTR(BL[j], kb_ + offB[j]); OESS_WTR(BH[j], kb_ + offB[j] + 4 * ROWB); } \
+    }
+    // wait for every outstanding LDS read; the "+v" operands tie later uses of the fragments to the wait
+#define OESS_WWAIT(AL, AH, BL, BH)                                                                                  \
+    {                                                                                                               \
+        if constexpr (MT == 2 && NT == 2)                                                                           \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(AL[0]), "+v"(AH[0]), "+v"(AL[1]), "+v"(AH[1]), "+v"(BL[0]), "+v"(BH[0]), "+v"(BL[1]), "+v"(BH[1]) :: "memory"); \
+        else if constexpr (MT == 1 && NT == 2)                                                                      \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(AL[0]), "+v"(AH[0]), "+v"(BL[0]), "+v"(BH[0]), "+v"(BL[1]), "+v"(BH[1]) :: "memory"); \
+        else                                                                                                        \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(AL[0]), "+v"(AH[0]), "+v"(BL[0]), "+v"(BH[0]) :: "memory");  \
+    }
+#define OESS_WMMA(AL, AH, BL, BH)                                                                                   \
+    {                                                                                                               \
+        bf16x8_t fa_[MT], fb_[NT];                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) fa_[i] = __builtin_shufflevector(AL[i], AH[i], 0, 1, 2, 3, 4, 5, 6, 7); \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) fb_[j] = __builtin_shufflevector(BL[j], BH[j], 0, 1, 2, 3, 4, 5, 6, 7); \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                              \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                          \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_[i], fb_[j], acc[i][j], 0, 0, 0);             \
+    }
+
+    if (nsteps > 0) issue(0);
+    for (int step = 0; step < nsteps; ++step) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // step's tiles are in LDS for every wave; the other stage is free
+        if (step + 1 < nsteps) issue(step + 1);
+        const uint32_t stage_ = lds0 + (uint32_t)((step & 1) * STAGE_B);
+        bf16x4_t al0[MT], ah0[MT], bl0[NT], bh0[NT], al1[MT], ah1[MT], bl1[NT], bh1[NT];
+        __builtin_amdgcn_s_setprio(3);
+        // at most 8 LDS reads outstanding (lgkmcnt is a 4-bit counter): wait for k-step ks, issue ks + 1, multiply ks
+        OESS_WREAD(al0, ah0, bl0, bh0, 0)
+        OESS_WWAIT(al0, ah0, bl0, bh0)
+        OESS_WREAD(al1, ah1, bl1, bh1, 1)
+        OESS_WMMA(al0, ah0, bl0, bh0)
+        OESS_WWAIT(al1, ah1, bl1, bh1)
+        OESS_WREAD(al0, ah0, bl0, bh0, 2)
+        OESS_WMMA(al1, ah1, bl1, bh1)
+        OESS_WWAIT(al0, ah0, bl0, bh0)
+        OESS_WREAD(al1, ah1, bl1, bh1, 3)
+        OESS_WMMA(al0, ah0, bl0, bh0)
+        OESS_WWAIT(al1, ah1, bl1, bh1)
+        OESS_WMMA(al1, ah1, bl1, bh1)
+        __builtin_amdgcn_s_setprio(0);
+    }
+#undef OESS_WTR
+#undef OESS_WREAD
+#undef OESS_WWAIT
+#undef OESS_WMMA
+    // ---- epilogue: plain stores of the partial tile; reduced by wgrad_reduce_kernel
+    const int ldn = a.tiles_n * TN;
+    float* P = a.part + (size_t)split * a.tiles_m * TMV * ldn;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int kq = kk0 + wn * WNV + j * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = co0 + wm * WMV + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                P[(size_t)co * ldn + kq] = acc[i][j][e];
+            }
+        }
+}
+
 // dW[co][ci][r][s] = sum over splits of part[split][co][(r,s,ci)]
 // Threads walk the PARTIAL layout (kq = (r,s,ci) contiguous): the `splits` reads per element are coalesced and independent
 // (unrolled by 4); the one write per element is the scattered side.  (Walking the OIHW layout made every read of a 3x3 layer a
@@ -235,7 +417,18 @@ int oess_conv2d_wgrad_bf16(const void* x, long long x_pix_stride, int B, int H, 
     a.rows_total = B * a.Ho;
     const int tiles = a.tiles_m * a.tiles_n;
     const int target = 512;
-    int splits = (target + tiles - 1) / tiles;               // ~2 workgroups per CU: measured best (1024: +3 % step time on frame2recon from the larger partial-sum traffic)
+    const long long x_bytes = (((long long)B * H * W - 1) * x_pix_stride + Cin_x) * 2;
+    const long long d_bytes = (((long long)B * a.Ho * a.Wo - 1) * dy_pix_stride + Cout) * 2;
+    const bool dma = x_bytes < 0x7ffffff0ll && d_bytes < 0x7ffffff0ll;      // 32-bit buffer offsets reach both tensors
+    // split-K over output rows.  Register-staged form: ~512 workgroups (1024: +3 % step time on frame2recon from the larger
+    // partial-sum traffic).  LDS-DMA form (64 KB of LDS: exactly two workgroups per CU = 512 slots): whichever of floor / ceil
+    // (512 / tiles) needs fewer rounds per split -- 36 tiles x 15 splits = 540 workgroups was a 1.05-round launch
+    int splits = (target + tiles - 1) / tiles;
+    if (dma && tiles <= target) {
+        const int lo = target / tiles, hi = splits;
+        auto cost = [&](int sp) { return (double)(((long long)tiles * sp + target - 1) / target) / (double)sp; };
+        splits = cost(lo) < cost(hi) ? lo : hi;
+    }
     const size_t per_split = (size_t)a.tiles_m * tmv * a.tiles_n * TN * sizeof(float);
     if (per_split > workspace_bytes) return OESS_ENOMEM;
     if ((size_t)splits * per_split > workspace_bytes) splits = (int)(workspace_bytes / per_split);
@@ -243,9 +436,25 @@ int oess_conv2d_wgrad_bf16(const void* x, long long x_pix_stride, int B, int H, 
     if (splits < 1) splits = 1;
     a.rows_per_split = (a.rows_total + splits - 1) / splits;
     splits = (a.rows_total + a.rows_per_split - 1) / a.rows_per_split;
-    if (tmv == 32) hipLaunchKernelGGL(conv_wgrad_kernel<32>, dim3(tiles, splits), dim3(WG), 0, (hipStream_t)stream, a);
-    else if (tmv == 64) hipLaunchKernelGGL(conv_wgrad_kernel<64>, dim3(tiles, splits), dim3(WG), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(conv_wgrad_kernel<128>, dim3(tiles, splits), dim3(WG), 0, (hipStream_t)stream, a);
+    const dim3 grid(tiles, splits);
+    hipStream_t st = (hipStream_t)stream;
+    if (dma) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)&conv_wgrad_dma_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)&conv_wgrad_dma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)&conv_wgrad_dma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
+        }
+        const size_t lds = (size_t)2 * 2 * KP * 256;
+        if (tmv == 32) hipLaunchKernelGGL(conv_wgrad_dma_kernel<32>, grid, dim3(WG), lds, st, a);
+        else if (tmv == 64) hipLaunchKernelGGL(conv_wgrad_dma_kernel<64>, grid, dim3(WG), lds, st, a);
+        else hipLaunchKernelGGL(conv_wgrad_dma_kernel<128>, grid, dim3(WG), lds, st, a);
+    } else {
+        if (tmv == 32) hipLaunchKernelGGL(conv_wgrad_kernel<32>, grid, dim3(WG), 0, st, a);
+        else if (tmv == 64) hipLaunchKernelGGL(conv_wgrad_kernel<64>, grid, dim3(WG), 0, st, a);
+        else hipLaunchKernelGGL(conv_wgrad_kernel<128>, grid, dim3(WG), 0, st, a);
+    }
     const long long total = (long long)Cout * a.Kdim;
     long long rg = (total + 255) / 256;
     if (rg > 4096) rg = 4096;

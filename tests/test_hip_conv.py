@@ -143,6 +143,8 @@ def test_conv_dgrad_operator():
     (1, 11, 13, 256, 256, 3, 1, 1, 1),
     (2, 10, 12, 32, 256, 1, 1, 0, 1),      # 1x1 head
     (2, 16, 24, 64, 64, 3, 2, 1, 1),       # stride 2
+    (2, 17, 70, 72, 136, 3, 2, 1, 1),      # stride 2 on the 128-row LDS-DMA form: ragged Cout / Cin / pixel chunks, two chunks per row
+    (8, 55, 80, 256, 256, 3, 1, 1, 1),     # the decoder's 55x80 layers at full size (10 per step)
     (1, 14, 18, 48, 136, 3, 1, 2, 2),      # dilation, ragged tiles
     (2, 8, 130, 8, 16, 5, 1, 2, 1),
     (1, 220, 320, 64, 32, 3, 1, 1, 1),     # decoder layer at scale: 70 400 pixels reduced by the full split-K fan-out
