@@ -368,6 +368,194 @@ __global__ __launch_bounds__(WG, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
         }
 }
 
+// =================================================================================================
+// Narrow layers at full resolution (the decoder's 3x3 convs with Cout <= 64: 440x640 64->32, 220x320 128->64 / 64->64): the
+// WHOLE gradient of a 64-channel input chunk -- TMV output channels x (9 taps x 64 ci) -- lives in one workgroup's accumulators.
+// The 128-wide (tap, channel) tiling read dY once per tile and X once per tap pair (26 FLOP per byte moved to LDS for TMV = 32);
+// here a K-step = 64 output pixels of one row fetches dY once (64 px x TMV) and a 3-row x 66-pixel x 64-channel HALO of X once,
+// and the nine taps' B operands are shifted windows of that halo: 81 FLOP/B (TMV = 32), X is read once from HBM.
+// LDS rows are 128 bytes (one pixel x 64 channels); chunk c of pixel row p sits at slot c ^ (((p >> 1) & 1) << 2): any four
+// consecutive pixel rows x four chunks (one ds_read_b64_tr_b16 lane group, whatever the tap shift) cover all 64 banks once.
+// Four waves share the 18 (tap, 32-channel) sub-tiles round-robin; 2 stages x 34 KB -> two workgroups per CU.
+// =================================================================================================
+constexpr int FR_PR = 68;                                    // halo pixels per X row in LDS (66 used)
+constexpr int FR_HROWS = 3 * FR_PR;                          // 204 pixel rows of 128 B
+constexpr int FR_HINSTR = (FR_HROWS + 7) / 8;                // 26 wave-level DMA instructions (8 pixel rows each)
+constexpr int FR_A_BYTES = KP * 128, FR_B_BYTES = FR_HINSTR * 1024, FR_STAGE = FR_A_BYTES + FR_B_BYTES;
+
+template <int TMV>
+__global__ __launch_bounds__(WG, 2) void conv_wgrad_fullres_kernel(WgradArgs a) {
+    constexpr int MT = TMV / 32;
+    constexpr int NSUB = 18, SPW = (NSUB + 3) / 4;           // sub-tiles per wave (5, 5, 4, 4)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int chunk = blockIdx.x;                            // 64-channel chunk of X
+    const int ci_base = chunk * 64;
+    const int split = blockIdx.y;
+    const int row_beg = split * a.rows_per_split;
+    int row_end = row_beg + a.rows_per_split;
+    if (row_end > a.rows_total) row_end = a.rows_total;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const long long x_bytes = (((long long)a.B * a.H * a.W - 1) * a.xps + a.Cin_x) * 2;
+    const long long d_bytes = (((long long)a.B * a.Ho * a.Wo - 1) * a.dps + a.Cout) * 2;
+    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)d_bytes, 0x00020000);
+
+    // ---- DMA roles.  One instruction = 8 pixel rows x 8 slots of 16 B.
+    const int slot = lane & 7, lr = lane >> 3;
+    // dY: instructions wave*2 + {0,1}: pixel rows (wave*2 + i)*8 + lr
+    int a_px[2], a_coff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int px = (wave * 2 + i) * 8 + lr;
+        const int c = slot ^ (((px >> 1) & 1) << 2);
+        a_px[i] = px;
+        a_coff[i] = (c * 8 < TMV && c * 8 < a.Cout) ? c * 8 : -1;
+    }
+    // X halo: instructions n = wave + 4*i (i < 7, n < 26): halo pixel rows n*8 + lr
+    int h_r[7], h_q[7], h_coff[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int hb = (wave + 4 * i) * 8 + lr;
+        const int r = hb / FR_PR, q = hb - r * FR_PR;
+        const int c = slot ^ (((hb >> 1) & 1) << 2);
+        h_r[i] = r; h_q[i] = q;
+        h_coff[i] = (hb < FR_HROWS && q < KP + 2 && ci_base + c * 8 < a.Cin_x) ? ci_base + c * 8 : -1;
+    }
+    const int spr = (a.Wo + KP - 1) / KP;
+    const int nsteps = (row_end - row_beg) * spr;
+    auto issue = [&](int step) {
+        unsigned char* st = smem + (step & 1) * FR_STAGE;
+        const int row_ = row_beg + step / spr, ox0 = (step % spr) * KP;
+        const int b_ = row_ / a.Ho, oy_ = row_ - b_ * a.Ho;
+        const long long orow = ((long long)b_ * a.Ho + oy_) * a.Wo;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ox = ox0 + a_px[i];
+            const unsigned va = (a_coff[i] >= 0 && ox < a.Wo) ? (unsigned)(((orow + ox) * a.dps + a_coff[i]) * 2) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (__attribute__((address_space(3))) void*)(st + (wave * 2 + i) * 1024), 16, va, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            if (wave + 4 * i >= FR_HINSTR) continue;
+            const int iy = oy_ - 1 + h_r[i], ix = ox0 - 1 + h_q[i];
+            const bool ok = h_coff[i] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const unsigned vb = ok ? (unsigned)(((((long long)b_ * a.H + iy) * a.W + ix) * a.xps + h_coff[i]) * 2) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(st + FR_A_BYTES + (wave + 4 * i) * 1024), 16, vb, 0, 0, 0);
+        }
+    };
+
+    f32x16_t acc[SPW][MT];
+#pragma unroll
+    for (int t = 0; t < SPW; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][i][e] = 0.0f;
+
+    // ---- tr-read geometry: row = 8*(g4>>1) + (li>>2) (pixel inside the 16-pixel k-step), column = 16*(g4&1) + 4*(li&3)
+    const int g4 = lane >> 4, li = lane & 15;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    const int tr_row = (g4 >> 1) * 8 + (li >> 2);
+    const int tr_col = (g4 & 1) * 16 + (li & 3) * 4;
+    // A: pixel row pa = ks*16 + tr_row; swizzle bit from (pa >> 1) & 1 == (tr_row >> 1) & 1
+    uint32_t offA[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int col = i * 32 + tr_col;
+        offA[i] = (uint32_t)(tr_row * 128 + ((((col >> 3) ^ (((tr_row >> 1) & 1) << 2))) << 4) + (col & 7) * 2);
+    }
+    // B: halo pixel row hb = r*68 + ks*16 + tr_row + s; r*68 and ks*16 leave bit 1 alone, so the swizzle bit is that of
+    // tr_row + s.  One offset per (s, 32-channel half).
+    uint32_t offB[3][2];
+#pragma unroll
+    for (int sx = 0; sx < 3; ++sx)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int pr = tr_row + sx, col = hf * 32 + tr_col;
+            offB[sx][hf] = (uint32_t)(FR_A_BYTES + pr * 128 + ((((col >> 3) ^ (((pr >> 1) & 1) << 2))) << 4) + (col & 7) * 2);
+        }
+#define OESS_FTR2(DST, ADDR) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(DST) : "v"(ADDR) : "memory")
+
+    if (nsteps > 0) issue(0);
+    for (int step = 0; step < nsteps; ++step) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (step + 1 < nsteps) issue(step + 1);
+        const uint32_t stage_ = lds0 + (uint32_t)((step & 1) * FR_STAGE);
+        __builtin_amdgcn_s_setprio(3);
+        // fragments of k-step ks + 1 are read under the MFMAs of k-step ks (two register sets)
+        bf16x4_t al[2][MT], ah[2][MT], bl[2][SPW], bh[2][SPW];
+        auto read_ks = [&](int set, int ks) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                OESS_FTR2(al[set][i], stage_ + offA[i] + (uint32_t)(ks * 16 * 128));
+                OESS_FTR2(ah[set][i], stage_ + offA[i] + (uint32_t)(ks * 16 * 128 + 4 * 128));
+            }
+#pragma unroll
+            for (int k = 0; k < SPW; ++k) {
+                const int t = wave + 4 * k;
+                if (t < NSUB) {
+                    const int tp = t >> 1, r = tp / 3, sx = tp - r * 3, hf = t & 1;
+                    const uint32_t ob = hf ? (sx == 0 ? offB[0][1] : (sx == 1 ? offB[1][1] : offB[2][1]))
+                                           : (sx == 0 ? offB[0][0] : (sx == 1 ? offB[1][0] : offB[2][0]));
+                    const uint32_t base = stage_ + (uint32_t)((r * FR_PR + ks * 16) * 128) + ob;
+                    OESS_FTR2(bl[set][k], base);
+                    OESS_FTR2(bh[set][k], base + 4 * 128);
+                }
+            }
+        };
+        auto wait_all = [&](int set) __attribute__((always_inline)) {
+            if constexpr (MT == 2)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(al[set][0]), "+v"(ah[set][0]), "+v"(al[set][1]), "+v"(ah[set][1]), "+v"(bl[set][0]), "+v"(bh[set][0]),
+                             "+v"(bl[set][1]), "+v"(bh[set][1]), "+v"(bl[set][2]), "+v"(bh[set][2]), "+v"(bl[set][3]), "+v"(bh[set][3]), "+v"(bl[set][4]), "+v"(bh[set][4]) :: "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(al[set][0]), "+v"(ah[set][0]), "+v"(bl[set][0]), "+v"(bh[set][0]), "+v"(bl[set][1]), "+v"(bh[set][1]),
+                             "+v"(bl[set][2]), "+v"(bh[set][2]), "+v"(bl[set][3]), "+v"(bh[set][3]), "+v"(bl[set][4]), "+v"(bh[set][4]) :: "memory");
+        };
+        auto mma = [&](int set) __attribute__((always_inline)) {
+            bf16x8_t fa[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = __builtin_shufflevector(al[set][i], ah[set][i], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int k = 0; k < SPW; ++k) {
+                if (wave + 4 * k < NSUB) {
+                    const bf16x8_t fb = __builtin_shufflevector(bl[set][k], bh[set][k], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb, acc[k][i], 0, 0, 0);
+                }
+            }
+        };
+        read_ks(0, 0);
+        wait_all(0); read_ks(1, 1); mma(0);
+        wait_all(1); read_ks(0, 2); mma(1);
+        wait_all(0); read_ks(1, 3); mma(0);
+        wait_all(1); mma(1);
+        __builtin_amdgcn_s_setprio(0);
+    }
+#undef OESS_FTR2
+    // ---- epilogue: partial tile part[split][co][kq], kq = tap * Cin_x + ci (the generic layout: wgrad_reduce_kernel reads it)
+    const int ldn = a.tiles_n * TN;
+    float* P = a.part + (size_t)split * a.tiles_m * TMV * ldn;
+#pragma unroll
+    for (int k = 0; k < SPW; ++k) {
+        const int t = wave + 4 * k;
+        if (t >= NSUB) continue;
+        const int tp = t >> 1, hf = t & 1;
+        const int ci = ci_base + hf * 32 + (lane & 31);
+        if (ci >= a.Cin_x) continue;
+        const int kq = tp * a.Cin_x + ci;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                P[(size_t)co * ldn + kq] = acc[k][i][e];
+            }
+    }
+}
+
 // dW[co][ci][r][s] = sum over splits of part[split][co][(r,s,ci)]
 // Threads walk the PARTIAL layout (kq = (r,s,ci) contiguous): the `splits` reads per element are coalesced and independent
 // (unrolled by 4); the one write per element is the scattered side.  (Walking the OIHW layout made every read of a 3x3 layer a
@@ -392,6 +580,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         dw[((size_t)co * Cin + ci) * RS + tp] = (s0 + s1) + (s2 + s3);
     }
 }
+
+static inline size_t per_split_bytes(const WgradArgs& a, int tmv) { return (size_t)a.tiles_m * tmv * a.tiles_n * TN * sizeof(float); }
 
 }  // namespace
 
@@ -436,8 +626,34 @@ int oess_conv2d_wgrad_bf16(const void* x, long long x_pix_stride, int B, int H, 
     if (splits < 1) splits = 1;
     a.rows_per_split = (a.rows_total + splits - 1) / splits;
     splits = (a.rows_total + a.rows_per_split - 1) / a.rows_per_split;
-    const dim3 grid(tiles, splits);
     hipStream_t st = (hipStream_t)stream;
+    // narrow full-resolution 3x3 layers: the whole (Cout x 9 x 64-channel) gradient per workgroup, X fetched once as a halo
+    // (measured against the 128-wide tiling: 440x640 64->32 390 -> 342 us, 220x320 128->64 267 -> 182; 220x320 64->64 118 -> 131:
+    //  one 64-channel chunk with 64 output channels stays on the generic form)
+    if (dma && R == 3 && S == 3 && stride == 1 && pad == 1 && dil == 1 && Cout <= 64 && (Cin_x % 64) == 0 && a.Wo >= KP &&
+        (long long)a.rows_total * a.Wo >= 200000 && (tmv == 32 || Cin_x >= 128)) {
+        const int chunks = Cin_x / 64;
+        int sp = target / chunks;
+        if (sp > a.rows_total) sp = a.rows_total;
+        if (sp < 1) sp = 1;
+        if ((size_t)sp * per_split_bytes(a, tmv) > workspace_bytes) sp = (int)(workspace_bytes / per_split_bytes(a, tmv));
+        if (sp >= 1) {
+            a.rows_per_split = (a.rows_total + sp - 1) / sp;
+            sp = (a.rows_total + a.rows_per_split - 1) / a.rows_per_split;
+            static bool attr2 = false;
+            if (!attr2) {
+                (void)hipFuncSetAttribute((const void*)&conv_wgrad_fullres_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)&conv_wgrad_fullres_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr2 = true;
+            }
+            if (tmv == 32) hipLaunchKernelGGL(conv_wgrad_fullres_kernel<32>, dim3(chunks, sp), dim3(WG), 2 * FR_STAGE, st, a);
+            else hipLaunchKernelGGL(conv_wgrad_fullres_kernel<64>, dim3(chunks, sp), dim3(WG), 2 * FR_STAGE, st, a);
+            splits = sp;
+            goto reduce;
+        }
+    }
+    {
+    const dim3 grid(tiles, splits);
     if (dma) {
         static bool attr = false;
         if (!attr) {
@@ -455,6 +671,8 @@ int oess_conv2d_wgrad_bf16(const void* x, long long x_pix_stride, int B, int H, 
         else if (tmv == 64) hipLaunchKernelGGL(conv_wgrad_kernel<64>, grid, dim3(WG), 0, st, a);
         else hipLaunchKernelGGL(conv_wgrad_kernel<128>, grid, dim3(WG), 0, st, a);
     }
+    }
+reduce:
     const long long total = (long long)Cout * a.Kdim;
     long long rg = (total + 255) / 256;
     if (rg > 4096) rg = 4096;

@@ -145,6 +145,9 @@ def test_conv_dgrad_operator():
     (2, 16, 24, 64, 64, 3, 2, 1, 1),       # stride 2
     (2, 17, 70, 72, 136, 3, 2, 1, 1),      # stride 2 on the 128-row LDS-DMA form: ragged Cout / Cin / pixel chunks, two chunks per row
     (8, 55, 80, 256, 256, 3, 1, 1, 1),     # the decoder's 55x80 layers at full size (10 per step)
+    (2, 330, 320, 64, 32, 3, 1, 1, 1),     # narrow full-resolution layer: whole-gradient-per-workgroup kernel (X halo), TMV = 32
+    (1, 520, 400, 128, 64, 3, 1, 1, 1),    # same kernel, TMV = 64, two 64-channel chunks, ragged last K-step per row (400 = 6 x 64 + 16)
+    (3, 300, 250, 64, 24, 3, 1, 1, 1),     # Cout not a multiple of 32 (rows 24..31 of the tile stay zero), W % 64 != 0
     (1, 14, 18, 48, 136, 3, 1, 2, 2),      # dilation, ragged tiles
     (2, 8, 130, 8, 16, 5, 1, 2, 1),
     (1, 220, 320, 64, 32, 3, 1, 1, 1),     # decoder layer at scale: 70 400 pixels reduced by the full split-K fan-out
