@@ -139,42 +139,45 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
     // bf16 path: stage the tile as [BM][BN] bf16 in LDS (row pitch BN*2 + 16 bytes against bank conflicts)
     uint16_t* lC = reinterpret_cast<uint16_t*>(smem);
     float* red = red_override ? red_override : reinterpret_cast<float*>(smem + BMX * PITCH * 2);   // [WAVES_M][BN][2] (BatchNorm partials)
-    if (a.stats) {
-        // per-column sum / sum of squares over this tile's rows of the values AS STORED (rounded to bf16): the statistics then
-        // describe exactly the tensor that BatchNorm normalises afterwards (sum of xhat == 0 over the stored values), which
-        // the backward needs -- with statistics of the un-rounded accumulators the residual mean of the rounding errors times
-        // d(beta) leaks into d(gamma), a second noise term as large as the rounding noise itself on common-mode gradients
-        // (measured: BatchNorm weight-gradient cosine 0.74 -> 0.51 on the DeepLab test).  Rows >= M are exact zeros (their A
-        // rows were zero filled; stats are only requested for bias-free convs).
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) { const float v = __uint_as_float(pack_bf16x2(acc[i][j][e], 0.0f) << 16); s1 += v; s2 += v * v; }
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (lane < 32) {
-                const int col = wn * WN + j * 32 + lane;
-                red[(wm * BN + col) * 2 + 0] = s1;
-                red[(wm * BN + col) * 2 + 1] = s2;
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
+    // bf16 image + (optionally) per-column sum / sum of squares over this tile's rows of the values AS STORED (rounded to bf16): the
+    // statistics then describe exactly the tensor that BatchNorm normalises afterwards (sum of xhat == 0 over the stored values),
+    // which the backward needs -- with statistics of the un-rounded accumulators the residual mean of the rounding errors times
+    // d(beta) leaks into d(gamma), a second noise term as large as the rounding noise itself on common-mode gradients (measured:
+    // BatchNorm weight-gradient cosine 0.74 -> 0.51 on the DeepLab test).  Rows >= M are exact zeros (their A rows were zero
+    // filled; stats are only requested for bias-free convs).  One rounding per value serves both the image and the sums.
+    auto stage = [&](auto with_stats) __attribute__((always_inline)) {
+        constexpr bool WS = decltype(with_stats)::value;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int nl = wn * WN + j * 32 + ncol_l;
             const int n = n0 + nl;
             const float bv = (a.bias && n < a.Cout) ? a.bias[n] : 0.0f;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int ml = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                lC[ml * PITCH + nl] = (uint16_t)pack_bf16x2(acc[i][j][e] + bv, 0.0f);      // activation applied after the residual
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ml = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    const uint32_t pk = pack_bf16x2(acc[i][j][e] + bv, 0.0f);      // activation applied after the residual
+                    lC[ml * PITCH + nl] = (uint16_t)pk;
+                    if constexpr (WS) {
+                        const float v = __uint_as_float(pk << 16);
+                        s1 += v; s2 += v * v;
+                    }
+                }
+            if constexpr (WS) {
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (lane < 32) {
+                    const int col = wn * WN + j * 32 + lane;
+                    red[(wm * BN + col) * 2 + 0] = s1;
+                    red[(wm * BN + col) * 2 + 1] = s2;
+                }
             }
         }
+    };
+    if (a.stats) stage(std::true_type{});
+    else stage(std::false_type{});
     __syncthreads();
     if (a.stats && tid < BN) {
         float s1 = 0.f, s2 = 0.f;
