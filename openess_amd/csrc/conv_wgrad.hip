@@ -369,31 +369,37 @@ __global__ __launch_bounds__(WG, 2) void conv_wgrad_dma_kernel(WgradArgs a) {
 }
 
 // =================================================================================================
-// Narrow layers at full resolution (the decoder's 3x3 convs with Cout <= 64: 440x640 64->32, 220x320 128->64 / 64->64): the
-// WHOLE gradient of a 64-channel input chunk -- TMV output channels x (9 taps x 64 ci) -- lives in one workgroup's accumulators.
-// The 128-wide (tap, channel) tiling read dY once per tile and X once per tap pair (26 FLOP per byte moved to LDS for TMV = 32);
-// here a K-step = 64 output pixels of one row fetches dY once (64 px x TMV) and a 3-row x 66-pixel x 64-channel HALO of X once,
-// and the nine taps' B operands are shifted windows of that halo: 81 FLOP/B (TMV = 32), X is read once from HBM.
+// Narrow layers at full resolution (the decoder's 3x3 convs with Cout <= 64: 440x640 64->32, 220x320 128->64): the WHOLE
+// gradient of a 64-channel input chunk -- TMV output channels x (9 taps x 64 ci) -- lives in one workgroup's accumulators.
+// The 128-wide (tap, channel) tiling read dY once per tile and X once per tap pair (26 FLOP per byte moved to LDS for TMV = 32).
+// Here a workgroup walks DOWN a 64-pixel-wide strip of one image; a K-step = one output row of the strip fetches one row of dY
+// (64 px x TMV) and ONE new row of X (66 px x 64 ch; rows oy-1, oy are already in LDS: ring of 6 rows, dY ring of 3, two steps
+// in flight), and the nine taps' B operands are shifted windows of the three resident X rows: X is read once.
 // LDS rows are 128 bytes (one pixel x 64 channels); chunk c of pixel row p sits at slot c ^ (((p >> 1) & 1) << 2): any four
-// consecutive pixel rows x four chunks (one ds_read_b64_tr_b16 lane group, whatever the tap shift) cover all 64 banks once.
-// Four waves share the 18 (tap, 32-channel) sub-tiles round-robin; 2 stages x 34 KB -> two workgroups per CU.
+// consecutive pixel rows x four chunks (one ds_read_b64_tr_b16 lane group, whatever the tap shift) cover all 64 banks once
+// (SQ_LDS_BANK_CONFLICT = 0).  Four waves share the 18 (tap, 32-channel) sub-tiles round-robin; waves 2 and 3 carry a fifth,
+// unused one so that the hot loop has no wave-dependent branch (its first form spent 118 scalar branches per step on them).
+// Work unit = (64-channel chunk, strip, row range); one partial tile per unit.
 // =================================================================================================
-constexpr int FR_PR = 68;                                    // halo pixels per X row in LDS (66 used)
-constexpr int FR_HROWS = 3 * FR_PR;                          // 204 pixel rows of 128 B
-constexpr int FR_HINSTR = (FR_HROWS + 7) / 8;                // 26 wave-level DMA instructions (8 pixel rows each)
-constexpr int FR_A_BYTES = KP * 128, FR_B_BYTES = FR_HINSTR * 1024, FR_STAGE = FR_A_BYTES + FR_B_BYTES;
+constexpr int ST_XROW = 9 * 1024;                            // 72 pixel-row slots of 128 B (66 used): 9 wave-level DMA instructions
+constexpr int ST_XRING = 6, ST_DRING = 3, ST_DROW = KP * 128;
+constexpr int ST_LDS = ST_XRING * ST_XROW + ST_DRING * ST_DROW;   // 79 872 -> two workgroups per CU
 
 template <int TMV>
-__global__ __launch_bounds__(WG, 2) void conv_wgrad_fullres_kernel(WgradArgs a) {
+__global__ __launch_bounds__(WG, 2) void conv_wgrad_strip_kernel(WgradArgs a, int row_splits, int rows_per) {
     constexpr int MT = TMV / 32;
-    constexpr int NSUB = 18, SPW = (NSUB + 3) / 4;           // sub-tiles per wave (5, 5, 4, 4)
+    constexpr int NSUB = 18, SPW = (NSUB + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int chunk = blockIdx.x;                            // 64-channel chunk of X
+    const int chunk = blockIdx.x;
     const int ci_base = chunk * 64;
-    const int split = blockIdx.y;
-    const int row_beg = split * a.rows_per_split;
-    int row_end = row_beg + a.rows_per_split;
-    if (row_end > a.rows_total) row_end = a.rows_total;
+    const int unit = blockIdx.y;                             // (strip, row range)
+    const int strip = unit / row_splits, rs = unit - strip * row_splits;
+    const int spr = (a.Wo + KP - 1) / KP;
+    const int b_ = strip / spr, ox0 = (strip - b_ * spr) * KP;
+    const int r0 = rs * rows_per;
+    int r1 = r0 + rows_per;
+    if (r1 > a.Ho) r1 = a.Ho;
+    const int nsteps = r1 - r0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -402,9 +408,8 @@ __global__ __launch_bounds__(WG, 2) void conv_wgrad_fullres_kernel(WgradArgs a) 
     __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)x_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)d_bytes, 0x00020000);
 
-    // ---- DMA roles.  One instruction = 8 pixel rows x 8 slots of 16 B.
     const int slot = lane & 7, lr = lane >> 3;
-    // dY: instructions wave*2 + {0,1}: pixel rows (wave*2 + i)*8 + lr
+    // dY row: instructions wave*2 + {0,1}: pixels (wave*2 + i)*8 + lr
     int a_px[2], a_coff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -413,36 +418,36 @@ __global__ __launch_bounds__(WG, 2) void conv_wgrad_fullres_kernel(WgradArgs a) 
         a_px[i] = px;
         a_coff[i] = (c * 8 < TMV && c * 8 < a.Cout) ? c * 8 : -1;
     }
-    // X halo: instructions n = wave + 4*i (i < 7, n < 26): halo pixel rows n*8 + lr
-    int h_r[7], h_q[7], h_coff[7];
+    // X row: instructions n = wave + 4*i (n < 9): halo pixels q = n*8 + lr (q = 0 is column ox0 - 1)
+    int h_q[3], h_coff[3];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const int hb = (wave + 4 * i) * 8 + lr;
-        const int r = hb / FR_PR, q = hb - r * FR_PR;
-        const int c = slot ^ (((hb >> 1) & 1) << 2);
-        h_r[i] = r; h_q[i] = q;
-        h_coff[i] = (hb < FR_HROWS && q < KP + 2 && ci_base + c * 8 < a.Cin_x) ? ci_base + c * 8 : -1;
+    for (int i = 0; i < 3; ++i) {
+        const int q = (wave + 4 * i) * 8 + lr;
+        const int c = slot ^ (((q >> 1) & 1) << 2);
+        h_q[i] = q;
+        h_coff[i] = (q < KP + 2 && ci_base + c * 8 < a.Cin_x) ? ci_base + c * 8 : -1;
     }
-    const int spr = (a.Wo + KP - 1) / KP;
-    const int nsteps = (row_end - row_beg) * spr;
-    auto issue = [&](int step) {
-        unsigned char* st = smem + (step & 1) * FR_STAGE;
-        const int row_ = row_beg + step / spr, ox0 = (step % spr) * KP;
-        const int b_ = row_ / a.Ho, oy_ = row_ - b_ * a.Ho;
-        const long long orow = ((long long)b_ * a.Ho + oy_) * a.Wo;
+    auto issue_x = [&](int iy) {                             // image row iy (may be -1 or H: zero fill) -> ring slot (iy + 1) % 6
+        unsigned char* dst = smem + ((iy + 1) % ST_XRING) * ST_XROW;
+        const bool row_ok = (unsigned)iy < (unsigned)a.H;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (wave + 4 * i >= 9) continue;
+            const int ix = ox0 - 1 + h_q[i];
+            const bool ok = row_ok && h_coff[i] >= 0 && (unsigned)ix < (unsigned)a.W;
+            const unsigned vb = ok ? (unsigned)(((((long long)b_ * a.H + iy) * a.W + ix) * a.xps + h_coff[i]) * 2) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(dst + (wave + 4 * i) * 1024), 16, vb, 0, 0, 0);
+        }
+    };
+    auto issue_d = [&](int oy) {                             // output row oy -> ring slot oy % 3 (rows >= r1: zero fill, never used)
+        unsigned char* dst = smem + ST_XRING * ST_XROW + (oy % ST_DRING) * ST_DROW;
+        const bool row_ok = oy < r1;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int ox = ox0 + a_px[i];
-            const unsigned va = (a_coff[i] >= 0 && ox < a.Wo) ? (unsigned)(((orow + ox) * a.dps + a_coff[i]) * 2) : 0x80000000u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (__attribute__((address_space(3))) void*)(st + (wave * 2 + i) * 1024), 16, va, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            if (wave + 4 * i >= FR_HINSTR) continue;
-            const int iy = oy_ - 1 + h_r[i], ix = ox0 - 1 + h_q[i];
-            const bool ok = h_coff[i] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const unsigned vb = ok ? (unsigned)(((((long long)b_ * a.H + iy) * a.W + ix) * a.xps + h_coff[i]) * 2) : 0x80000000u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(st + FR_A_BYTES + (wave + 4 * i) * 1024), 16, vb, 0, 0, 0);
+            const bool ok = row_ok && a_coff[i] >= 0 && ox < a.Wo;
+            const unsigned va = ok ? (unsigned)(((((long long)b_ * a.Ho + oy) * a.Wo + ox) * a.dps + a_coff[i]) * 2) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (__attribute__((address_space(3))) void*)(dst + (wave * 2 + i) * 1024), 16, va, 0, 0, 0);
         }
     };
 
@@ -454,56 +459,67 @@ __global__ __launch_bounds__(WG, 2) void conv_wgrad_fullres_kernel(WgradArgs a) 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][i][e] = 0.0f;
 
-    // ---- tr-read geometry: row = 8*(g4>>1) + (li>>2) (pixel inside the 16-pixel k-step), column = 16*(g4&1) + 4*(li&3)
     const int g4 = lane >> 4, li = lane & 15;
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
     const int tr_row = (g4 >> 1) * 8 + (li >> 2);
     const int tr_col = (g4 & 1) * 16 + (li & 3) * 4;
-    // A: pixel row pa = ks*16 + tr_row; swizzle bit from (pa >> 1) & 1 == (tr_row >> 1) & 1
     uint32_t offA[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int col = i * 32 + tr_col;
         offA[i] = (uint32_t)(tr_row * 128 + ((((col >> 3) ^ (((tr_row >> 1) & 1) << 2))) << 4) + (col & 7) * 2);
     }
-    // B: halo pixel row hb = r*68 + ks*16 + tr_row + s; r*68 and ks*16 leave bit 1 alone, so the swizzle bit is that of
-    // tr_row + s.  One offset per (s, 32-channel half).
     uint32_t offB[3][2];
 #pragma unroll
     for (int sx = 0; sx < 3; ++sx)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             const int pr = tr_row + sx, col = hf * 32 + tr_col;
-            offB[sx][hf] = (uint32_t)(FR_A_BYTES + pr * 128 + ((((col >> 3) ^ (((pr >> 1) & 1) << 2))) << 4) + (col & 7) * 2);
+            offB[sx][hf] = (uint32_t)(pr * 128 + ((((col >> 3) ^ (((pr >> 1) & 1) << 2))) << 4) + (col & 7) * 2);
         }
 #define OESS_FTR2(DST, ADDR) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(DST) : "v"(ADDR) : "memory")
+    // this wave's sub-tiles t = wave + 4k: tap = t >> 1 (X row r = tap / 3, shift sx = tap % 3), channel half = t & 1; t >= 18 (the
+    // fifth sub-tile of waves 2, 3) is computed on sub-tile 0's operands and dropped at the end
+    int sub_r[SPW];
+    uint32_t sub_off[SPW];
+#pragma unroll
+    for (int k = 0; k < SPW; ++k) {
+        const int t = wave + 4 * k < NSUB ? wave + 4 * k : 0;
+        const int tp = t >> 1, r = tp / 3, sx = tp - r * 3, hf = t & 1;
+        sub_r[k] = r;
+        sub_off[k] = hf ? (sx == 0 ? offB[0][1] : (sx == 1 ? offB[1][1] : offB[2][1])) : (sx == 0 ? offB[0][0] : (sx == 1 ? offB[1][0] : offB[2][0]));
+    }
 
-    if (nsteps > 0) issue(0);
+    // prologue: rows r0-1, r0 | group 0 = (X row r0+1, dY r0) | group 1 = (X row r0+2, dY r0+1)
+    issue_x(r0 - 1); issue_x(r0);
+    issue_x(r0 + 1); issue_d(r0);
+    issue_x(r0 + 2); issue_d(r0 + 1);
     for (int step = 0; step < nsteps; ++step) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (step + 1 < nsteps) issue(step + 1);
-        const uint32_t stage_ = lds0 + (uint32_t)((step & 1) * FR_STAGE);
+        const int oy = r0 + step;
+        // group `step` has landed; group step+1 (this wave: 3 or 2 X instructions + 2 dY instructions) may stay in flight
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // ... for every wave; the slots of rows oy-3 / dY oy-1 are free
+        issue_x(oy + 3); issue_d(oy + 2);
+        const uint32_t abase = lds0 + (uint32_t)(ST_XRING * ST_XROW + (oy % ST_DRING) * ST_DROW);
+        uint32_t xb[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) xb[r] = lds0 + (uint32_t)(((oy + r) % ST_XRING) * ST_XROW);      // image row oy - 1 + r
         __builtin_amdgcn_s_setprio(3);
-        // fragments of k-step ks + 1 are read under the MFMAs of k-step ks (two register sets)
         bf16x4_t al[2][MT], ah[2][MT], bl[2][SPW], bh[2][SPW];
+        uint32_t bb[SPW];                                    // this step's B base of every sub-tile (ring slot of its X row)
+#pragma unroll
+        for (int k = 0; k < SPW; ++k) bb[k] = (sub_r[k] == 0 ? xb[0] : (sub_r[k] == 1 ? xb[1] : xb[2])) + sub_off[k];
         auto read_ks = [&](int set, int ks) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                OESS_FTR2(al[set][i], stage_ + offA[i] + (uint32_t)(ks * 16 * 128));
-                OESS_FTR2(ah[set][i], stage_ + offA[i] + (uint32_t)(ks * 16 * 128 + 4 * 128));
+                OESS_FTR2(al[set][i], abase + offA[i] + (uint32_t)(ks * 16 * 128));
+                OESS_FTR2(ah[set][i], abase + offA[i] + (uint32_t)(ks * 16 * 128 + 4 * 128));
             }
 #pragma unroll
             for (int k = 0; k < SPW; ++k) {
-                const int t = wave + 4 * k;
-                if (t < NSUB) {
-                    const int tp = t >> 1, r = tp / 3, sx = tp - r * 3, hf = t & 1;
-                    const uint32_t ob = hf ? (sx == 0 ? offB[0][1] : (sx == 1 ? offB[1][1] : offB[2][1]))
-                                           : (sx == 0 ? offB[0][0] : (sx == 1 ? offB[1][0] : offB[2][0]));
-                    const uint32_t base = stage_ + (uint32_t)((r * FR_PR + ks * 16) * 128) + ob;
-                    OESS_FTR2(bl[set][k], base);
-                    OESS_FTR2(bh[set][k], base + 4 * 128);
-                }
+                OESS_FTR2(bl[set][k], bb[k] + (uint32_t)(ks * 16 * 128));
+                OESS_FTR2(bh[set][k], bb[k] + (uint32_t)(ks * 16 * 128 + 4 * 128));
             }
         };
         auto wait_all = [&](int set) __attribute__((always_inline)) {
@@ -520,11 +536,9 @@ __global__ __launch_bounds__(WG, 2) void conv_wgrad_fullres_kernel(WgradArgs a) 
             for (int i = 0; i < MT; ++i) fa[i] = __builtin_shufflevector(al[set][i], ah[set][i], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int k = 0; k < SPW; ++k) {
-                if (wave + 4 * k < NSUB) {
-                    const bf16x8_t fb = __builtin_shufflevector(bl[set][k], bh[set][k], 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8_t fb = __builtin_shufflevector(bl[set][k], bh[set][k], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb, acc[k][i], 0, 0, 0);
-                }
+                for (int i = 0; i < MT; ++i) acc[k][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb, acc[k][i], 0, 0, 0);
             }
         };
         read_ks(0, 0);
@@ -535,9 +549,9 @@ __global__ __launch_bounds__(WG, 2) void conv_wgrad_fullres_kernel(WgradArgs a) 
         __builtin_amdgcn_s_setprio(0);
     }
 #undef OESS_FTR2
-    // ---- epilogue: partial tile part[split][co][kq], kq = tap * Cin_x + ci (the generic layout: wgrad_reduce_kernel reads it)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the look-ahead groups beyond the last row (zero fills) have landed
     const int ldn = a.tiles_n * TN;
-    float* P = a.part + (size_t)split * a.tiles_m * TMV * ldn;
+    float* P = a.part + (size_t)unit * a.tiles_m * TMV * ldn;
 #pragma unroll
     for (int k = 0; k < SPW; ++k) {
         const int t = wave + 4 * k;
@@ -578,6 +592,48 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         }
         for (; k < splits; ++k) s0 += p[(size_t)k * sstride];
         dw[((size_t)co * Cin + ci) * RS + tp] = (s0 + s1) + (s2 + s3);
+    }
+}
+
+// Many slices of a small gradient (the strip / whole-gradient kernels: ~500 slices of 18 432 elements):
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ part, int splits, int Mpad, int ldn,
+                                                                int Cout, int Cin, int Cin_x, int RS, float* __restrict__ dw) {
+    // 32 consecutive (r,s,ci) elements x 8 split lanes per workgroup: lane l adds splits l, l + 8, ... in order (four independent
+    // chains), the eight lane sums are added in lane order through LDS -- a fixed association whatever the launch geometry.
+    // (One thread per element walked all `splits` slices itself: with the strip / whole-gradient kernels' ~500 slices of a
+    // 18 432-element gradient that was 72 workgroups x 480 dependent reads = ~120 us, more than the gradient kernel.)
+    __shared__ float red[8][32];
+    const int kdim = RS * Cin_x;
+    const long long total = (long long)Cout * kdim;
+    const size_t sstride = (size_t)Mpad * ldn;
+    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    for (long long i0 = (long long)blockIdx.x * 32; i0 < total; i0 += (long long)gridDim.x * 32) {
+        const long long i = i0 + el;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int co = 0, tp = 0, ci = Cin;
+        if (i < total) {
+            co = (int)(i / kdim);
+            const int kq = (int)(i - (long long)co * kdim);
+            tp = kq / Cin_x; ci = kq - tp * Cin_x;
+            if (ci < Cin) {
+                const float* p = part + (size_t)co * ldn + kq;
+                int k = sl;
+                for (; k + 24 < splits; k += 32) {
+                    s0 += p[(size_t)k * sstride]; s1 += p[(size_t)(k + 8) * sstride];
+                    s2 += p[(size_t)(k + 16) * sstride]; s3 += p[(size_t)(k + 24) * sstride];
+                }
+                for (; k < splits; k += 8) s0 += p[(size_t)k * sstride];
+            }
+        }
+        red[sl][el] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (sl == 0 && i < total && ci < Cin) {
+            float t = red[0][el];
+#pragma unroll
+            for (int l = 1; l < 8; ++l) t += red[l][el];
+            dw[((size_t)co * Cin + ci) * RS + tp] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -631,24 +687,25 @@ int oess_conv2d_wgrad_bf16(const void* x, long long x_pix_stride, int B, int H, 
     // (measured against the 128-wide tiling: 440x640 64->32 390 -> 342 us, 220x320 128->64 267 -> 182; 220x320 64->64 118 -> 131:
     //  one 64-channel chunk with 64 output channels stays on the generic form)
     if (dma && R == 3 && S == 3 && stride == 1 && pad == 1 && dil == 1 && Cout <= 64 && (Cin_x % 64) == 0 && a.Wo >= KP &&
-        (long long)a.rows_total * a.Wo >= 200000 && (tmv == 32 || Cin_x >= 128)) {
+        (long long)a.rows_total * a.Wo >= 100000) {
         const int chunks = Cin_x / 64;
-        int sp = target / chunks;
-        if (sp > a.rows_total) sp = a.rows_total;
-        if (sp < 1) sp = 1;
-        if ((size_t)sp * per_split_bytes(a, tmv) > workspace_bytes) sp = (int)(workspace_bytes / per_split_bytes(a, tmv));
-        if (sp >= 1) {
-            a.rows_per_split = (a.rows_total + sp - 1) / sp;
-            sp = (a.rows_total + a.rows_per_split - 1) / a.rows_per_split;
+        const int spr = (a.Wo + KP - 1) / KP, strips = B * spr;
+        int rsplit = (target / chunks) / strips;                     // row ranges per strip: at most 512 workgroups in all (one round)
+        if (rsplit < 1) rsplit = 1;
+        if (rsplit > a.Ho) rsplit = a.Ho;
+        int rows_per = (a.Ho + rsplit - 1) / rsplit;
+        rsplit = (a.Ho + rows_per - 1) / rows_per;
+        const long long units = (long long)strips * rsplit;
+        if (units * per_split_bytes(a, tmv) <= workspace_bytes && units <= 65535) {
             static bool attr2 = false;
             if (!attr2) {
-                (void)hipFuncSetAttribute((const void*)&conv_wgrad_fullres_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute((const void*)&conv_wgrad_fullres_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)&conv_wgrad_strip_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)&conv_wgrad_strip_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr2 = true;
             }
-            if (tmv == 32) hipLaunchKernelGGL(conv_wgrad_fullres_kernel<32>, dim3(chunks, sp), dim3(WG), 2 * FR_STAGE, st, a);
-            else hipLaunchKernelGGL(conv_wgrad_fullres_kernel<64>, dim3(chunks, sp), dim3(WG), 2 * FR_STAGE, st, a);
-            splits = sp;
+            if (tmv == 32) hipLaunchKernelGGL(conv_wgrad_strip_kernel<32>, dim3(chunks, (unsigned)units), dim3(WG), ST_LDS, st, a, rsplit, rows_per);
+            else hipLaunchKernelGGL(conv_wgrad_strip_kernel<64>, dim3(chunks, (unsigned)units), dim3(WG), ST_LDS, st, a, rsplit, rows_per);
+            splits = (int)units;
             goto reduce;
         }
     }
@@ -674,10 +731,17 @@ int oess_conv2d_wgrad_bf16(const void* x, long long x_pix_stride, int B, int H, 
     }
 reduce:
     const long long total = (long long)Cout * a.Kdim;
-    long long rg = (total + 255) / 256;
-    if (rg > 4096) rg = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rg), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, splits,
-                       a.tiles_m * tmv, a.tiles_n * TN, Cout, Cin, Cin_x, R * S, dw_oihw);
+    if (splits >= 16) {         // many slices: 8 split lanes per element (fixed-order combine)
+        long long rg = (total + 31) / 32;
+        if (rg > 8192) rg = 8192;
+        hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)rg), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
+                           splits, a.tiles_m * tmv, a.tiles_n * TN, Cout, Cin, Cin_x, R * S, dw_oihw);
+    } else {
+        long long rg = (total + 255) / 256;
+        if (rg > 4096) rg = 4096;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rg), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, splits,
+                           a.tiles_m * tmv, a.tiles_n * TN, Cout, Cin, Cin_x, R * S, dw_oihw);
+    }
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }
