@@ -148,6 +148,8 @@ def test_conv_dgrad_operator():
     (2, 330, 320, 64, 32, 3, 1, 1, 1),     # narrow full-resolution layer: whole-gradient-per-workgroup kernel (X halo), TMV = 32
     (1, 520, 400, 128, 64, 3, 1, 1, 1),    # same kernel, TMV = 64, two 64-channel chunks, ragged last K-step per row (400 = 6 x 64 + 16)
     (3, 300, 250, 64, 24, 3, 1, 1, 1),     # Cout not a multiple of 32 (rows 24..31 of the tile stay zero), W % 64 != 0
+    (2, 400, 130, 192, 48, 3, 1, 1, 1),    # three 64-channel chunks, Cout 48 on the 64-row tile, a 2-pixel-wide last strip
+    (1, 7, 15000, 64, 32, 3, 1, 1, 1),     # very wide, 7 rows: more strips than workgroup slots, row ranges of one or two rows
     (1, 14, 18, 48, 136, 3, 1, 2, 2),      # dilation, ragged tiles
     (2, 8, 130, 8, 16, 5, 1, 2, 1),
     (1, 220, 320, 64, 32, 3, 1, 1, 1),     # decoder layer at scale: 70 400 pixels reduced by the full split-K fan-out
