@@ -1544,7 +1544,7 @@ __global__ __launch_bounds__(256) void conv_fwd_dma32_kernel(ConvArgs a) {
 // pixel per register quad and stores them as 8-byte pieces.
 // =================================================================================================
 template <int R, int S>
-__global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_smallcin_kernel(ConvArgs a) {
     // PERSISTENT over tiles: the weights are fetched once per workgroup, and the halo of the NEXT tile travels
     // HBM -> registers while the current tile is multiplied and stored, so a tile costs its LDS / MFMA / store work and
     // not a load round trip on top (one tile per workgroup measured 111 us for 180 MB of traffic: 3x the HBM time).

@@ -119,7 +119,7 @@ __device__ __forceinline__ abf16x4_t att_tr_read(uint32_t lds_addr) {
     return v;
 }
 
-__global__ __launch_bounds__(THREADS) void attention_d64_mfma_kernel(const uint16_t* __restrict__ qkv, int64_t qs, int B, int L,
+__global__ __launch_bounds__(THREADS, 3) void attention_d64_mfma_kernel(const uint16_t* __restrict__ qkv, int64_t qs, int B, int L,
                                                                      int heads, float scale, uint16_t* __restrict__ out, int64_t os) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * KST + 2 * VST];          // [K stage 0][K stage 1][V stage 0][V stage 1]
     const int C = heads * 64;
