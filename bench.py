@@ -417,6 +417,8 @@ def main():
                              "frame2voxel_pixel_distill_online"],
                     help="..._online: the pseudo-labels are argmax of the frozen MaskCLIP ViT-B/16 tower run inside the step "
                          "(SURVEY 8f rank 1) instead of the offline PNG labels the reference reads")
+    ap.add_argument("--wavefront", action="store_true", help="headline workload with the recurrent encoder on the wavefront schedule "
+                    "(one HIP stream per ConvLSTM level; same results; per-launch durations of the roofline object overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC child passes (roofline.traffic = null)")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only: no stages / configs / ingest blocks")
@@ -438,7 +440,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     inputs = make_inputs(rank, device)
-    wl = Workload(a.workload, rank, world, device, inputs, force_buckets=launched and world == 1)
+    wl = Workload(a.workload, rank, world, device, inputs, wavefront=a.wavefront, force_buckets=launched and world == 1)
     if a.child:
         wl.timed(a.steps, a.warmup)
         return
