@@ -251,6 +251,15 @@ int oess_convlstm_gates_bf16(const void* gates, long long gates_pix_stride, cons
  * enc_w_packed of the [64, 32, 5, 5] weight; *_relu in {0, 1}; out: NHWC bf16 [B, (H-1)/2+1, (W-1)/2+1, 64] view, pixel stride
  * out_pix_stride (a channel slice of the ConvLSTM's cat(x, h) buffer), 16-byte aligned.  Same result as the two
  * oess_conv2d_fwd_bf16 calls (the head output rounded to bf16 in between, as there). */
+/* The same kernel fed from the fp32 event tensor [B, Ctot, H, W]: the EventPreprocessor apply of the slice events[:, c0:c0+Cs]
+ * (e2vid/utils/inference_utils.py:80-85; stats = {sum, sumsq, nnz} from oess_masked_stats_slice(s)_f32, normalize = 0 skips it)
+ * and the zero-padded 8-channel bf16 packing happen per patch inside the kernel: the NHWC8 tensor of
+ * oess_event_slice_to_nhwc8_bf16 is never written either.  Cs <= 5.  Same result as that call followed by
+ * oess_e2vid_head_enc0_bf16. */
+int oess_e2vid_events_head_enc0_bf16(const float* events, int B, int Ctot, int c0, int Cs, int H, int W, const double* stats,
+                                     int normalize, const void* head_w_packed, const float* head_bias, int head_relu,
+                                     const void* enc_w_packed, const float* enc_bias, int enc_relu, void* out,
+                                     long long out_pix_stride, oess_stream_t stream);
 int oess_e2vid_head_enc0_bf16(const void* x8, long long x8_pix_stride, int B, int H, int W, const void* head_w_packed,
                               const float* head_bias, int head_relu, const void* enc_w_packed, const float* enc_bias, int enc_relu,
                               void* out, long long out_pix_stride, oess_stream_t stream);

@@ -81,6 +81,7 @@ SIGNATURES = {
                                        c_int, c_int, c_int, c_vp, c_vp, c_sz, c_vp]),
     "oess_conv2d_packed_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     "oess_conv2d_pack_weight": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
+    "oess_e2vid_events_head_enc0_bf16": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_ll, c_vp]),
     "oess_e2vid_head_enc0_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_ll, c_vp]),
     "oess_conv2d_fwd_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,
                                      c_int, c_int, c_int, c_vp, c_ll, c_vp, c_vp, c_ll, c_vp, c_vp, c_sz, c_vp]),

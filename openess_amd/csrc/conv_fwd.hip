@@ -1052,6 +1052,11 @@ struct S2Head {              // FUSED: the encoder's input is relu(conv5x5(x8, h
     const uint16_t* hw;      // packed head weight [128][256] (rows 0..31 used, k = tap * 8 + channel)
     const float* hb;         // [32] or null
     int relu;
+    // ev != null: the 8-channel input is formed on the fly from the fp32 NCHW event tensor (EventPreprocessor apply + NHWC8
+    // bf16 re-layout of oess_event_slice_to_nhwc8_bf16, same arithmetic): x8 is not read
+    const float* ev;         // [B][Ctot][H][W] fp32
+    int Ctot, c0, Cs, normalize;
+    const double* stats;     // {sum, sumsq, nnz} of the slice
 };
 constexpr int S2_IMG_PITCH = 72;                                     // bf16 output image [128 pixels][64 + 8]
 
@@ -1083,7 +1088,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_halo_kernel(ConvArgs a, S2He
 
     const long long in_bytes = FUSED ? (((long long)a.B * a.H * a.W - 1) * hd.x8_stride + 8) * 2
                                      : (((long long)a.B * a.H * a.W - 1) * a.in_pix_stride + a.Cin) * 2;
-    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(FUSED ? (void*)hd.x8 : (void*)a.in, 0, (int)in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(FUSED ? (void*)hd.x8 : (void*)a.in, 0, (FUSED && !hd.x8) ? 0 : (int)in_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7ffffff0, 0x00020000);
 
     // ---- halo DMA geometry: lane (block lb = lane >> 2, slot = lane & 3) of instruction i writes block u = (wave*11 + i)*16 + lb
@@ -1179,18 +1184,61 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_halo_kernel(ConvArgs a, S2He
 #pragma unroll
             for (int ks = 0; ks < 13; ++ks) wf[ks] = *reinterpret_cast<const bf16x8_t*>(hd.hw + (size_t)p32 * 256 + (ks * 2 + hi) * 8);
         }
+        if (hd.ev) {
+            // voxel patch straight from the fp32 event tensor: the slice's EventPreprocessor normalisation (inference_utils.py:80-85,
+            // the float32 operation order of norm_to_nhwc8_kernel) and the 8-channel bf16 packing happen here, per patch
 #pragma unroll
-        for (int i = 0; i < S2_VINSTR; ++i) {
-            const int v = (wave * S2_VINSTR + i) * 64 + lane;
-            const int vy = v / S2_VW, vx = v - vy * S2_VW;
-            const int iy = 2 * oy0 - 4 + vy, ix = 2 * ox0 - 4 + vx;
-            const bool ok = v < S2_VH * S2_VW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const unsigned voff = ok ? (unsigned)((((long long)b * a.H + iy) * a.W + ix) * hd.x8_stride * 2) : 0x80000000u;
-            if (wave * S2_VINSTR + i < S2_VTOTAL)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vox + (wave * S2_VINSTR + i) * 1024), 16, voff, 0, 0, 0);
+            for (int s = 0; s < S2_RING - 1; ++s) issue_w(s, s);
+            const double nnz = hd.stats ? hd.stats[2] : 0.0;
+            const bool active = hd.normalize && nnz > 0.0;
+            float mean = 0.f, stdv = 1.f;
+            if (active) {
+                const float nf = (float)nnz;
+                mean = (float)hd.stats[0] / nf;
+                stdv = sqrtf(__fsub_rn((float)hd.stats[1] / nf, __fmul_rn(mean, mean)));
+            }
+            const long long hw_ = (long long)a.H * a.W;
+            float raw[4][5];
+            bool okv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int v = tid + 256 * i;
+                const int vy = v / S2_VW, vx = v - vy * S2_VW;
+                const int iy = 2 * oy0 - 4 + vy, ix = 2 * ox0 - 4 + vx;
+                okv[i] = v < S2_VH * S2_VW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const float* src = hd.ev + ((long long)b * hd.Ctot + hd.c0) * hw_ + (long long)iy * a.W + ix;
+#pragma unroll
+                for (int c = 0; c < 5; ++c) raw[i][c] = (okv[i] && c < hd.Cs) ? src[c * hw_] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int v = tid + 256 * i;
+                float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    float q = raw[i][c];
+                    if (active) q = __fmul_rn((q != 0.0f) ? 1.0f : 0.0f, __fsub_rn(q, mean)) / stdv;
+                    f[c] = (okv[i] && c < hd.Cs) ? q : 0.0f;
+                }
+                const u32x4_t o = {pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+                if (v < S2_VTOTAL * 64)
+                    asm volatile("ds_write_b128 %0, %1" :: "v"((uint32_t)(uintptr_t)vox + (uint32_t)(v * 16)), "v"(o) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+#pragma unroll
+            for (int i = 0; i < S2_VINSTR; ++i) {
+                const int v = (wave * S2_VINSTR + i) * 64 + lane;
+                const int vy = v / S2_VW, vx = v - vy * S2_VW;
+                const int iy = 2 * oy0 - 4 + vy, ix = 2 * ox0 - 4 + vx;
+                const bool ok = v < S2_VH * S2_VW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const unsigned voff = ok ? (unsigned)((((long long)b * a.H + iy) * a.W + ix) * hd.x8_stride * 2) : 0x80000000u;
+                if (wave * S2_VINSTR + i < S2_VTOTAL)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vox + (wave * S2_VINSTR + i) * 1024), 16, voff, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < S2_RING - 1; ++s) issue_w(s, s);
         }
-#pragma unroll
-        for (int s = 0; s < S2_RING - 1; ++s) issue_w(s, s);
         float bq[4][4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -2005,13 +2053,8 @@ int oess_convlstm_fused_bf16(const void* in, long long in_pix_stride, int B, int
                          nullptr, nullptr, 0, nullptr, &l, stream);
 }
 
-int oess_e2vid_head_enc0_bf16(const void* x8, long long x8_pix_stride, int B, int H, int W, const void* head_w_packed,
-                              const float* head_bias, int head_relu, const void* enc_w_packed, const float* enc_bias, int enc_relu,
-                              void* out, long long out_pix_stride, oess_stream_t stream) {
-    if (!x8 || !head_w_packed || !enc_w_packed || !out || B <= 0 || H <= 0 || W <= 0 || (x8_pix_stride & 7) || x8_pix_stride < 8 ||
-        (out_pix_stride & 7) || out_pix_stride < 64 || (((uintptr_t)out) & 15) || (unsigned)head_relu > 1u || (unsigned)enc_relu > 1u)
-        return OESS_EINVAL;
-    if ((((long long)B * H * W - 1) * x8_pix_stride + 8) * 2 >= 0x7ffffff0ll) return OESS_EINVAL;     // 32-bit buffer offsets
+static int e2vid_head_enc0_launch(const S2Head& hd, int B, int H, int W, const void* enc_w_packed, const float* enc_bias, int enc_relu,
+                                  void* out, long long out_pix_stride, oess_stream_t stream) {
     conv_set_attrs();
     ConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -2022,10 +2065,32 @@ int oess_e2vid_head_enc0_bf16(const void* x8, long long x8_pix_stride, int B, in
     a.M = B * a.Ho * a.Wo; a.relu = enc_relu;
     a.tiles_n = 1;
     a.tiles_m = B * ((a.Ho + S2_PH - 1) / S2_PH) * ((a.Wo + S2_PW - 1) / S2_PW);
-    S2Head hd{(const uint16_t*)x8, x8_pix_stride, (const uint16_t*)head_w_packed, head_bias, head_relu};
     hipLaunchKernelGGL((conv5x5s2_halo_kernel<true>), dim3(a.tiles_m), dim3(256), S2_LDS_FUSED, (hipStream_t)stream, a, hd);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
+}
+
+int oess_e2vid_events_head_enc0_bf16(const float* events, int B, int Ctot, int c0, int Cs, int H, int W, const double* stats,
+                                     int normalize, const void* head_w_packed, const float* head_bias, int head_relu,
+                                     const void* enc_w_packed, const float* enc_bias, int enc_relu, void* out,
+                                     long long out_pix_stride, oess_stream_t stream) {
+    if (!events || !head_w_packed || !enc_w_packed || !out || B <= 0 || H <= 0 || W <= 0 || Ctot <= 0 || c0 < 0 || Cs <= 0 ||
+        Cs > 5 || c0 + Cs > Ctot || (normalize && !stats) || (out_pix_stride & 7) || out_pix_stride < 64 || (((uintptr_t)out) & 15) ||
+        (unsigned)head_relu > 1u || (unsigned)enc_relu > 1u)
+        return OESS_EINVAL;
+    S2Head hd{nullptr, 8, (const uint16_t*)head_w_packed, head_bias, head_relu, events, Ctot, c0, Cs, normalize, stats};
+    return e2vid_head_enc0_launch(hd, B, H, W, enc_w_packed, enc_bias, enc_relu, out, out_pix_stride, stream);
+}
+
+int oess_e2vid_head_enc0_bf16(const void* x8, long long x8_pix_stride, int B, int H, int W, const void* head_w_packed,
+                              const float* head_bias, int head_relu, const void* enc_w_packed, const float* enc_bias, int enc_relu,
+                              void* out, long long out_pix_stride, oess_stream_t stream) {
+    if (!x8 || !head_w_packed || !enc_w_packed || !out || B <= 0 || H <= 0 || W <= 0 || (x8_pix_stride & 7) || x8_pix_stride < 8 ||
+        (out_pix_stride & 7) || out_pix_stride < 64 || (((uintptr_t)out) & 15) || (unsigned)head_relu > 1u || (unsigned)enc_relu > 1u)
+        return OESS_EINVAL;
+    if ((((long long)B * H * W - 1) * x8_pix_stride + 8) * 2 >= 0x7ffffff0ll) return OESS_EINVAL;     // 32-bit buffer offsets
+    S2Head hd{(const uint16_t*)x8, x8_pix_stride, (const uint16_t*)head_w_packed, head_bias, head_relu, nullptr, 0, 0, 0, 0, nullptr};
+    return e2vid_head_enc0_launch(hd, B, H, W, enc_w_packed, enc_bias, enc_relu, out, out_pix_stride, stream);
 }
 
 }  // extern "C"

@@ -36,14 +36,21 @@ class ImageReconstructor:
             else:
                 events, (c0, cs) = event_tensor, channel_slice
             import contextlib
-            first = torch.cuda.stream(wavefront.streams[0]) if wavefront is not None else contextlib.nullcontext()
-            with first:                               # EventPreprocessor + re-layout belong to level 0's stream
-                x = self.event_preprocessor.slice_to_nhwc8(events, c0, cs)
-                if self.crop.needs_pad:
-                    x = self.crop.pad(x.float()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             kw = {} if wavefront is None else {'wavefront': wavefront}
             if not need_latents and not reconstruct:
                 kw['need_head'] = False
+            unet = getattr(self.model, 'unetrecurrent', None)
+            if (not need_latents and not reconstruct and not self.crop.needs_pad and unet is not None
+                    and unet.events_fusable(events, cs)):
+                # EventPreprocessor apply + NHWC8 re-layout + head + encoder-0 conv in ONE kernel, straight from the event tensor
+                kw['raw'] = (events, c0, cs, not self.event_preprocessor.no_normalize)
+                x = None
+            else:
+                first = torch.cuda.stream(wavefront.streams[0]) if wavefront is not None else contextlib.nullcontext()
+                with first:                               # EventPreprocessor + re-layout belong to level 0's stream
+                    x = self.event_preprocessor.slice_to_nhwc8(events, c0, cs)
+                    if self.crop.needs_pad:
+                        x = self.crop.pad(x.float()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             img, states, latent = self.model(x, self.last_states_for_each_channel['grayscale'], reconstruct=reconstruct, **kw)
             self.last_states_for_each_channel['grayscale'] = None if self.no_recurrent else states
         return img, states, latent

@@ -46,20 +46,36 @@ class UNetRecurrent(nn.Module):
                 and not (m.norm == 'BN' and m.norm_layer.training)
         return ok and h.conv2d.in_channels <= 8
 
-    def _head_enc0(self, x, prev_state):
+    def _head_enc0(self, x, prev_state, raw=None):
         """Encoder 0's conv output straight from the voxel slice (the 32-channel head output is never written): fills the x half
-        of the level-0 cat(x, h) buffer and returns the state."""
+        of the level-0 cat(x, h) buffer and returns the state.  raw = (events fp32 [B, Ctot, H, W], c0, cs, normalize): the slice is
+        normalised and packed inside the kernel as well (x is not needed)."""
         from ... import engine, hip
         h, e = self.head, self.encoders[0]
-        state = prev_state if prev_state is not None else e.new_state(x)
+        state = prev_state if prev_state is not None else e.new_state(raw[0] if raw is not None else x)
         pwh = h._pw.get(h.conv2d.weight, h.conv2d.bias, h.norm_layer if h.norm == 'BN' else None, cin_pad=8)
         ec = e.conv
         pwe = ec._pw.get(ec.conv2d.weight, ec.conv2d.bias, ec.norm_layer if ec.norm == 'BN' else None, cin_pad=32)
-        hip.e2vid_head_enc0(engine.nhwc(x), pwh.packed, pwh.bias, h.activation_name == 'relu', pwe.packed, pwe.bias,
-                            ec.activation_name == 'relu', out=engine.nhwc(state['xh'][state['cur']][:, :64]))
+        out = engine.nhwc(state['xh'][state['cur']][:, :64])
+        if raw is not None:
+            ev, c0, cs, normalize = raw
+            hip.e2vid_events_head_enc0(ev, c0, cs, normalize, pwh.packed, pwh.bias, h.activation_name == 'relu', pwe.packed, pwe.bias,
+                                       ec.activation_name == 'relu', out=out)
+        else:
+            hip.e2vid_head_enc0(engine.nhwc(x), pwh.packed, pwh.bias, h.activation_name == 'relu', pwe.packed, pwe.bias,
+                                ec.activation_name == 'relu', out=out)
         return state
 
-    def forward(self, x, prev_states, reconstruct=False, wavefront=None, need_head=True):
+    def events_fusable(self, events, cs):
+        """True when `forward(None, ..., need_head=False, raw=(events, c0, cs, normalize))` may replace EventPreprocessor + NHWC8
+        re-layout + head + encoder-0 conv by one kernel."""
+        import torch
+        if not (events.is_cuda and events.dtype == torch.float32 and events.is_contiguous() and events.ndim == 4 and 0 < cs <= 5):
+            return False
+        probe = torch.empty((1, 8, 1, 1), dtype=torch.bfloat16, device=events.device)
+        return self._head_enc0_fusable(probe)
+
+    def forward(self, x, prev_states, reconstruct=False, wavefront=None, need_head=True, raw=None):
         """x: logical [B, 8, H, W] channels_last bf16 (bins zero-padded to 8).  Returns (img | None, states, latent):
         the training path stops at the latents; `reconstruct=True` also runs the residual blocks, decoders and the
         prediction layer (unet.py:160-170) and returns the [B, 1, H, W] fp32 image in [0, 1] (offline reconstruction).
@@ -71,7 +87,7 @@ class UNetRecurrent(nn.Module):
         blocks, states = [], []
         if wavefront is not None and not reconstruct:
             import torch
-            fuse = not need_head and self._head_enc0_fusable(x)
+            fuse = raw is not None or (not need_head and self._head_enc0_fusable(x))
             head = None
             if not fuse:
                 with torch.cuda.stream(wavefront.streams[0]):
@@ -80,7 +96,7 @@ class UNetRecurrent(nn.Module):
             for i, encoder in enumerate(self.encoders):
                 with torch.cuda.stream(wavefront.streams[i]):
                     wavefront.before_conv(i)
-                    state = self._head_enc0(x, prev_states[0]) if (fuse and i == 0) else encoder.run_conv(x, prev_states[i])
+                    state = self._head_enc0(x, prev_states[0], raw) if (fuse and i == 0) else encoder.run_conv(x, prev_states[i])
                     wavefront.after_conv(i)
                     wavefront.before_lstm(i)
                     x = encoder.recurrent_block.step(state)
@@ -88,14 +104,14 @@ class UNetRecurrent(nn.Module):
                 blocks.append(x)
                 states.append(state)
         else:
-            fuse = not need_head and not reconstruct and self._head_enc0_fusable(x)
+            fuse = raw is not None or (not need_head and not reconstruct and self._head_enc0_fusable(x))
             head = None
             if not fuse:
                 x = self.head(x)
                 head = x
             for i, encoder in enumerate(self.encoders):
                 if fuse and i == 0:
-                    state = self._head_enc0(x, prev_states[0])
+                    state = self._head_enc0(x, prev_states[0], raw)
                     x = encoder.recurrent_block.step(state)
                 else:
                     x, state = encoder(x, prev_states[i])

@@ -566,6 +566,36 @@ def e2vid_head_enc0(x8, head_packed, head_bias, head_relu, enc_packed, enc_bias,
     return out
 
 
+def e2vid_events_head_enc0(events, c0, cs, normalize, head_packed, head_bias, head_relu, enc_packed, enc_bias, enc_relu, out=None):
+    """e2vid_head_enc0 fed from the fp32 event tensor [B, Ctot, H, W]: the slice's EventPreprocessor normalisation and the
+    NHWC8 bf16 packing happen inside the kernel (no intermediate tensor at all between the voxel grid and encoder 0's output)."""
+    lib = _lib.load()
+    _need_gpu(events, head_packed, enc_packed)
+    if events.dtype != torch.float32 or not events.is_contiguous() or events.ndim != 4:
+        raise ValueError("needs contiguous float32 [B, C, H, W]")
+    B, Ct, H, W = events.shape
+    if cs > 5 or c0 < 0 or c0 + cs > Ct:
+        raise ValueError("bad channel slice")
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, 64), dtype=torch.bfloat16, device=events.device)
+    _, _, _, _, ops = _nhwc_geom(out)
+    if tuple(out.shape) != (B, Ho, Wo, 64):
+        raise ValueError(f"bad output shape {tuple(out.shape)} != {(B, Ho, Wo, 64)}")
+    stats = None
+    if normalize and Ct > cs and Ct % cs == 0 and c0 % cs == 0:
+        stats = masked_stats_slices(events, cs, refresh=(c0 == 0))[c0 // cs]
+    elif normalize:
+        stats = torch.empty(4, dtype=torch.float64, device=events.device)
+        _lib.check(lib.oess_masked_stats_slice_f32(_ptr(events), B, Ct, c0, cs, H * W, _ptr(stats), _stream()),
+                   "oess_masked_stats_slice_f32")
+    _lib.check(lib.oess_e2vid_events_head_enc0_bf16(_ptr(events), B, Ct, c0, cs, H, W, _ptr(stats), int(bool(normalize)),
+                                                    _ptr(head_packed), _ptr(head_bias), int(bool(head_relu)), _ptr(enc_packed),
+                                                    _ptr(enc_bias), int(bool(enc_relu)), _ptr(out), ops, _stream()),
+               "oess_e2vid_events_head_enc0_bf16")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ pointwise
 def convlstm_gates(gates, cell, hidden_out, prev_cell_is_zero=False):
     """gates: bf16 NHWC [B,H,W,4C]; cell: fp32 [B,H,W,C] (updated in place); hidden_out: bf16 NHWC view

@@ -424,3 +424,28 @@ def test_e2vid_head_enc0_fused_equals_two_convs(geom):
     one2 = hip.e2vid_head_enc0(x8, ph, None, False, pe, None, False)
     ref2 = ref_conv(ref_conv(x8, wh, None, 1, 2, 1).bfloat16(), we, None, 2, 2, 1)
     np.testing.assert_allclose(one2.float().cpu().numpy(), ref2.cpu().numpy(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("geom", [(8, 440, 640), (3, 37, 51), (2, 64, 96)])
+@pytest.mark.parametrize("normalize", [True, False])
+def test_e2vid_events_head_enc0_equals_relayout_plus_fused(geom, normalize):
+    """oess_e2vid_events_head_enc0_bf16 (EventPreprocessor apply + NHWC8 packing inside the fused head / encoder-0 kernel) ==
+    oess_event_slice_to_nhwc8_bf16 followed by oess_e2vid_head_enc0_bf16, bit for bit, on the third of four 5-bin slices."""
+    from openess_amd import hip
+    B, H, W = geom
+    torch.manual_seed(sum(geom) + int(normalize))
+    ev = torch.randn(B, 20, H, W, device="cuda")
+    ev[ev.abs() < 0.7] = 0.0
+    wh = torch.zeros(32, 8, 5, 5, device="cuda")
+    wh[:, :5] = torch.randn(32, 5, 5, 5, device="cuda") / np.sqrt(125)
+    bh = torch.randn(32, device="cuda") * 0.1
+    we = torch.randn(64, 32, 5, 5, device="cuda") / np.sqrt(800)
+    be = torch.randn(64, device="cuda") * 0.1
+    ph, pe = hip.pack_conv_weight(wh), hip.pack_conv_weight(we)
+    x8 = hip.event_slice_to_nhwc8(ev, 10, 5, normalize=normalize)                  # logical [B, 8, H, W] channels_last
+    two = hip.e2vid_head_enc0(x8.permute(0, 2, 3, 1), ph, bh, True, pe, be, True)
+    one = hip.e2vid_events_head_enc0(ev, 10, 5, normalize, ph, bh, True, pe, be, True)
+    assert torch.equal(one, two)
+    # a tensor that is exactly one slice (the reference-contract call form) takes the single-slice statistics
+    sl = ev[:, 10:15].contiguous()
+    assert torch.equal(hip.e2vid_events_head_enc0(sl, 0, 5, normalize, ph, bh, True, pe, be, True), two)
