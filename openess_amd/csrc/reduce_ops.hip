@@ -634,6 +634,14 @@ int oess_masked_stats_slices_f32(const float* in, int B, int Ctot, int Cs, int n
     const int64_t L = (int64_t)Cs * HW, in_stride = (int64_t)Ctot * HW;
     const int vec = ((L & 3) == 0) && ((in_stride & 3) == 0) && (((uintptr_t)in & 15) == 0);
     dim3 grid = norm_grid(L, B, vec);
+    {   // norm_grid caps a launch at 256 workgroups because all of them add into ONE triple of doubles; here every slice has its
+        // own triple, so the cap applies per slice: up to 4x more workgroups per slice keep the 720 MB pass on the HBM roofline
+        int64_t gx = (L / (vec ? 4 : 1) + THREADS * 8 - 1) / (THREADS * 8);
+        int64_t cap = 1024 / B;
+        if (cap < 1) cap = 1;
+        if (gx > cap) gx = cap;
+        if (gx > (int64_t)grid.x) grid.x = (unsigned)gx;
+    }
     grid.z = (unsigned)n_slices;
     hipLaunchKernelGGL(norm_stats_kernel, grid, dim3(THREADS), 0, st, in, L, (int64_t)B, in_stride, (int64_t)0, vec, stats);
     OESS_HIP(hipGetLastError());
