@@ -194,7 +194,7 @@ def pmc_traffic(timeout_s=420):
 
 # ------------------------------------------------------------------------------------------------ the step
 class Workload:
-    def __init__(self, name, rank, world, device, inputs, wavefront=False, force_buckets=False):
+    def __init__(self, name, rank, world, device, inputs, wavefront=False, force_buckets=False, skew=True):
         from openess_amd.training.ddp import GradAllReduce, broadcast_module_states
         from openess_amd.training.pretrain_step import PretrainStep
         self.name, self.device, self.world = name, device, world
@@ -209,6 +209,8 @@ class Workload:
         self.step = PretrainStep(config_option=self.option, img_size=(H_NET, W_SENSOR), nr_events_data=NWIN, nr_temporal_bins=C,
                                  if_spatial_contrastive=self.contrastive, superpixel_size=100, device=device,
                                  online_teacher=self.online_teacher, wavefront=wavefront)
+        if not skew and getattr(self.step, "reconstructor", None) is not None:
+            self.step.reconstructor.skew = False
         if world > 1:      # identical initial weights on every rank
             broadcast_module_states(self.step.models_dict.values())
         # force_buckets: launched by torch.distributed.run with ONE rank -> the whole bucket / hook / RCCL all-reduce path still runs
@@ -419,6 +421,8 @@ def main():
                          "(SURVEY 8f rank 1) instead of the offline PNG labels the reference reads")
     ap.add_argument("--wavefront", action="store_true", help="headline workload with the recurrent encoder on the wavefront schedule "
                     "(one HIP stream per ConvLSTM level; same results; per-launch durations of the roofline object overlap)")
+    ap.add_argument("--no-skew", action="store_true", help="recurrent encoder in the plain order (one ConvLSTM launch per level and "
+                    "sub-window) instead of the default skewed schedule with grouped launches; same results (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC child passes (roofline.traffic = null)")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only: no stages / configs / ingest blocks")
@@ -440,7 +444,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     inputs = make_inputs(rank, device)
-    wl = Workload(a.workload, rank, world, device, inputs, wavefront=a.wavefront, force_buckets=launched and world == 1)
+    wl = Workload(a.workload, rank, world, device, inputs, wavefront=a.wavefront, force_buckets=launched and world == 1, skew=not a.no_skew)
     if a.child:
         wl.timed(a.steps, a.warmup)
         return

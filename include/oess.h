@@ -276,6 +276,18 @@ int oess_convlstm_fused_bf16(const void* in, long long in_pix_stride, int B, int
                              const float* prev_cell, float* cell, void* hidden, long long hidden_pix_stride,
                              oess_stream_t stream);
 
+/* n <= 3 INDEPENDENT ConvLSTM steps (arguments as oess_convlstm_fused_bf16) in ONE launch: the three levels of E2VID's recurrent
+ * encoder (e2vid/model/unet.py:141-150) on the skewed schedule, where level l works on sub-window s - l, so the three Gates
+ * convolutions of a stage have no dependency on each other.  Results are those of n separate calls (same tiles, same arithmetic);
+ * what the single launch saves is each level's partial last round of tiles and two launch gaps.  No output (hidden, cell) of one
+ * problem may overlap any buffer of another (checked).  Geometries the row-halo kernel does not take run as n launches. */
+typedef struct {
+    const void* in; long long in_pix_stride; int B, H, W, Cin;
+    const void* w_packed_gates; const float* bias; int C_hidden, R, S, pad;
+    const float* prev_cell; float* cell; void* hidden; long long hidden_pix_stride;
+} oess_convlstm_desc_t;
+int oess_convlstm_fused_group_bf16(const oess_convlstm_desc_t* problems, int n, oess_stream_t stream);
+
 /* Statistics of a channel slice without the apply pass (first half of K2): stats = {sum, sumsq, nnz, -}. */
 /* ... and of n_slices consecutive Cs-channel slices in ONE launch (the 20 sub-windows of a pre-training sample are known up
  * front, pretrain_trainer.py:437-441): stats[4 z ..] = {sum, sumsq, nnz, -} of in[:, z*Cs : (z+1)*Cs]. */

@@ -18,6 +18,13 @@ c_d = ctypes.c_double
 c_vp = ctypes.c_void_p
 c_sz = ctypes.c_size_t
 
+class ConvLstmDesc(ctypes.Structure):
+    """oess_convlstm_desc_t (include/oess.h): one problem of oess_convlstm_fused_group_bf16."""
+    _fields_ = [("in_", c_vp), ("in_pix_stride", c_ll), ("B", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int),
+                ("w_packed_gates", c_vp), ("bias", c_vp), ("C_hidden", c_int), ("R", c_int), ("S", c_int), ("pad", c_int),
+                ("prev_cell", c_vp), ("cell", c_vp), ("hidden", c_vp), ("hidden_pix_stride", c_ll)]
+
+
 # name -> (restype, argtypes).  Must list EVERY symbol of include/oess.h (tests/test_abi.py checks).
 SIGNATURES = {
     "oess_abi_version": (c_int, []),
@@ -45,6 +52,7 @@ SIGNATURES = {
     "oess_convlstm_gates_bf16": (c_int, [c_vp, c_ll, c_vp, c_vp, c_vp, c_ll, c_ll, c_int, c_vp]),
     "oess_convlstm_fused_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp,
                                          c_vp, c_vp, c_ll, c_vp]),
+    "oess_convlstm_fused_group_bf16": (c_int, [c_vp, c_int, c_vp]),
     "oess_loss_partials_bytes": (c_sz, []),
     "oess_l1_mean_fwd": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
     "oess_l1_mean_bwd": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]),

@@ -822,21 +822,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a) {
 // =================================================================================================
 constexpr int HALO_ROWS = 160;
 
+// one 128 x 128 tile (`bid` = tile index after the XCD remap); smem = [halo 0][halo 1][weights 0][weights 1]
 template <int EPI>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv3x3_halo_tile(const ConvArgs& a, const int bid, unsigned char* smem) {
     constexpr int BMX = 128, BN = 128, NWAVES = 4, WAVES_N = 2, WM = 64, WN = 64, MT = 2, NT = 2;
     constexpr int H_INSTR = HALO_ROWS / 8 / NWAVES;      // 5 DMA instructions per thread per halo
     constexpr int B_INSTR = BN * 8 / 64 / NWAVES;        // 4
     constexpr int HALO_BYTES = HALO_ROWS * 128, BST_BYTES = BN * 128;
     constexpr int NFRAG = MT + NT;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [halo 0][halo 1][weights 0][weights 1]
 
-    const int nwg = a.tiles_m * a.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
     const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
     const int m0 = tile_m * BMX, n0 = tile_n * BN;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1008,6 +1002,44 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a) {
 
     if constexpr (EPI == 1) lstm_epilogue<MT, NT, true, false>(a, acc, smem, m0, n0, wm, wn, lane, tid, &pref);
     else conv_epilogue<BMX, BN, BN + 8, 256, WAVES_N>(a, acc, smem, m0, n0, wm, wn, lane, tid);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nwg = a.tiles_m * a.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    conv3x3_halo_tile<EPI>(a, bid, smem);
+}
+
+// Up to three INDEPENDENT problems of the kernel above in one launch (the three ConvLSTM levels of E2VID's recurrent encoder
+// on the skewed schedule: level l works on sub-window s - l, e2vid/model/unet.py mirror).  Alone, the levels are 18.75 /
+// 9.4 / 4.7 rounds of tiles over the 512 workgroup slots and each pays its own partial last round and launch gap; together
+// they are 32.8 rounds.  The host orders the problems by K, longest tiles first, so that the launch ends on the short ones.
+// Workgroup blockIdx = 8 * idx + xcd: problem p owns idx in [start8[p], start8[p + 1]) on every XCD, and inside it the tiles
+// are dealt to the XCDs in contiguous chunks exactly as the single-problem kernel does (neighbouring tiles share halo rows
+// and weight slabs in that XCD's L2).
+struct ConvGroup {
+    ConvArgs a[3];
+    int start8[4];           // problem p owns idx in [start8[p], start8[p + 1]); absent problems: empty ranges at the end
+};
+template <int EPI>
+__global__ __launch_bounds__(256) void conv3x3_halo_group_kernel(ConvGroup g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    // (alternating the short-K tiles with the long-K ones, so that a CU's two workgroups differ in kind, was measured: -2.8 %
+    //  against this problem-after-problem order -- the problems' weight slabs and halos evict each other from the XCD's L2)
+    const int p = (idx >= g.start8[1] ? 1 : 0) + (idx >= g.start8[2] ? 1 : 0);
+    const int li = idx - g.start8[p];
+    const ConvArgs& a = g.a[p];
+    const int nwg = a.tiles_m * a.tiles_n;
+    const int q = nwg >> 3, r = nwg & 7;
+    if (li >= q + (xcd < r ? 1 : 0)) return;             // padding of a problem whose tile count is not a multiple of 8
+    conv3x3_halo_tile<EPI>(a, (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + li, smem);
 }
 
 // =================================================================================================
@@ -1798,7 +1830,7 @@ void conv_set_attrs() {
                              (const void*)&conv_fwd_dma_kernel<128, 128, 2, true>, (const void*)&conv_fwd_dma_kernel<128, 64, 2, true>, (const void*)&conv_fwd_dma_kernel<128, 32, 2, true>,
                              (const void*)&conv_fwd_dma_kernel<64, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<64, 128, 2, true>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 2, false, 1>, (const void*)&conv_fwd_dma_kernel<128, 128, 2, true, 1>,
-                             (const void*)&conv3x3_halo_kernel<0>, (const void*)&conv3x3_halo_kernel<1>,
+                             (const void*)&conv3x3_halo_kernel<0>, (const void*)&conv3x3_halo_kernel<1>, (const void*)&conv3x3_halo_group_kernel<1>,
                              (const void*)&conv_fwd_dma_kernel<256, 256, 2, true>,
                              (const void*)&conv_fwd_dma32_kernel<128, true, 0, 3>, (const void*)&conv5x5s2_halo_kernel<false>,
                              (const void*)&conv5x5s2_halo_kernel<true>};
@@ -1811,8 +1843,12 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
                   const float* bias, int Cout, int R, int S, int stride, int pad, int dil, int relu,
                   const void* residual, long long res_pix_stride, void* out_bf16, float* out_f32,
                   long long out_pix_stride, float* tile_stats, const LstmOut* lstm, oess_stream_t stream,
-                  void* workspace = nullptr, size_t workspace_bytes = 0, size_t* want_workspace = nullptr) {
+                  void* workspace = nullptr, size_t workspace_bytes = 0, size_t* want_workspace = nullptr,
+                  ConvArgs* capture = nullptr) {
+    // capture != null (ConvLSTM only): fill *capture with the launch arguments of the row-halo kernel instead of launching it;
+    // OESS_EINVAL when the geometry takes another kernel (the caller then launches the problems one by one)
     if (want_workspace) *want_workspace = 0;
+    if (capture && !lstm) return OESS_EINVAL;
     if (lstm) {
         if (!lstm->cell || !lstm->h || lstm->C <= 0 || (lstm->C & 31) || Cout != 4 * lstm->C || (lstm->h_stride & 1) ||
             lstm->h_stride < lstm->C || residual || relu || tile_stats || out_f32 || stride != 1)
@@ -1913,6 +1949,7 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
     if (R == 3 && S == 3 && stride == 1 && pad == dil && fastk && bn == 128 && a.Kpad == 9 * Cin && a.Ho == H && a.Wo == W &&
         (dil + 127 + dil * ((BM + W - 2) / W) + dil + 1) <= HALO_ROWS && !want64) {
         if (want_workspace) return OESS_OK;
+        if (capture) { *capture = a; return OESS_OK; }
         const size_t lds = (size_t)2 * HALO_ROWS * 128 + (size_t)2 * 128 * 128;
         if (lstm) hipLaunchKernelGGL((conv3x3_halo_kernel<1>), grid, block, lds, st, a);
         else hipLaunchKernelGGL((conv3x3_halo_kernel<0>), grid, block, lds, st, a);
@@ -1920,6 +1957,7 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
         return OESS_OK;
     }
     // (3) fused ConvLSTM cell update on geometries the halo kernel does not take
+    if (capture) return OESS_EINVAL;
     if (lstm) {
         const size_t lds = (size_t)2 * (BM + 128) * 8 * 16;
         if (fastk) hipLaunchKernelGGL((conv_fwd_dma_kernel<128, 128, 2, true, 1>), grid, block, lds, st, a);
@@ -2051,6 +2089,62 @@ int oess_convlstm_fused_bf16(const void* in, long long in_pix_stride, int B, int
     LstmOut l{prev_cell, cell, hidden, hidden_pix_stride, C_hidden};
     return conv_fwd_impl(in, in_pix_stride, B, H, W, Cin, w_packed_gates, bias, 4 * C_hidden, R, S, 1, pad, 1, 0, nullptr, 0,
                          nullptr, nullptr, 0, nullptr, &l, stream);
+}
+
+int oess_convlstm_fused_group_bf16(const oess_convlstm_desc_t* d, int n, oess_stream_t stream) {
+    if (!d || n <= 0 || n > 3) return OESS_EINVAL;
+    auto span = [](const void* p, long long pixels, long long stride, int c, const char** lo, const char** hi) {
+        *lo = (const char*)p; *hi = *lo + (pixels - 1) * stride * 2 + (long long)c * 2;
+    };
+    for (int i = 0; i < n; ++i) {
+        if (!d[i].in || !d[i].hidden || !d[i].cell || d[i].B <= 0 || d[i].H <= 0 || d[i].W <= 0) return OESS_EINVAL;
+        const long long px = (long long)d[i].B * d[i].H * d[i].W;
+        const char *h0, *h1, *c0 = (const char*)d[i].cell, *c1 = c0 + px * d[i].C_hidden * 4;
+        span(d[i].hidden, px, d[i].hidden_pix_stride, d[i].C_hidden, &h0, &h1);
+        for (int j = 0; j < n; ++j) {       // the problems run concurrently: no output of one may overlap anything of another
+            const long long pj = (long long)d[j].B * d[j].H * d[j].W;
+            const char *i0, *i1, *g0, *g1, *e0 = (const char*)d[j].cell, *e1 = e0 + pj * d[j].C_hidden * 4;
+            span(d[j].in, pj, d[j].in_pix_stride, d[j].Cin, &i0, &i1);
+            span(d[j].hidden, pj, d[j].hidden_pix_stride, d[j].C_hidden, &g0, &g1);
+            if (h0 < i1 && i0 < h1) return OESS_EINVAL;                   // (j == i: the single-problem rule)
+            if (j != i && ((h0 < g1 && g0 < h1) || (c0 < e1 && e0 < c1) || (c0 < i1 && i0 < c1))) return OESS_EINVAL;
+        }
+    }
+    ConvArgs args[3];
+    bool grouped = n >= 2;
+    for (int i = 0; i < n && grouped; ++i) {
+        LstmOut l{d[i].prev_cell, d[i].cell, d[i].hidden, d[i].hidden_pix_stride, d[i].C_hidden};
+        grouped = conv_fwd_impl(d[i].in, d[i].in_pix_stride, d[i].B, d[i].H, d[i].W, d[i].Cin, d[i].w_packed_gates, d[i].bias,
+                                4 * d[i].C_hidden, d[i].R, d[i].S, 1, d[i].pad, 1, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, &l,
+                                stream, nullptr, 0, nullptr, &args[i]) == OESS_OK;
+    }
+    if (!grouped) {
+        for (int i = 0; i < n; ++i) {
+            const int rc = oess_convlstm_fused_bf16(d[i].in, d[i].in_pix_stride, d[i].B, d[i].H, d[i].W, d[i].Cin, d[i].w_packed_gates,
+                                                    d[i].bias, d[i].C_hidden, d[i].R, d[i].S, d[i].pad, d[i].prev_cell, d[i].cell,
+                                                    d[i].hidden, d[i].hidden_pix_stride, stream);
+            if (rc != OESS_OK) return rc;
+        }
+        return OESS_OK;
+    }
+    int order[3] = {0, 1, 2};                  // longest K first: the launch ends on the short tiles
+    for (int i = 1; i < n; ++i)
+        for (int j = i; j > 0 && args[order[j]].Kpad > args[order[j - 1]].Kpad; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    ConvGroup g;
+    memset(&g, 0, sizeof(g));
+    int at = 0;
+    for (int i = 0; i < 3; ++i) {
+        g.start8[i] = at;
+        if (i < n) {
+            g.a[i] = args[order[i]];
+            at += (g.a[i].tiles_m * g.a[i].tiles_n + 7) / 8;
+        }
+    }
+    g.start8[3] = at;
+    const size_t lds = (size_t)2 * HALO_ROWS * 128 + (size_t)2 * 128 * 128;
+    hipLaunchKernelGGL((conv3x3_halo_group_kernel<1>), dim3(8 * at), dim3(CONV_THREADS), lds, (hipStream_t)stream, g);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
 }
 
 static int e2vid_head_enc0_launch(const S2Head& hd, int B, int H, int W, const void* enc_w_packed, const float* enc_bias, int enc_relu,

@@ -19,6 +19,8 @@ class ImageReconstructor:
         self.crop = CropParameters(self.width, self.height, self.model.num_encoders)
         self.last_states_for_each_channel = {'grayscale': None}
         self.event_preprocessor = EventPreprocessor(options)
+        # skewed schedule of the recurrent encoder (UNetRecurrent._forward_skew) for calls with need_latents=False; False = plain order
+        self.skew = not bool(getattr(options, 'no_skew', False))
 
     def update_reconstruction(self, event_tensor, event_tensor_id=None, stamp=None, channel_slice=None, reconstruct=False, wavefront=None,
                               need_latents=True):
@@ -28,7 +30,9 @@ class ImageReconstructor:
         (`_, _, latent = update_reconstruction(...)`), so it is only computed with `reconstruct=True` (offline
         reconstruction, e2vid/run_reconstruction.py), cropped back from the padded size like the reference's CropParameters.
         need_latents=False: the caller drops this call's latents (all but the last sub-window of a step): latent[1] (the head
-        output) is None and is never written to memory (head + encoder-0 conv in one kernel); states are advanced as usual."""
+        output) is None and is never written to memory (head + encoder-0 conv in one kernel).  With `self.skew` (default) such
+        calls also run the recurrent encoder on the skewed schedule: the returned states hold levels 1, 2 one / two sub-windows
+        behind until the next call with need_latents=True (or reconstruct=True) drains them -- same results, fewer launches."""
         with torch.no_grad():
             if channel_slice is None:
                 events = event_tensor.to(self.device).float().contiguous()
@@ -40,6 +44,8 @@ class ImageReconstructor:
             if not need_latents and not reconstruct:
                 kw['need_head'] = False
             unet = getattr(self.model, 'unetrecurrent', None)
+            if self.skew and wavefront is None and not reconstruct and not self.no_recurrent and events.is_cuda and unet is not None:
+                kw['skew'] = True
             if (not need_latents and not reconstruct and not self.crop.needs_pad and unet is not None
                     and unet.events_fusable(events, cs)):
                 # EventPreprocessor apply + NHWC8 re-layout + head + encoder-0 conv in ONE kernel, straight from the event tensor

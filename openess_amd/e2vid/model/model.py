@@ -28,9 +28,9 @@ class E2VIDRecurrent(BaseE2VID):
                                            num_residual_blocks=self.num_residual_blocks, norm=self.norm,
                                            use_upsample_conv=self.use_upsample_conv)
 
-    def forward(self, event_tensor, prev_states, reconstruct=False, wavefront=None, need_head=True, raw=None):
+    def forward(self, event_tensor, prev_states, reconstruct=False, wavefront=None, need_head=True, raw=None, skew=False):
         return self.unetrecurrent.forward(event_tensor, prev_states, reconstruct=reconstruct, wavefront=wavefront,
-                                          need_head=need_head, raw=raw)
+                                          need_head=need_head, raw=raw, skew=skew)
 
 
 # architecture of E2VID_lightweight.pth.tar; used for random-init synthetic runs

@@ -148,6 +148,31 @@ class ConvLSTM(nn.Module):
         self._pw = engine.PackedWeight()
         self._pw_fused = {}
 
+    def fused_args(self, state):
+        """Arguments of hip.convlstm_fused (or one problem of hip.convlstm_fused_group) for this state: xh, packed gates, bias,
+        cell, hidden view, k, pad, prev_cell_is_zero.  The caller flips state['cur'] / clears state['fresh'] after the launch."""
+        g = self.Gates
+        cur = state['cur']
+        xh = state['xh'][cur]
+        k, pad = g.kernel_size[0], g.padding[0]
+        pw = self._pw_fused
+        key = (g.weight._version, g.bias._version)
+        if pw.get('key') != key:
+            with torch.no_grad():
+                pw['packed'] = hip.pack_conv_weight(g.weight, flip=2)
+                pw['bias'] = g.bias.detach().float().contiguous()
+            pw['key'] = key
+        h_view = state['xh'][1 - cur][:, self.input_size:]
+        if state['fresh']:
+            # first sub-window: h_prev = 0 and c_prev = 0 (submodules.py:190-198), so the h half of the Gates
+            # reduction contributes nothing -> convolve the x half only (half the K loop), same cell update
+            if pw.get('packed_x') is None or pw.get('key_x') != key:
+                with torch.no_grad():
+                    pw['packed_x'] = hip.pack_conv_weight(g.weight[:, :self.input_size], flip=2)
+                pw['key_x'] = key
+            return (engine.nhwc(xh[:, :self.input_size]), pw['packed_x'], pw['bias'], state['cell'], engine.nhwc(h_view), k, pad, True)
+        return (engine.nhwc(xh), pw['packed'], pw['bias'], state['cell'], engine.nhwc(h_view), k, pad, False)
+
     def step(self, state):
         """state: dict(xh=[two cat(x, h) buffers, B x (Cin+Ch) x H x W cl bf16], cur=index of the buffer whose x half
         was just written and whose h half holds h_prev, cell=fp32 [B,H,W,Ch], fresh=bool).
@@ -158,26 +183,8 @@ class ConvLSTM(nn.Module):
         xh = state['xh'][cur]
         k, pad = g.kernel_size[0], g.padding[0]
         if self.hidden_size % 32 == 0:
-            pw = self._pw_fused
-            key = (g.weight._version, g.bias._version)
-            if pw.get('key') != key:
-                with torch.no_grad():
-                    pw['packed'] = hip.pack_conv_weight(g.weight, flip=2)
-                    pw['bias'] = g.bias.detach().float().contiguous()
-                pw['key'] = key
+            hip.convlstm_fused(*self.fused_args(state))
             h_view = state['xh'][1 - cur][:, self.input_size:]
-            if state['fresh']:
-                # first sub-window: h_prev = 0 and c_prev = 0 (submodules.py:190-198), so the h half of the Gates
-                # reduction contributes nothing -> convolve the x half only (half the K loop), same cell update
-                if pw.get('packed_x') is None or pw.get('key_x') != key:
-                    with torch.no_grad():
-                        pw['packed_x'] = hip.pack_conv_weight(g.weight[:, :self.input_size], flip=2)
-                    pw['key_x'] = key
-                hip.convlstm_fused(engine.nhwc(xh[:, :self.input_size]), pw['packed_x'], pw['bias'], state['cell'],
-                                   engine.nhwc(h_view), k, pad, prev_cell_is_zero=True)
-            else:
-                hip.convlstm_fused(engine.nhwc(xh), pw['packed'], pw['bias'], state['cell'], engine.nhwc(h_view), k, pad,
-                                   prev_cell_is_zero=state['fresh'])
             state['cur'] = 1 - cur
         else:
             pw = self._pw.get(g.weight, g.bias, None, cin_pad=xh.shape[1])

@@ -7,6 +7,19 @@ import torch.nn as nn
 from .submodules import ConvLayer, RecurrentConvLayer, ResidualBlock, TransposedConvLayer, UpsampleConvLayer
 
 
+class _SkewStates(list):
+    """Per-level ConvLSTM states of the skewed schedule (UNetRecurrent._forward_skew) plus what is in flight between levels:
+    ready[l] = hidden state of level l not yet consumed by level l + 1's encoder conv, out[l] = level l's latest hidden state."""
+
+    def __init__(self, states, n):
+        super().__init__(states if states is not None else [None] * n)
+        self.ready = [None] * n
+        self.out = [None] * n
+
+    def pending(self):
+        return any(r is not None for r in self.ready[:-1])
+
+
 class UNetRecurrent(nn.Module):
     def __init__(self, num_input_channels, num_output_channels=1, skip_type='sum', recurrent_block_type='convlstm',
                  activation='sigmoid', num_encoders=4, base_num_channels=32, num_residual_blocks=2, norm=None,
@@ -75,13 +88,83 @@ class UNetRecurrent(nn.Module):
         probe = torch.empty((1, 8, 1, 1), dtype=torch.bfloat16, device=events.device)
         return self._head_enc0_fusable(probe)
 
-    def forward(self, x, prev_states, reconstruct=False, wavefront=None, need_head=True, raw=None):
+    def _lstm_stage(self, st, levels):
+        """The ConvLSTM steps of `levels` (independent of each other on the skewed schedule) as ONE launch when they all take the
+        fused kernel, else one by one; st.out[l] = the new hidden state, st.ready[l] = the same view as level l + 1's next input."""
+        from ... import hip
+        blocks = [self.encoders[l].recurrent_block for l in levels]
+        if len(levels) > 1 and all(b.hidden_size % 32 == 0 for b in blocks):
+            hs = hip.convlstm_fused_group([b.fused_args(st[l]) for b, l in zip(blocks, levels)])
+            for l, b in zip(levels, blocks):
+                state = st[l]
+                h = state['xh'][1 - state['cur']][:, b.input_size:]
+                state['cur'] = 1 - state['cur']
+                state['fresh'] = False
+                st.out[l] = st.ready[l] = h
+        else:
+            for l, b in zip(levels, blocks):
+                st.out[l] = st.ready[l] = b.step(st[l])
+
+    def _forward_skew(self, x, prev_states, need_head, raw):
+        """Skewed schedule of the recurrent encoder on ONE stream: call s runs the encoder conv + ConvLSTM of level l for
+        sub-window s - l (level l needs level l of the sub-window before and level l - 1 of the same one, so the three levels of
+        a call do not depend on each other), and the ConvLSTM steps of a call are one launch (oess_convlstm_fused_group_bf16).
+        Same kernels on the same buffers in a dependency-respecting order: results are identical to the plain order.  The
+        deeper levels trail by l sub-windows until a call with need_head=True (the caller wants latents) drains them."""
+        n = self.num_encoders
+        st = prev_states if isinstance(prev_states, _SkewStates) else _SkewStates(prev_states, n)
+        fuse = raw is not None or (not need_head and self._head_enc0_fusable(x))
+
+        def deeper():                                       # levels whose input arrived from the level above in the last call
+            levels = []
+            for l in range(n - 1, 0, -1):
+                if st.ready[l - 1] is not None:
+                    st[l] = self.encoders[l].run_conv(st.ready[l - 1], st[l])
+                    st.ready[l - 1] = None
+                    levels.append(l)
+            return levels
+
+        levels = deeper()
+        head = None
+        if fuse:
+            st[0] = self._head_enc0(x, st[0], raw)
+        else:
+            head = self.head(x)
+            st[0] = self.encoders[0].run_conv(head, st[0])
+        self._lstm_stage(st, levels + [0])
+        latent = {1: head}
+        if need_head:
+            self._drain(st)
+            for i in range(n):
+                latent[2 ** (i + 1)] = st.out[i]
+        return None, st, latent
+
+    def _drain(self, st):
+        """Bring the deeper levels of a skewed sequence up to the last sub-window."""
+        n = self.num_encoders
+        while st.pending():
+            levels = []
+            for l in range(n - 1, 0, -1):
+                if st.ready[l - 1] is not None:
+                    st[l] = self.encoders[l].run_conv(st.ready[l - 1], st[l])
+                    st.ready[l - 1] = None
+                    levels.append(l)
+            self._lstm_stage(st, levels)
+
+    def forward(self, x, prev_states, reconstruct=False, wavefront=None, need_head=True, raw=None, skew=False):
         """x: logical [B, 8, H, W] channels_last bf16 (bins zero-padded to 8).  Returns (img | None, states, latent):
         the training path stops at the latents; `reconstruct=True` also runs the residual blocks, decoders and the
         prediction layer (unet.py:160-170) and returns the [B, 1, H, W] fp32 image in [0, 1] (offline reconstruction).
         `wavefront` (e2vid/wavefront.py): run level l on its own HIP stream, ordered by events; same kernels, same results.
         `need_head=False` (the caller discards this call's latents: every sub-window but the last of a pre-training step,
-        pretrain_trainer.py:437-441): latent[1] is None and head + encoder-0 conv run as ONE kernel."""
+        pretrain_trainer.py:437-441): latent[1] is None and head + encoder-0 conv run as ONE kernel.
+        `skew=True`: the skewed single-stream schedule of _forward_skew (calls with need_head=False return no usable latents and
+        leave the deeper levels one / two sub-windows behind; the need_head=True call that ends the sequence drains them)."""
+        if skew and not reconstruct and wavefront is None:
+            return self._forward_skew(x, prev_states, need_head, raw)
+        if isinstance(prev_states, _SkewStates):
+            self._drain(prev_states)                      # a skewed sequence that did not end with need_head=True
+            prev_states = list(prev_states)
         if prev_states is None:
             prev_states = [None] * self.num_encoders
         blocks, states = [], []

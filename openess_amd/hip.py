@@ -4,6 +4,8 @@ PyTorch is plumbing only here: device memory (tensors), the current HIP stream a
 bookkeeping.  Every function enqueues hand-written HIP kernels on the CURRENT torch stream and
 raises if the library is missing or a tensor is not on the GPU -- there is no CPU/eager fallback.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -628,6 +630,43 @@ def convlstm_fused(xh, packed_gates, bias, cell, hidden_out, k, pad, prev_cell_i
                                             C, k, k, pad, None if prev_cell_is_zero else _ptr(cell), _ptr(cell),
                                             _ptr(hidden_out), hs, _stream()), "oess_convlstm_fused_bf16")
     return hidden_out
+
+
+def convlstm_fused_group(problems):
+    """Up to three INDEPENDENT ConvLSTM steps in one launch (oess_convlstm_fused_group_bf16): `problems` = tuples
+    (xh, packed_gates, bias, cell, hidden_out, k, pad, prev_cell_is_zero) as for convlstm_fused.  Same results as calling
+    convlstm_fused on each (the levels of E2VID's recurrent encoder on the skewed schedule, e2vid/model/unet.py mirror)."""
+    lib = _lib.load()
+    n = len(problems)
+    if not 1 <= n <= 3:
+        raise ValueError("convlstm_fused_group: 1..3 problems")
+    descs = (_lib.ConvLstmDesc * n)()
+    flops, keys = 0.0, []
+    for d, (xh, packed_gates, bias, cell, hidden_out, k, pad, prev_zero) in zip(descs, problems):
+        _need_gpu(xh, packed_gates, cell, hidden_out)
+        B, H, W, Cin, ps = _nhwc_geom(xh)
+        _, _, _, C, hs = _nhwc_geom(hidden_out)
+        if cell.dtype != torch.float32 or not cell.is_contiguous() or cell.numel() != B * H * W * C:
+            raise ValueError("convlstm_fused_group: cell must be contiguous fp32 [B,H,W,C]")
+        if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() != 4 * C):
+            raise ValueError("convlstm_fused_group: bias must be contiguous fp32 [4C]")
+        d.in_, d.in_pix_stride, d.B, d.H, d.W, d.Cin = _ptr(xh), ps, B, H, W, Cin
+        d.w_packed_gates, d.bias, d.C_hidden, d.R, d.S, d.pad = _ptr(packed_gates), _ptr(bias), C, k, k, pad
+        d.prev_cell, d.cell, d.hidden, d.hidden_pix_stride = (None if prev_zero else _ptr(cell)), _ptr(cell), _ptr(hidden_out), hs
+        fl = 2.0 * B * H * W * 4 * C * Cin * k * k
+        flops += fl
+        keys.append(((H, W, Cin, 4 * C, k, 1, "lstm"), fl))
+    t = _CONV_TIMING
+    if t is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(lib.oess_convlstm_fused_group_bf16(ctypes.addressof(descs), n, _stream()), "oess_convlstm_fused_group_bf16")
+    if t is not None:
+        e1.record()
+        t["events"].append((e0, e1))
+        t["flops"] += flops
+        t.setdefault("keys", []).append((("group",) + tuple(k_[0] for k_ in keys), flops))
+    return [p[4] for p in problems]
 
 
 _SLICE_STATS = {}

@@ -329,6 +329,52 @@ def test_convlstm_fused_step_matches_torch(B, H, W, Cx, C):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("geoms", [
+    # (B, H, W, Cx = C): the three E2VID levels (scaled down), tile counts 30 x 2 / 8 x 4 / 2 x 8 (not all multiples of 8)
+    [(1, 48, 80, 64), (1, 24, 40, 128), (1, 12, 20, 256)],
+    [(2, 24, 40, 128), (2, 12, 20, 256)],                        # two problems (the drain stage of the skewed schedule)
+    [(1, 13, 11, 64), (1, 7, 9, 64), (3, 5, 6, 128)],            # ragged last tiles, 3 + 1 + 2 tiles
+    [(1, 9, 11, 64), (1, 13, 10, 32)],                           # the zero-state problem has Cin = 32: not the row-halo kernel's -> launched one by one
+])
+def test_convlstm_fused_group_equals_separate_launches(geoms):
+    """oess_convlstm_fused_group_bf16: n independent ConvLSTM steps in one launch give bit-identical hidden and cell states to n
+    oess_convlstm_fused_bf16 launches (same tiles, same arithmetic), with zero and non-zero previous cells mixed; outputs of one
+    problem overlapping another's buffers are rejected."""
+    import torch
+    from openess_amd import hip
+    torch.manual_seed(len(geoms) * 7 + geoms[0][1])
+    dev = "cuda"
+    probs_a, probs_b, keep = [], [], []
+    for i, (B, H, W, C) in enumerate(geoms):
+        fresh = (i == 1)
+        w = torch.randn(4 * C, 2 * C, 3, 3, device=dev) * (0.3 / C ** 0.5)
+        bias = torch.randn(4 * C, device=dev) * 0.1
+        packed = hip.pack_conv_weight(w[:, :C] if fresh else w, flip=2)
+        xh = (torch.randn(B, H, W, 2 * C, device=dev) * 0.5).bfloat16()
+        cell0 = torch.randn(B, H, W, C, device=dev)
+        for probs in (probs_a, probs_b):
+            cell = cell0.clone()
+            h = torch.full((B, H, W, 2 * C), 7.0, device=dev, dtype=torch.bfloat16)
+            probs.append((xh[..., :C] if fresh else xh, packed, bias, cell, h[..., C:], 3, 1, fresh))
+            keep.append(h)
+    for pr in probs_a:
+        hip.convlstm_fused(*pr)
+    out = hip.convlstm_fused_group(probs_b)
+    assert len(out) == len(geoms)
+    for pa, pb in zip(probs_a, probs_b):
+        assert torch.equal(pa[3], pb[3])
+        assert torch.equal(pa[4], pb[4])
+        assert float(pb[4].float().abs().max()) < 1.01           # every hidden value written (|h| <= 1)
+    # overlapping outputs: a second problem that updates problem 0's cell (its hidden output is another buffer)
+    B, H, W, C = geoms[0]
+    clash = [probs_b[0], probs_b[0][:3] + (probs_b[0][3], keep[0][..., C:]) + probs_b[0][5:]]
+    with pytest.raises(RuntimeError):
+        hip.convlstm_fused_group(clash)
+    with pytest.raises(ValueError):
+        hip.convlstm_fused_group([])
+
+
+@pytest.mark.gpu
 def test_convlstm_fused_rejects_aliasing_and_bad_shapes():
     import torch
     from openess_amd import hip

@@ -79,8 +79,32 @@ def test_e2vid_recurrent_latents(g, keys):
         assert relerr(latent3[k].float().cpu().numpy(), latent[k].float().cpu().numpy()) < 5e-3, k
         assert relerr(latent3[k].float().cpu().numpy(), lat_ref[k].numpy()) < 3e-2, k
     rec4 = ImageReconstructor(m, 32, 48, 5, torch.device("cuda"))
+    rec4.skew = False
     _, _, lat_none = rec4.update_reconstruction(ev, channel_slice=(0, 5), need_latents=False)
     assert lat_none[1] is None and lat_none[2].shape == latent[2].shape
+    # skewed schedule (default for need_latents=False calls: level l works on sub-window s - l, the ConvLSTM steps of a call are one
+    # launch) == plain order, bit for bit, over a sequence longer than the skew; the states after the draining call are complete
+    ev5 = torch.cat([ev, ev.flip(1)[:, :10] * 0.5], 1).contiguous()           # 5 sub-windows
+    lat = {}
+    for skew in (False, True):
+        r = ImageReconstructor(m, 32, 48, 5, torch.device("cuda"))
+        r.skew = skew
+        for i in range(5):
+            _, states, l5 = r.update_reconstruction(ev5, channel_slice=(5 * i, 5), need_latents=(i == 4))
+        lat[skew] = ({k: v.clone() for k, v in l5.items()}, [s_['cell'].clone() for s_ in states], [s_['cur'] for s_ in states])
+        if skew:
+            assert not states.pending()
+            # a sequence that stops without the draining call is drained by the next plain call (here: reconstruct=True)
+            for i in range(3):
+                r.update_reconstruction(ev5, channel_slice=(5 * i, 5), need_latents=False)
+            assert r.last_states_for_each_channel['grayscale'].pending()
+            img, _, _ = r.update_reconstruction(ev5, channel_slice=(15, 5), reconstruct=True)
+            assert img.shape[-2:] == (32, 48) and bool(torch.isfinite(img).all())
+    for k in (1, 2, 4, 8):
+        assert torch.equal(lat[True][0][k], lat[False][0][k]), k
+    for a_, b_ in zip(lat[True][1], lat[False][1]):
+        assert torch.equal(a_, b_)
+    assert lat[True][2] == lat[False][2]
 
 
 @pytest.fixture(scope="module")
