@@ -19,9 +19,9 @@ subprocess.run([sys.executable, "tools/mfma_util.py", os.path.join(src, "pmc_mfm
                check=True, stdout=subprocess.DEVNULL)
 # plain-text outputs quoted in DESIGN / EXPERIMENTS (present from round 3 on)
 with open(os.path.join(dst, f"{R}_misc_outputs.txt"), "w") as f:
-    for name in ("pytest_gpu.txt", "smoke.txt", "bench_torchrun_world1.txt", "train_loop.txt", "png.txt", "deeplab_breakdown.txt",
+    for name in ("pytest_gpu.txt", "smoke.txt", "bench_no_skew.txt", "bench_torchrun_world1.txt", "train_loop.txt", "png.txt", "deeplab_breakdown.txt",
                  "segmean.txt", "voxelizer_pmc.txt", "stage_deeplab_fwd.txt", "stage_maskclip_fwd.txt", "stage_teacher_fwd.txt",
-                 "vox_raw1.txt", "vox_raw0.txt", "enc_s2.txt", "gap_probe.txt", "insitu_probe.txt", "step_sequence.txt"):
+                 "vox_raw1.txt", "vox_raw0.txt", "enc_s2.txt", "probe_1x1.txt", "gap_probe.txt", "insitu_probe.txt", "step_sequence.txt"):
         p = os.path.join(src, name)
         if os.path.exists(p):
             body = [l for l in open(p, errors="replace").read().split("\n") if l.strip() and "amdgpu.ids" not in l and not l.startswith("+")]

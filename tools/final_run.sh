@@ -9,6 +9,8 @@ rm -rf $O; mkdir -p $O
 timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 timeout 1200 python bench.py > $O/bench.txt 2>&1
+# same box, same code, recurrent encoder in the plain order (one ConvLSTM launch per level and sub-window): the A/B of the skewed schedule
+timeout 600 python bench.py --steps 30 --warmup 5 --no-skew --no-cpu-baseline --no-pmc --no-extras > $O/bench_no_skew.txt 2>&1
 # RCCL call path with ONE rank (the box has one GPU): torch.distributed.run -> nccl process group -> bucketed all-reduce per step
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --no-pmc --no-extras > $O/bench_torchrun_world1.txt 2>&1
 for wl in frame2voxel_pixel_distill frame2voxel_full frame2recon_full; do
@@ -28,6 +30,7 @@ timeout 300 python tools/bench_png.py > $O/png.txt 2>&1
 timeout 300 python tools/bench_stage.py deeplab_fwd --breakdown > $O/deeplab_breakdown.txt 2>&1
 timeout 300 python tools/bench_segmean.py > $O/segmean.txt 2>&1 || true
 timeout 300 python tools/bench_enc_s2.py > $O/enc_s2.txt 2>&1 || true
+timeout 300 python tools/probe_1x1_epi.py > $O/probe_1x1.txt 2>&1 || true
 timeout 300 python tools/quant_probe.py > $O/quant_probe.txt 2>&1 || true
 timeout 300 python tools/gap_probe.py > $O/gap_probe.txt 2>&1 || true
 timeout 300 python tools/insitu_probe.py > $O/insitu_probe.txt 2>&1 || true
