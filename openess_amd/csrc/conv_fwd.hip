@@ -67,6 +67,9 @@ struct ConvArgs {
     // adds the slices in a fixed order and does what the epilogue would have done (bias / residual / activation / tile stats)
     float* partial;
     int ksplit, kt_per;
+    // row-halo kernel: exact reciprocals of W and W + dil for the small per-lane quotients of its prologue (x < 256:
+    // x / d == umulhi(x, floor(2^32 / d) + 1) whenever x * d < 2^32); 0 = divide
+    unsigned mg_w, mg_wd;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
@@ -857,19 +860,20 @@ __device__ __forceinline__ void conv3x3_halo_tile(const ConvArgs& a, const int b
     for (int i = 0; i < H_INSTR; ++i) {
         const int h = (wave * H_INSTR + i) * 8 + lrow;
         const int hp = h - dil;
-        int m_seg, px;                                   // first tile pixel of the row's segment, x coordinate of this halo row
-        if (hp < L0 + dil) { m_seg = m0; px = ox0 + hp; }
+        int m_seg, px, drow;                             // first tile pixel of the row's segment, x coordinate of this halo row, image rows below the tile's first
+        if (hp < L0 + dil) { m_seg = m0; px = ox0 + hp; drow = 0; }
         else {
             const int h2 = hp - (L0 + dil);
-            const int q = h2 / wd, r = h2 - q * wd;
-            m_seg = m0 + L0 + q * W; px = r;
+            const int q = a.mg_wd ? (int)__umulhi((unsigned)h2, a.mg_wd) : h2 / wd, r = h2 - q * wd;
+            m_seg = m0 + L0 + q * W; px = r; drow = q + 1;
         }
         const bool valid = m_seg < a.M && (m_seg == m0 || m_seg - m0 < BMX) && (unsigned)px < (unsigned)W;
-        const int ms = valid ? m_seg : 0;
-        const int b = ms / hw, rr = ms - b * hw;
-        const int oy = rr / W;
+        // segment q starts an image row: its row is the tile's first row + drow, carried into the next image(s) -- no division
+        int oy = oy0 + drow;
+        const long long grow = (long long)b0 * a.H + oy;  // row index over the whole batch
+        while (oy >= a.H) oy -= a.H;
         hy[i] = valid ? oy : -0x4000;
-        hoff[i] = (int)((((long long)b * a.H + oy) * W + px) * a.in_pix_stride * 2) + (slot ^ ((h >> 1) & 7)) * 16;
+        hoff[i] = valid ? (int)((grow * W + px) * a.in_pix_stride * 2) + (slot ^ ((h >> 1) & 7)) * 16 : 0;
     }
     int boff[B_INSTR];
 #pragma unroll
@@ -924,7 +928,7 @@ __device__ __forceinline__ void conv3x3_halo_tile(const ConvArgs& a, const int b
         int hr;
         if (r < L0) hr = r;                              // (+ dil lead rows, - dil for the dx = 0 tap)
         else {
-            const int t = r - L0, q = t / W, rr = t - q * W;
+            const int t = r - L0, q = a.mg_w ? (int)__umulhi((unsigned)t, a.mg_w) : t / W, rr = t - q * W;
             hr = L0 + dil + q * wd + rr;
         }
 #pragma unroll
@@ -1017,9 +1021,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a) {
 }
 
 // Up to three INDEPENDENT problems of the kernel above in one launch (the three ConvLSTM levels of E2VID's recurrent encoder
-// on the skewed schedule: level l works on sub-window s - l, e2vid/model/unet.py mirror).  Alone, the levels are 18.75 /
-// 9.4 / 4.7 rounds of tiles over the 512 workgroup slots and each pays its own partial last round and launch gap; together
-// they are 32.8 rounds.  The host orders the problems by K, longest tiles first, so that the launch ends on the short ones.
+// on the skewed schedule: level l works on sub-window s - l, e2vid/model/unet.py mirror).  Alone, the levels are 17.2 /
+// 8.6 / 4.3 rounds of tiles over the 512 workgroup slots and each pays its own partial last round and launch gap; together
+// they are 30.1 rounds.  The host orders the problems by K, longest tiles first, so that the launch ends on the short ones.
 // Workgroup blockIdx = 8 * idx + xcd: problem p owns idx in [start8[p], start8[p + 1]) on every XCD, and inside it the tiles
 // are dealt to the XCDs in contiguous chunks exactly as the single-problem kernel does (neighbouring tiles share halo rows
 // and weight slabs in that XCD's L2).
@@ -1883,6 +1887,8 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
     a.lstm_h = lstm ? (uint16_t*)lstm->h : nullptr; a.lstm_h_stride = lstm ? lstm->h_stride : 0; a.lstm_C = lstm ? lstm->C : 0;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.partial = nullptr; a.ksplit = 1; a.kt_per = 0;
+    a.mg_w = (W >= 2 && 256ll * W < 0x100000000ll) ? (unsigned)(0x100000000ull / (unsigned)W) + 1u : 0u;
+    a.mg_wd = (256ll * (W + dil) < 0x100000000ll) ? (unsigned)(0x100000000ull / (unsigned)(W + dil)) + 1u : 0u;
     hipStream_t st = (hipStream_t)stream;
     conv_set_attrs();
     // The LDS-DMA kernels address the input with 32-bit buffer offsets and decode filter taps with exact small-range
