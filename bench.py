@@ -423,11 +423,16 @@ def main():
                     "(one HIP stream per ConvLSTM level; same results; per-launch durations of the roofline object overlap)")
     ap.add_argument("--no-skew", action="store_true", help="recurrent encoder in the plain order (one ConvLSTM launch per level and "
                     "sub-window) instead of the default skewed schedule with grouped launches; same results (A/B)")
+    ap.add_argument("--no-s2-group", action="store_true", help="skewed schedule with one launch per stride-2 encoder conv (A/B of the "
+                    "grouped launch of levels 1 and 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC child passes (roofline.traffic = null)")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only: no stages / configs / ingest blocks")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)        # profiled child of pmc_traffic(): steps only
     a = ap.parse_args()
+    if a.no_s2_group:
+        from openess_amd.e2vid.model.unet import UNetRecurrent
+        UNetRecurrent.group_s2 = False
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

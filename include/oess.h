@@ -288,6 +288,17 @@ typedef struct {
 } oess_convlstm_desc_t;
 int oess_convlstm_fused_group_bf16(const oess_convlstm_desc_t* problems, int n, oess_stream_t stream);
 
+/* n <= 2 INDEPENDENT 5x5 / stride-2 / pad-2 convolutions (out = act(conv(in, w) + bias), arguments as oess_conv2d_fwd_bf16 with
+ * R = S = 5, stride 2, pad 2, relu in {0, 1}) in ONE launch: the encoder ConvLayers of levels 1 and 2 of E2VID's recurrent encoder
+ * (e2vid/model/unet.py:141-150, submodules.py:96-115) on the skewed schedule.  Results are those of separate calls.  Neither output
+ * may overlap the other problem's input or output (checked); geometries the 2-D-halo kernel does not take run as n launches. */
+typedef struct {
+    const void* in; long long in_pix_stride; int B, H, W, Cin;
+    const void* w_packed; const float* bias; int Cout, relu;
+    void* out; long long out_pix_stride;
+} oess_conv_s2_desc_t;
+int oess_conv5x5s2_group_bf16(const oess_conv_s2_desc_t* problems, int n, oess_stream_t stream);
+
 /* Statistics of a channel slice without the apply pass (first half of K2): stats = {sum, sumsq, nnz, -}. */
 /* ... and of n_slices consecutive Cs-channel slices in ONE launch (the 20 sub-windows of a pre-training sample are known up
  * front, pretrain_trainer.py:437-441): stats[4 z ..] = {sum, sumsq, nnz, -} of in[:, z*Cs : (z+1)*Cs]. */

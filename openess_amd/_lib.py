@@ -25,6 +25,12 @@ class ConvLstmDesc(ctypes.Structure):
                 ("prev_cell", c_vp), ("cell", c_vp), ("hidden", c_vp), ("hidden_pix_stride", c_ll)]
 
 
+class ConvS2Desc(ctypes.Structure):
+    """oess_conv_s2_desc_t (include/oess.h): one problem of oess_conv5x5s2_group_bf16."""
+    _fields_ = [("in_", c_vp), ("in_pix_stride", c_ll), ("B", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int),
+                ("w_packed", c_vp), ("bias", c_vp), ("Cout", c_int), ("relu", c_int), ("out", c_vp), ("out_pix_stride", c_ll)]
+
+
 # name -> (restype, argtypes).  Must list EVERY symbol of include/oess.h (tests/test_abi.py checks).
 SIGNATURES = {
     "oess_abi_version": (c_int, []),
@@ -53,6 +59,7 @@ SIGNATURES = {
     "oess_convlstm_fused_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp,
                                          c_vp, c_vp, c_ll, c_vp]),
     "oess_convlstm_fused_group_bf16": (c_int, [c_vp, c_int, c_vp]),
+    "oess_conv5x5s2_group_bf16": (c_int, [c_vp, c_int, c_vp]),
     "oess_loss_partials_bytes": (c_sz, []),
     "oess_l1_mean_fwd": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
     "oess_l1_mean_bwd": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]),

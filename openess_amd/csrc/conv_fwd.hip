@@ -1099,16 +1099,10 @@ constexpr int S2_IMG_PITCH = 72;                                     // bf16 out
 template <typename F, int... Is>
 __device__ __forceinline__ void s2_for_taps(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 
+// one 8 x 16-pixel x 64-channel tile (`bid` = tile index after the XCD remap)
 template <bool FUSED>
-__global__ __launch_bounds__(256, 2) void conv5x5s2_halo_kernel(ConvArgs a, S2Head hd) {
+__device__ __forceinline__ void conv5x5s2_halo_tile(const ConvArgs& a, const S2Head& hd, const int bid, unsigned char* smem) {
     constexpr int S2_RING = FUSED ? S2_RING_FUSED : S2_RING_PLAIN;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int nwg = a.tiles_m * a.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
     const int tile_n = bid % a.tiles_n;
     int patch = bid / a.tiles_n;
     const int tiles_x = (a.Wo + S2_PW - 1) / S2_PW, tiles_y = (a.Ho + S2_PH - 1) / S2_PH;
@@ -1433,6 +1427,37 @@ __global__ __launch_bounds__(256, 2) void conv5x5s2_halo_kernel(ConvArgs a, S2He
             out_store16(a.out + (((long long)b * a.Ho + oy) * a.Wo + ox) * a.out_pix_stride + n0 + c * 8,
                         *reinterpret_cast<const uint4*>(img + pl * S2_IMG_PITCH + c * 8));
     }
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(256, 2) void conv5x5s2_halo_kernel(ConvArgs a, S2Head hd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nwg = a.tiles_m * a.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    conv5x5s2_halo_tile<FUSED>(a, hd, bid, smem);
+}
+
+// Two independent problems of the plain kernel in one launch (encoder convs of levels 1 and 2 on the skewed schedule of the
+// recurrent encoder: 2 240 + 1 120 workgroups = 4.4 + 2.2 rounds over the 512 slots alone, 6.6 together); mapping as in
+// conv3x3_halo_group_kernel, longest K first.
+struct S2Group {
+    ConvArgs a[2];
+    int start8[3];
+};
+__global__ __launch_bounds__(256, 2) void conv5x5s2_halo_group_kernel(S2Group g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int p = idx >= g.start8[1] ? 1 : 0;
+    const int li = idx - g.start8[p];
+    const ConvArgs& a = g.a[p];
+    const int nwg = a.tiles_m * a.tiles_n;
+    const int q = nwg >> 3, r = nwg & 7;
+    if (li >= q + (xcd < r ? 1 : 0)) return;
+    conv5x5s2_halo_tile<false>(a, S2Head{}, (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + li, smem);
 }
 
 // =================================================================================================
@@ -1837,7 +1862,7 @@ void conv_set_attrs() {
                              (const void*)&conv3x3_halo_kernel<0>, (const void*)&conv3x3_halo_kernel<1>, (const void*)&conv3x3_halo_group_kernel<1>,
                              (const void*)&conv_fwd_dma_kernel<256, 256, 2, true>,
                              (const void*)&conv_fwd_dma32_kernel<128, true, 0, 3>, (const void*)&conv5x5s2_halo_kernel<false>,
-                             (const void*)&conv5x5s2_halo_kernel<true>};
+                             (const void*)&conv5x5s2_halo_kernel<true>, (const void*)&conv5x5s2_halo_group_kernel};
         for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attrs_set = true;
     }
@@ -1852,7 +1877,6 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
     // capture != null (ConvLSTM only): fill *capture with the launch arguments of the row-halo kernel instead of launching it;
     // OESS_EINVAL when the geometry takes another kernel (the caller then launches the problems one by one)
     if (want_workspace) *want_workspace = 0;
-    if (capture && !lstm) return OESS_EINVAL;
     if (lstm) {
         if (!lstm->cell || !lstm->h || lstm->C <= 0 || (lstm->C & 31) || Cout != 4 * lstm->C || (lstm->h_stride & 1) ||
             lstm->h_stride < lstm->C || residual || relu || tile_stats || out_f32 || stride != 1)
@@ -1920,7 +1944,7 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
     const bool want64 = bn == 128 && !tile_stats && !lstm && e64 > e128 * 1.04;
 
     // (1) Cin == 8 stencil layers (E2VID head): LDS halo tile instead of the im2col gather
-    if (!lstm && Cin == 8 && stride == 1 && dil == 1 && R == 5 && S == 5 && Cout <= 32 && (Cout & 3) == 0 && !residual && !out_f32 &&
+    if (!capture && !lstm && Cin == 8 && stride == 1 && dil == 1 && R == 5 && S == 5 && Cout <= 32 && (Cout & 3) == 0 && !residual && !out_f32 &&
         !tile_stats && (out_pix_stride & 3) == 0 && a.Kpad == 256 && dma_ok) {
         if (want_workspace) return OESS_OK;
         const int tiles = B * ((a.Ho + 7) / 8) * ((a.Wo + 63) / 64);
@@ -1930,7 +1954,7 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
     }
     if (!dma_ok) {
         if (want_workspace) return OESS_OK;
-        if (lstm) return OESS_EINVAL;       // the fused ConvLSTM epilogue exists only in the LDS-DMA kernels
+        if (lstm || capture) return OESS_EINVAL;       // the fused ConvLSTM epilogue exists only in the LDS-DMA kernels
         const size_t tab = (size_t)(a.Kpad / 8) * 8;
         size_t lds = (size_t)2 * (BM + bn) * 8 * 16 + tab;
         if (lds < epi) lds = epi;
@@ -1946,10 +1970,12 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
         if (want_workspace) return OESS_OK;
         a.tiles_n = Cout / 64;
         a.tiles_m = B * ((a.Ho + S2_PH - 1) / S2_PH) * ((a.Wo + S2_PW - 1) / S2_PW);
+        if (capture) { *capture = a; return OESS_OK; }
         hipLaunchKernelGGL((conv5x5s2_halo_kernel<false>), dim3(a.tiles_m * a.tiles_n), dim3(256), S2_LDS, st, a, S2Head{});
         OESS_HIP(hipGetLastError());
         return OESS_OK;
     }
+    if (capture && !lstm) return OESS_EINVAL;          // (non-ConvLSTM captures are for the stride-2 group launch only)
     // (2) 3x3 stride-1 'same' convolutions with Cin % 64 == 0: row-halo reuse of the pixel operand, unless the 64-row tiling
     //     is what the layer wants (tile quantisation of small maps)
     if (R == 3 && S == 3 && stride == 1 && pad == dil && fastk && bn == 128 && a.Kpad == 9 * Cin && a.Ho == H && a.Wo == W &&
@@ -2149,6 +2175,61 @@ int oess_convlstm_fused_group_bf16(const oess_convlstm_desc_t* d, int n, oess_st
     g.start8[3] = at;
     const size_t lds = (size_t)2 * HALO_ROWS * 128 + (size_t)2 * 128 * 128;
     hipLaunchKernelGGL((conv3x3_halo_group_kernel<1>), dim3(8 * at), dim3(CONV_THREADS), lds, (hipStream_t)stream, g);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_conv5x5s2_group_bf16(const oess_conv_s2_desc_t* d, int n, oess_stream_t stream) {
+    if (!d || n <= 0 || n > 2) return OESS_EINVAL;
+    for (int i = 0; i < n; ++i)
+        if (!d[i].in || !d[i].w_packed || !d[i].out || d[i].B <= 0 || d[i].H <= 0 || d[i].W <= 0) return OESS_EINVAL;
+    if (n == 2) {       // the problems run concurrently: neither output may overlap the other's input or output
+        const char *lo[2][2], *hi[2][2];
+        long long st[2][2], cb[2][2];                      // pixel stride and channel bytes of {in, out}
+        for (int i = 0; i < 2; ++i) {
+            const long long pin = (long long)d[i].B * d[i].H * d[i].W;
+            const long long pout = (long long)d[i].B * ((d[i].H - 1) / 2 + 1) * ((d[i].W - 1) / 2 + 1);
+            st[i][0] = d[i].in_pix_stride * 2; cb[i][0] = (long long)d[i].Cin * 2;
+            st[i][1] = d[i].out_pix_stride * 2; cb[i][1] = (long long)d[i].Cout * 2;
+            lo[i][0] = (const char*)d[i].in; hi[i][0] = lo[i][0] + (pin - 1) * st[i][0] + cb[i][0];
+            lo[i][1] = (const char*)d[i].out; hi[i][1] = lo[i][1] + (pout - 1) * st[i][1] + cb[i][1];
+        }
+        for (int i = 0; i < 2; ++i)
+            for (int k = 0; k < 2; ++k) {
+                if (!(lo[i][1] < hi[1 - i][k] && lo[1 - i][k] < hi[i][1])) continue;
+                // overlapping spans are fine when the two views are disjoint CHANNEL SLICES of one pixel grid (the x half and
+                // the h half of a ConvLSTM cat(x, h) buffer): same pixel stride S, offsets differing by delta (mod S) with
+                // delta >= bytes of the first and delta + bytes of the second <= S
+                const long long S = st[i][1];
+                if (S != st[1 - i][k] || S <= 0) return OESS_EINVAL;
+                const long long diff = (long long)(lo[1 - i][k] - lo[i][1]);
+                const long long delta = ((diff % S) + S) % S;
+                if (!(delta >= cb[i][1] && delta + cb[1 - i][k] <= S)) return OESS_EINVAL;
+            }
+    }
+    ConvArgs args[2];
+    bool grouped = n == 2;
+    for (int i = 0; i < n && grouped; ++i)
+        grouped = conv_fwd_impl(d[i].in, d[i].in_pix_stride, d[i].B, d[i].H, d[i].W, d[i].Cin, d[i].w_packed, d[i].bias, d[i].Cout, 5, 5, 2,
+                                2, 1, d[i].relu, nullptr, 0, d[i].out, nullptr, d[i].out_pix_stride, nullptr, nullptr, stream, nullptr, 0,
+                                nullptr, &args[i]) == OESS_OK;
+    if (!grouped) {
+        for (int i = 0; i < n; ++i) {
+            const int rc = conv_fwd_impl(d[i].in, d[i].in_pix_stride, d[i].B, d[i].H, d[i].W, d[i].Cin, d[i].w_packed, d[i].bias,
+                                         d[i].Cout, 5, 5, 2, 2, 1, d[i].relu, nullptr, 0, d[i].out, nullptr, d[i].out_pix_stride, nullptr,
+                                         nullptr, stream);
+            if (rc != OESS_OK) return rc;
+        }
+        return OESS_OK;
+    }
+    S2Group g;
+    memset(&g, 0, sizeof(g));
+    const int first = args[1].Cin > args[0].Cin ? 1 : 0;           // longest K first
+    g.a[0] = args[first]; g.a[1] = args[1 - first];
+    g.start8[0] = 0;
+    g.start8[1] = (g.a[0].tiles_m * g.a[0].tiles_n + 7) / 8;
+    g.start8[2] = g.start8[1] + (g.a[1].tiles_m * g.a[1].tiles_n + 7) / 8;
+    hipLaunchKernelGGL(conv5x5s2_halo_group_kernel, dim3(8 * g.start8[2]), dim3(256), S2_LDS, (hipStream_t)stream, g);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }

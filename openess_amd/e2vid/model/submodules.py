@@ -220,6 +220,18 @@ class RecurrentConvLayer(nn.Module):
         return {'xh': [make(B, 2 * Co, Ho, Wo, x.device), make(B, 2 * Co, Ho, Wo, x.device)], 'cur': 0,
                 'cell': torch.empty((B, Ho, Wo, Co), dtype=torch.float32, device=x.device), 'fresh': True}
 
+    def conv_s2_args(self, x, state):
+        """One problem of hip.conv5x5s2_group for this layer's encoder conv (x -> x half of the current cat(x, h) buffer), or None
+        when the layer is not a 5x5 / stride-2 / pad-2 conv with a foldable norm and relu / no activation."""
+        m, c = self.conv, self.conv.conv2d
+        if not (c.kernel_size == (5, 5) and c.stride == (2, 2) and c.padding == (2, 2) and m.activation_name in (None, 'relu')
+                and m.norm != 'IN' and not (m.norm == 'BN' and m.norm_layer.training) and x.shape[1] % 32 == 0
+                and c.out_channels % 64 == 0 and x.dtype == torch.bfloat16 and x.stride(1) == 1):
+            return None
+        pw = m._pw.get(c.weight, c.bias, m.norm_layer if m.norm == 'BN' else None, cin_pad=x.shape[1])
+        out = state['xh'][state['cur']][:, :c.out_channels]
+        return (engine.nhwc(x), pw.packed, pw.bias, c.out_channels, m.activation_name == 'relu', engine.nhwc(out))
+
     def run_conv(self, x, prev_state):
         state = prev_state if prev_state is not None else self.new_state(x)
         Co = self.conv.conv2d.out_channels

@@ -21,6 +21,8 @@ class _SkewStates(list):
 
 
 class UNetRecurrent(nn.Module):
+    group_s2 = True          # skewed schedule: the two deeper encoder convs of a call as one launch (False: one launch each; A/B switch)
+
     def __init__(self, num_input_channels, num_output_channels=1, skip_type='sum', recurrent_block_type='convlstm',
                  activation='sigmoid', num_encoders=4, base_num_channels=32, num_residual_blocks=2, norm=None,
                  use_upsample_conv=True):
@@ -115,16 +117,7 @@ class UNetRecurrent(nn.Module):
         st = prev_states if isinstance(prev_states, _SkewStates) else _SkewStates(prev_states, n)
         fuse = raw is not None or (not need_head and self._head_enc0_fusable(x))
 
-        def deeper():                                       # levels whose input arrived from the level above in the last call
-            levels = []
-            for l in range(n - 1, 0, -1):
-                if st.ready[l - 1] is not None:
-                    st[l] = self.encoders[l].run_conv(st.ready[l - 1], st[l])
-                    st.ready[l - 1] = None
-                    levels.append(l)
-            return levels
-
-        levels = deeper()
+        levels = self._deeper_convs(st)
         head = None
         if fuse:
             st[0] = self._head_enc0(x, st[0], raw)
@@ -139,17 +132,29 @@ class UNetRecurrent(nn.Module):
                 latent[2 ** (i + 1)] = st.out[i]
         return None, st, latent
 
+    def _deeper_convs(self, st):
+        """Encoder convs of the levels whose input arrived from the level above in the last call (independent of each other: level
+        l reads h_{l-1}, writes the x half of its own cat buffer); two stride-2 convs go out as ONE launch.  Returns the levels."""
+        from ... import hip
+        n = self.num_encoders
+        levels = [l for l in range(n - 1, 0, -1) if st.ready[l - 1] is not None]
+        for l in levels:
+            if st[l] is None:
+                st[l] = self.encoders[l].new_state(st.ready[l - 1])
+        probs = [self.encoders[l].conv_s2_args(st.ready[l - 1], st[l]) for l in levels] if (len(levels) == 2 and self.group_s2) else []
+        if len(probs) == 2 and all(p is not None for p in probs):
+            hip.conv5x5s2_group(probs)
+        else:
+            for l in levels:
+                st[l] = self.encoders[l].run_conv(st.ready[l - 1], st[l])
+        for l in levels:
+            st.ready[l - 1] = None
+        return levels
+
     def _drain(self, st):
         """Bring the deeper levels of a skewed sequence up to the last sub-window."""
-        n = self.num_encoders
         while st.pending():
-            levels = []
-            for l in range(n - 1, 0, -1):
-                if st.ready[l - 1] is not None:
-                    st[l] = self.encoders[l].run_conv(st.ready[l - 1], st[l])
-                    st.ready[l - 1] = None
-                    levels.append(l)
-            self._lstm_stage(st, levels)
+            self._lstm_stage(st, self._deeper_convs(st))
 
     def forward(self, x, prev_states, reconstruct=False, wavefront=None, need_head=True, raw=None, skew=False):
         """x: logical [B, 8, H, W] channels_last bf16 (bins zero-padded to 8).  Returns (img | None, states, latent):

@@ -669,6 +669,42 @@ def convlstm_fused_group(problems):
     return [p[4] for p in problems]
 
 
+def conv5x5s2_group(problems):
+    """Up to two INDEPENDENT 5x5 / stride-2 / pad-2 convolutions in one launch (oess_conv5x5s2_group_bf16): `problems` = tuples
+    (x NHWC bf16, packed weight, bias | None, Cout, relu, out NHWC bf16 view).  Same results as conv2d_nhwc on each."""
+    lib = _lib.load()
+    n = len(problems)
+    if not 1 <= n <= 2:
+        raise ValueError("conv5x5s2_group: 1..2 problems")
+    descs = (_lib.ConvS2Desc * n)()
+    flops, keys = 0.0, []
+    for d, (x, packed, bias, Cout, relu, out) in zip(descs, problems):
+        _need_gpu(x, packed, out)
+        B, H, W, Cin, ps = _nhwc_geom(x)
+        Bo, Ho, Wo, Co, ops = _nhwc_geom(out)
+        if (Bo, Ho, Wo, Co) != (B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cout):
+            raise ValueError("conv5x5s2_group: output view must be [B, (H-1)//2+1, (W-1)//2+1, Cout]")
+        if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() < Cout):
+            raise ValueError("conv5x5s2_group: bias must be contiguous fp32 [Cout]")
+        d.in_, d.in_pix_stride, d.B, d.H, d.W, d.Cin = _ptr(x), ps, B, H, W, Cin
+        d.w_packed, d.bias, d.Cout, d.relu, d.out, d.out_pix_stride = _ptr(packed), _ptr(bias), Cout, int(bool(relu)), _ptr(out), ops
+        fl = 2.0 * B * Ho * Wo * Cout * Cin * 25
+        if Cout > 64:
+            flops += fl
+            keys.append((H, W, Cin, Cout, 5, 2, 1))
+    t = _CONV_TIMING if flops > 0 else None
+    if t is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(lib.oess_conv5x5s2_group_bf16(ctypes.addressof(descs), n, _stream()), "oess_conv5x5s2_group_bf16")
+    if t is not None:
+        e1.record()
+        t["events"].append((e0, e1))
+        t["flops"] += flops
+        t.setdefault("keys", []).append((("group",) + tuple(keys), flops))
+    return [p[5] for p in problems]
+
+
 _SLICE_STATS = {}
 
 

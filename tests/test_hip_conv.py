@@ -495,3 +495,43 @@ def test_e2vid_events_head_enc0_equals_relayout_plus_fused(geom, normalize):
     # a tensor that is exactly one slice (the reference-contract call form) takes the single-slice statistics
     sl = ev[:, 10:15].contiguous()
     assert torch.equal(hip.e2vid_events_head_enc0(sl, 0, 5, normalize, ph, bh, True, pe, be, True), two)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W", [(2, 44, 64), (1, 23, 37), (8, 220, 320)])
+def test_conv5x5s2_group_equals_separate_launches(B, H, W):
+    """oess_conv5x5s2_group_bf16: the level-1 and level-2 encoder convs of the skewed schedule in one launch are bit-identical to two
+    oess_conv2d_fwd_bf16 calls -- with the real buffer layout (the level-2 conv reads the h half of the cat(x, h) buffer whose x half
+    the level-1 conv writes in the same launch); truly overlapping outputs and wrong output shapes are rejected."""
+    import torch
+    from openess_amd import hip
+    torch.manual_seed(B + H)
+    dev = "cuda"
+    H1, W1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    H2, W2 = (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1
+    h0 = (torch.randn(B, H, W, 128, device=dev) * 0.5).bfloat16()                 # cat buffer of level 0: its h half feeds level 1
+    w1 = torch.randn(128, 64, 5, 5, device=dev) * 0.03
+    w2 = torch.randn(256, 128, 5, 5, device=dev) * 0.02
+    b1, b2 = torch.randn(128, device=dev) * 0.1, torch.randn(256, device=dev) * 0.1
+    p1, p2 = hip.pack_conv_weight(w1), hip.pack_conv_weight(w2)
+    res = []
+    for grouped in (False, True):
+        xh1 = (torch.randn(B, H1, W1, 256, device=dev, generator=torch.Generator(dev).manual_seed(3)) * 0.5).bfloat16()
+        xh2 = torch.zeros(B, H2, W2, 512, device=dev, dtype=torch.bfloat16)
+        h1_before = xh1[..., 128:].clone()
+        probs = [(xh1[..., 128:], p2, b2, 256, False, xh2[..., :256]), (h0[..., 64:], p1, b1, 128, True, xh1[..., :128])]
+        if grouped:
+            hip.conv5x5s2_group(probs)
+        else:
+            for x, pk, bias, Co, relu, out in probs:
+                hip.conv2d_nhwc(x, pk, bias, Co, 5, 5, 2, 2, 1, relu=relu, out=out)
+        assert torch.equal(xh1[..., 128:], h1_before)                              # the h half is only read
+        res.append((xh1.clone(), xh2.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert float(res[1][1][..., :256].float().abs().max()) > 0
+    xh1 = torch.zeros(B, H1, W1, 256, device=dev, dtype=torch.bfloat16)
+    xh2 = torch.zeros(B, H2, W2, 512, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):            # level 2 reads what level 1 writes
+        hip.conv5x5s2_group([(xh1[..., :128], p2, b2, 256, False, xh2[..., :256]), (h0[..., 64:], p1, b1, 128, True, xh1[..., :128])])
+    with pytest.raises(ValueError):
+        hip.conv5x5s2_group([(h0[..., 64:], p1, b1, 128, True, xh1[..., :64])])
