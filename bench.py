@@ -465,7 +465,7 @@ def main():
         roof = None
         if conv_stats and conv_stats["ms"] > 0:
             ach = conv_stats["flops"] / (conv_stats["ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "conv3x3_halo_kernel<{0|1}> (3x3 stride-1, row-halo reuse; <1> = fused ConvLSTM epilogue) + conv_fwd_dma_kernel<{128|64},128,2> + conv_fwd_dma_kernel<256,256,2> (large 1x1 layers) + short-K conv_fwd_dma32_kernel<128,..,3> + conv5x5s2_halo_kernel (5x5 stride-2 encoders, 2-D input halo): implicit-GEMM bf16 MFMA with LDS-DMA operands, every forward / data-gradient launch with Cout > 64; conv FLOPs only",
+            roof = {"bound": "mfma", "kernel": "conv3x3_halo_group_kernel<1> (the three fused-ConvLSTM levels of a stage of the recurrent encoder in one launch) + conv3x3_halo_kernel<{0|1}> (3x3 stride-1, row-halo reuse) + conv_fwd_dma_kernel<{128|64},128,2> + conv_fwd_dma_kernel<256,256,2> (large 1x1 layers) + short-K conv_fwd_dma32_kernel<128,..,3> + conv5x5s2_halo{,_group}_kernel (5x5 stride-2 encoders, 2-D input halo; levels 1 + 2 in one launch): implicit-GEMM bf16 MFMA with LDS-DMA operands, every forward / data-gradient launch with Cout > 64; conv FLOPs only",
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                     "launches_per_step": conv_stats["launches"] // a.steps,

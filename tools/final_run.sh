@@ -10,7 +10,11 @@ timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 timeout 1200 python bench.py > $O/bench.txt 2>&1
 # same box, same code, recurrent encoder in the plain order (one ConvLSTM launch per level and sub-window): the A/B of the skewed schedule
-timeout 600 python bench.py --steps 30 --warmup 5 --no-skew --no-cpu-baseline --no-pmc --no-extras > $O/bench_no_skew.txt 2>&1
+# (alternating short runs: the 100-step line above and a 30-step run are not the same thermal state)
+for i in 1 2; do
+  timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-pmc --no-extras 2>&1 | tail -1 | cut -c1-160 >> $O/bench_no_skew.txt
+  timeout 600 python bench.py --steps 30 --warmup 5 --no-skew --no-cpu-baseline --no-pmc --no-extras 2>&1 | tail -1 | cut -c1-160 >> $O/bench_no_skew.txt
+done
 # RCCL call path with ONE rank (the box has one GPU): torch.distributed.run -> nccl process group -> bucketed all-reduce per step
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --no-pmc --no-extras > $O/bench_torchrun_world1.txt 2>&1
 for wl in frame2voxel_pixel_distill frame2voxel_full frame2recon_full; do
