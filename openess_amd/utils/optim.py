@@ -10,7 +10,9 @@ from torch.autograd.graph import increment_version
 
 from .. import _lib
 
-CHUNK = 65536
+# elements per workgroup of the multi-tensor kernel: the 7.4 M trainable parameters of the pre-training step are ~1 800 workgroups
+# (65 536 made 127 workgroups on 256 CUs with 256 dependent iterations each: 165 us for 206 MB of traffic)
+CHUNK = 4096
 
 
 def step_key(plist):
