@@ -16,9 +16,9 @@ cnt = collections.Counter()
 class Spy(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func)
-        if any(k in name for k in ("copy", "fill", "zero", "add", "mul", "clone")):
+        if any(k in name for k in ("copy", "fill", "zero", "add", "mul", "clone", "contiguous", "cat", "stack", "index", "slice_scatter")):
             t = next((a for a in args if torch.is_tensor(a)), None)
-            if t is not None and t.numel() <= 4096:
+            if t is not None and (t.numel() <= 4096 or "copy" in name or "clone" in name):
                 fr = [f"{os.path.basename(f.filename)}:{f.lineno}" for f in traceback.extract_stack()[:-1]
                       if "/root/repo" in f.filename or "openess_amd" in f.filename][-3:]
                 cnt[(name, str(t.device), tuple(t.shape), " <- ".join(fr))] += 1
