@@ -94,6 +94,10 @@ class UNetRecurrent(nn.Module):
         """The ConvLSTM steps of `levels` (independent of each other on the skewed schedule) as ONE launch when they all take the
         fused kernel, else one by one; st.out[l] = the new hidden state, st.ready[l] = the same view as level l + 1's next input."""
         from ... import hip
+        if len(levels) > 3:                                  # the grouped launch takes three problems (num_encoders = 4 variants)
+            self._lstm_stage(st, levels[:3])
+            self._lstm_stage(st, levels[3:])
+            return
         blocks = [self.encoders[l].recurrent_block for l in levels]
         if len(levels) > 1 and all(b.hidden_size % 32 == 0 for b in blocks):
             hs = hip.convlstm_fused_group([b.fused_args(st[l]) for b, l in zip(blocks, levels)])

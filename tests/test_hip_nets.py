@@ -605,3 +605,29 @@ def test_wavefront_schedule_equals_single_stream_order():
         losses.append({k: float(v) for k, v in ls.items()})
     for k in losses[0]:
         assert losses[1][k] == pytest.approx(losses[0][k], rel=2e-3), (k, losses)
+
+
+def test_skewed_schedule_with_four_encoders_equals_plain_order():
+    """num_encoders = 4 (the full-size E2VID of e2vid/model/model.py): a call of the skewed schedule has four independent ConvLSTM
+    steps -- one grouped launch of three plus one single launch -- and three deeper encoder convs (launched one by one); latents
+    and cell states are bit-identical to the plain order over a sequence longer than the skew."""
+    from openess_amd.e2vid.image_reconstructor import ImageReconstructor
+    from openess_amd.e2vid.model.model import E2VIDRecurrent
+    cfg = dict(E2VID_LIGHTWEIGHT_CONFIG, num_encoders=4)
+    m = E2VIDRecurrent(cfg).eval()
+    fill_by_name(m, 5)
+    m.cuda()
+    torch.manual_seed(3)
+    ev = (torch.randn(1, 35, 64, 96, device="cuda") * (torch.rand(1, 35, 64, 96, device="cuda") > 0.7)).contiguous()
+    out = {}
+    for skew in (False, True):
+        r = ImageReconstructor(m, 64, 96, 5, torch.device("cuda"))
+        r.skew = skew
+        for i in range(7):
+            _, states, lat = r.update_reconstruction(ev, channel_slice=(5 * i, 5), need_latents=(i == 6))
+        out[skew] = ({k: v.clone() for k, v in lat.items()}, [s_['cell'].clone() for s_ in states])
+    assert sorted(out[True][0]) == [1, 2, 4, 8, 16]
+    for k in out[True][0]:
+        assert torch.equal(out[True][0][k], out[False][0][k]), k
+    for a_, b_ in zip(out[True][1], out[False][1]):
+        assert torch.equal(a_, b_)
