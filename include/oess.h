@@ -125,10 +125,12 @@ int oess_segment_mean_bwd(const float* grad_k, const float* count, const int64_t
  * logits element (pixel p, class c) lives at logits[p*stride_p + c*stride_c] within a sample of
  * `pixels_per_sample` pixels whose base is b*stride_b (covers NCHW: stride_p=1, stride_c=HW,
  * stride_b=K*HW; and NHWC: stride_p=K, stride_c=1, stride_b=HW*K).  float32 or bf16.
- * target: [P] int64.  sums: (3*K+2) doubles scratch {inter[K], psq[K], ysum[K], ce_sum, n_valid},
- * zeroed by the fwd call and consumed by the bwd call.  loss_out: 3 floats {total, dice, ce}.
+ * target: [P] int64.  sums: oess_task_loss_sums_doubles(K) doubles of scratch: {inter[K], psq[K], ysum[K], ce_sum, n_valid}
+ * totals (written by the fwd call, consumed by the bwd call) followed by one row of partial sums per forward workgroup, which
+ * the fwd call adds in row order (no atomics: bit-repeatable).  loss_out: 3 floats {total, dice, ce}.
  * flags bit0 = dice, bit1 = cross-entropy.
  * ------------------------------------------------------------------------------------------ */
+size_t oess_task_loss_sums_doubles(int K);
 int oess_task_loss_fwd(const void* logits, int is_bf16, const int64_t* target, int64_t P, int64_t pixels_per_sample,
                        int64_t stride_b, int64_t stride_p, int64_t stride_c, int K, int ignore_index, int flags,
                        double* sums, float* loss_out, oess_stream_t stream);

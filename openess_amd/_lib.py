@@ -50,6 +50,7 @@ SIGNATURES = {
     "oess_masked_normalize_slice_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp]),
     "oess_segment_mean_fwd": (c_int, [c_vp, c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "oess_segment_mean_bwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_int, c_vp, c_sz, c_vp]),
+    "oess_task_loss_sums_doubles": (c_sz, [c_int]),
     "oess_task_loss_fwd": (c_int, [c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp,
                                    c_vp, c_vp]),
     "oess_task_loss_bwd": (c_int, [c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp,

@@ -434,6 +434,7 @@ __device__ __forceinline__ float load_logit(const void* base, int64_t idx) {
 }
 
 struct LossGeom { int64_t P, pps, sb, sp, sc; int K, ignore; };
+constexpr int TASK_LOSS_MAX_ROWS = 1024;           // forward workgroups = rows of partial sums
 
 // sums layout: inter[K] psq[K] ysum[K] ce_sum n_valid
 template <int KMAX, bool BF16>
@@ -482,28 +483,204 @@ __global__ __launch_bounds__(THREADS) void task_loss_fwd_kernel(const void* __re
         if (lane == 0) { red[w][3 * KMAX] = a; red[w][3 * KMAX + 1] = b2; }
     }
     __syncthreads();
+    // this workgroup's row of partial sums (no atomics: task_loss_finalize_kernel adds the rows in a fixed order)
+    double* row = sums + (size_t)(3 * g.K + 2) * (1 + blockIdx.x);
     for (int i = threadIdx.x; i < 3 * KMAX + 2; i += THREADS) {
         double s = 0;
         for (int k2 = 0; k2 < THREADS / 64; ++k2) s += red[k2][i];
         int dst;
         if (i < 3 * KMAX) { const int grp = i / KMAX, c = i % KMAX; if (c >= g.K) continue; dst = grp * g.K + c; }
         else dst = 3 * g.K + (i - 3 * KMAX);
-        if (s != 0.0) atomicAdd(&sums[dst], s);
+        row[dst] = s;
     }
 }
 
-__global__ void task_loss_finalize_kernel(const double* __restrict__ sums, int K, int ignore, int flags,
-                                          float* __restrict__ loss_out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// Dense NHWC fp32 logits ([P][K], what the decoder's classifier conv writes): a lane's K logits are K consecutive floats, so K
+// scalar loads per pixel touch every 128-byte line of the wave's span K times at 4 / (4 K) efficiency (76 us forward, 126 us
+// backward for 2.25 M pixels x 11 classes = 1.2-1.6 TB/s).  Here a workgroup moves its 256 pixels x K floats through LDS with
+// 16-byte accesses (row stride K words: conflict-free reads for odd K) -- same arithmetic as the generic kernels above.
+template <int KMAX>
+__device__ __forceinline__ void dense_tile_load(const float* __restrict__ src, int64_t total, float* sbuf) {
+    const int64_t n4 = total >> 2;
+    for (int64_t j = threadIdx.x; j < n4; j += THREADS)
+        *reinterpret_cast<float4*>(sbuf + 4 * j) = *reinterpret_cast<const float4*>(src + 4 * j);
+    for (int64_t j = 4 * n4 + threadIdx.x; j < total; j += THREADS) sbuf[j] = src[j];
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(THREADS) void task_loss_fwd_dense_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                                      LossGeom g, double* __restrict__ sums) {
+    __shared__ __attribute__((aligned(16))) float sbuf[THREADS * KMAX];
+    float inter[KMAX], psq[KMAX], ysum[KMAX];
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) { inter[c] = 0.f; psq[c] = 0.f; ysum[c] = 0.f; }
+    float ce = 0.f, nvalid = 0.f;
+    for (int64_t p0 = (int64_t)blockIdx.x * THREADS; p0 < g.P; p0 += (int64_t)gridDim.x * THREADS) {
+        const int64_t n = (g.P - p0 < THREADS) ? g.P - p0 : THREADS;
+        __syncthreads();                                   // the previous tile has been read
+        dense_tile_load<KMAX>(logits + p0 * g.K, n * g.K, sbuf);
+        __syncthreads();
+        const int64_t p = p0 + threadIdx.x;
+        const int64_t t = (threadIdx.x < n) ? target[p] : (int64_t)g.ignore;
+        if (t == g.ignore) continue;                       // (no barrier below this point in the iteration)
+        float z[KMAX];
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c)
+            if (c < g.K) { z[c] = sbuf[threadIdx.x * g.K + c]; m = fmaxf(m, z[c]); }
+        float den = 0.f, zt = 0.f;
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c)
+            if (c < g.K) { const float sh = z[c] - m; if (c == t) zt = sh; z[c] = expf(sh); den += z[c]; }
+        const float inv = 1.0f / den;
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c)
+            if (c < g.K) {
+                const float pr = z[c] * inv;
+                psq[c] += pr * pr;
+                if (c == t) { inter[c] += pr; ysum[c] += 1.0f; }
+            }
+        ce += logf(den) - zt;
+        nvalid += 1.0f;
+    }
+    __shared__ double red[THREADS / 64][3 * KMAX + 2];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) {
+        double a = wave_sum((double)inter[c]), b2 = wave_sum((double)psq[c]), y = wave_sum((double)ysum[c]);
+        if (lane == 0) { red[w][c] = a; red[w][KMAX + c] = b2; red[w][2 * KMAX + c] = y; }
+    }
+    {
+        double a = wave_sum((double)ce), b2 = wave_sum((double)nvalid);
+        if (lane == 0) { red[w][3 * KMAX] = a; red[w][3 * KMAX + 1] = b2; }
+    }
+    __syncthreads();
+    // this workgroup's row of partial sums (no atomics: task_loss_finalize_kernel adds the rows in a fixed order)
+    double* row = sums + (size_t)(3 * g.K + 2) * (1 + blockIdx.x);
+    for (int i = threadIdx.x; i < 3 * KMAX + 2; i += THREADS) {
+        double s = 0;
+        for (int k2 = 0; k2 < THREADS / 64; ++k2) s += red[k2][i];
+        int dst;
+        if (i < 3 * KMAX) { const int grp = i / KMAX, c = i % KMAX; if (c >= g.K) continue; dst = grp * g.K + c; }
+        else dst = 3 * g.K + (i - 3 * KMAX);
+        row[dst] = s;
+    }
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(THREADS) void task_loss_bwd_dense_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                                      LossGeom g, const double* __restrict__ sums, int flags,
+                                                                      float gscale_in, const float* __restrict__ gscale_dev,
+                                                                      float* __restrict__ grad) {
+    __shared__ __attribute__((aligned(16))) float sbuf[THREADS * KMAX];
+    const float gscale = gscale_dev ? gscale_in * gscale_dev[0] : gscale_in;
+    __shared__ float sN[KMAX], sD[KMAX];
+    if (threadIdx.x < KMAX) {
+        const int c = threadIdx.x;
+        if (c < g.K) {
+            sN[c] = (float)sums[c] * 2.0f + 1.0f;
+            sD[c] = (float)sums[g.K + c] + (float)sums[2 * g.K + c] + 1.0f;
+        }
+    }
+    const float inv_nvalid = (float)(1.0 / sums[3 * g.K + 1]);
+    const float invK = 1.0f / (float)g.K;
+    for (int64_t p0 = (int64_t)blockIdx.x * THREADS; p0 < g.P; p0 += (int64_t)gridDim.x * THREADS) {
+        const int64_t n = (g.P - p0 < THREADS) ? g.P - p0 : THREADS;
+        const int64_t total = n * g.K;
+        __syncthreads();                                   // sN / sD ready; the previous tile's gradient has left LDS
+        dense_tile_load<KMAX>(logits + p0 * g.K, total, sbuf);
+        __syncthreads();
+        if (threadIdx.x < n) {
+            const int64_t t = target[p0 + threadIdx.x];
+            float dz[KMAX];
+            if (t == g.ignore) {
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c) dz[c] = 0.f;
+            } else {
+                float z[KMAX];
+                float m = -INFINITY;
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c)
+                    if (c < g.K) { z[c] = sbuf[threadIdx.x * g.K + c]; m = fmaxf(m, z[c]); }
+                float den = 0.f;
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c)
+                    if (c < g.K) { z[c] = expf(z[c] - m); den += z[c]; }
+                const float inv = 1.0f / den;
+                float gp[KMAX];
+                float dot = 0.f;
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c)
+                    if (c < g.K) {
+                        const float pr = z[c] * inv;
+                        z[c] = pr;
+                        float gg = 0.f;
+                        if ((flags & 1) && c != g.ignore) {
+                            const float y = (c == t) ? 1.0f : 0.0f;
+                            gg = invK * (2.0f * pr * sN[c] - 2.0f * y * sD[c]) / (sD[c] * sD[c]);
+                        }
+                        gp[c] = gg;
+                        dot += gg * pr;
+                    }
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c)
+                    if (c < g.K) {
+                        float d = z[c] * (gp[c] - dot);
+                        if (flags & 2) d += (z[c] - ((c == t) ? 1.0f : 0.0f)) * inv_nvalid;
+                        dz[c] = d * gscale;
+                    }
+            }
+            // a thread only ever touches its own K words of the tile: the gradient may overwrite the logits in place
+#pragma unroll
+            for (int c = 0; c < KMAX; ++c)
+                if (c < g.K) sbuf[threadIdx.x * g.K + c] = dz[c];
+        }
+        __syncthreads();
+        float* dst = grad + p0 * g.K;
+        const int64_t n4 = total >> 2;
+        for (int64_t j = threadIdx.x; j < n4; j += THREADS)
+            *reinterpret_cast<float4*>(dst + 4 * j) = *reinterpret_cast<const float4*>(sbuf + 4 * j);
+        for (int64_t j = 4 * n4 + threadIdx.x; j < total; j += THREADS) dst[j] = sbuf[j];
+    }
+}
+
+// sums[0 .. 3K+2) = the rows of the forward workgroups added in a fixed order (bit-repeatable), then the loss.
+// 1024 threads = 128 columns x 8 row lanes: lane l adds rows l, l + 8, ... in order, the eight lane sums are added 0..7
+// (one thread per column walking all 1 024 rows took 42 us).
+__global__ __launch_bounds__(1024) void task_loss_finalize_kernel(double* __restrict__ sums, int rows, int K, int ignore, int flags,
+                                                                  float* __restrict__ loss_out) {
+    __shared__ double part[8][128];
+    __shared__ double tot[3 * 32 + 2];
+    const int nv = 3 * K + 2;
+    const int col = threadIdx.x & 127, rl = threadIdx.x >> 7;
+    {
+        double s = 0.0;
+        if (col < nv) {
+            const double* p = sums + nv + col;
+#pragma unroll 4
+            for (int r = rl; r < rows; r += 8) s += p[(size_t)r * nv];
+        }
+        part[rl][col] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nv) {
+        double s = 0.0;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) s += part[l][threadIdx.x];
+        tot[threadIdx.x] = s;
+        sums[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     float dice = 0.f;
     for (int c = 0; c < K; ++c) {
         if (c == ignore) continue;                          // loss_functions.py:128
-        const float num = (float)sums[c] * 2.0f + 1.0f;     // BinaryDiceLoss: smooth = 1, p = 2
-        const float den = (float)sums[K + c] + (float)sums[2 * K + c] + 1.0f;
+        const float num = (float)tot[c] * 2.0f + 1.0f;      // BinaryDiceLoss: smooth = 1, p = 2
+        const float den = (float)tot[K + c] + (float)tot[2 * K + c] + 1.0f;
         dice += 1.0f - num / den;
     }
     dice /= (float)K;                                       // total_loss / target.shape[1]
-    const float ce = (float)(sums[3 * K] / sums[3 * K + 1]);
+    const float ce = (float)(tot[3 * K] / tot[3 * K + 1]);
     float total = 0.f;
     if (flags & 1) total += dice;
     if (flags & 2) total += ce;
@@ -748,18 +925,27 @@ int oess_segment_mean_bwd(const float* grad_k, const float* count, const int64_t
     return OESS_OK;
 }
 
+size_t oess_task_loss_sums_doubles(int K) { return K > 0 ? (size_t)(3 * K + 2) * (1 + TASK_LOSS_MAX_ROWS) : 0; }
+
 int oess_task_loss_fwd(const void* logits, int is_bf16, const int64_t* target, int64_t P, int64_t pixels_per_sample,
                        int64_t stride_b, int64_t stride_p, int64_t stride_c, int K, int ignore_index, int flags,
                        double* sums, float* loss_out, oess_stream_t stream) {
     if (!logits || !target || !sums || !loss_out || P <= 0 || pixels_per_sample <= 0 || K <= 0 || K > 32)
         return OESS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    OESS_HIP(hipMemsetAsync(sums, 0, (size_t)(3 * K + 2) * sizeof(double), st));
     LossGeom g{P, pixels_per_sample, stride_b, stride_p, stride_c, K, ignore_index};
-    // every workgroup ends in 3K+2 double atomics on the same few cache lines (serialised in L2: 2048 workgroups spent
-    // ~100 us there): at most 512 workgroups, the per-thread fp32 partials then cover <= ~20 pixels before the promotion
+    // every workgroup leaves one row of 3K+2 double partial sums behind sums[0 .. 3K+2) (oess_task_loss_sums_doubles); the
+    // finalize kernel adds the rows in order.  (Double atomics on the totals instead: serialised in L2 -- 2 048 workgroups spent
+    // ~100 us there, a cap of 512 workgroups left the pixel loop latency-bound -- and order-dependent.)
     int grid = stream_grid(P, THREADS * 4);
-    if (grid > 512) grid = 512;
+    if (grid > TASK_LOSS_MAX_ROWS) grid = TASK_LOSS_MAX_ROWS;
+    // dense NHWC fp32 ([P][K]): tiles through LDS
+    const bool dense = !is_bf16 && stride_c == 1 && stride_p == K && stride_b == pixels_per_sample * K && K <= 16 &&
+                       (((uintptr_t)logits) & 15) == 0;
+    if (dense) {
+        if (K <= 8) hipLaunchKernelGGL((task_loss_fwd_dense_kernel<8>), dim3(grid), dim3(THREADS), 0, st, (const float*)logits, target, g, sums);
+        else hipLaunchKernelGGL((task_loss_fwd_dense_kernel<16>), dim3(grid), dim3(THREADS), 0, st, (const float*)logits, target, g, sums);
+    } else {
 #define LAUNCH_FWD(KM)                                                                                              \
     do {                                                                                                            \
         if (is_bf16)                                                                                                \
@@ -769,7 +955,8 @@ int oess_task_loss_fwd(const void* logits, int is_bf16, const int64_t* target, i
     } while (0)
     if (K <= 8) LAUNCH_FWD(8); else if (K <= 16) LAUNCH_FWD(16); else LAUNCH_FWD(32);
 #undef LAUNCH_FWD
-    hipLaunchKernelGGL(task_loss_finalize_kernel, dim3(1), dim3(64), 0, st, sums, K, ignore_index, flags, loss_out);
+    }
+    hipLaunchKernelGGL(task_loss_finalize_kernel, dim3(1), dim3(1024), 0, st, sums, grid, K, ignore_index, flags, loss_out);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }
@@ -783,6 +970,15 @@ int oess_task_loss_bwd(const void* logits, int is_bf16, const int64_t* target, i
     hipStream_t st = (hipStream_t)stream;
     LossGeom g{P, pixels_per_sample, stride_b, stride_p, stride_c, K, ignore_index};
     const int grid = stream_grid(P, THREADS * 4);
+    if (!is_bf16 && !grad_is_bf16 && stride_c == 1 && stride_p == K && stride_b == pixels_per_sample * K && K <= 16 &&
+        (((uintptr_t)logits) & 15) == 0 && (((uintptr_t)grad_logits) & 15) == 0) {        // dense NHWC fp32: tiles through LDS
+        if (K <= 8) hipLaunchKernelGGL((task_loss_bwd_dense_kernel<8>), dim3(grid), dim3(THREADS), 0, st, (const float*)logits, target, g, sums,
+                                       flags, grad_scale, grad_scale_dev, (float*)grad_logits);
+        else hipLaunchKernelGGL((task_loss_bwd_dense_kernel<16>), dim3(grid), dim3(THREADS), 0, st, (const float*)logits, target, g, sums,
+                                flags, grad_scale, grad_scale_dev, (float*)grad_logits);
+        OESS_HIP(hipGetLastError());
+        return OESS_OK;
+    }
 #define LAUNCH_BWD(KM, A, B)                                                                                   \
     hipLaunchKernelGGL((task_loss_bwd_kernel<KM, A, B>), dim3(grid), dim3(THREADS), 0, st, logits, target, g, sums, \
                        flags, grad_scale, grad_scale_dev, grad_logits)

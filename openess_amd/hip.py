@@ -283,7 +283,7 @@ class _TaskLoss(torch.autograd.Function):
     def forward(ctx, logits, target, K, ignore_index, flags, strides):
         lib = _lib.load()
         P, pps, sb, sp, sc = strides
-        sums = torch.empty(3 * K + 2, dtype=torch.float64, device=logits.device)
+        sums = torch.empty(lib.oess_task_loss_sums_doubles(K), dtype=torch.float64, device=logits.device)   # totals + partial rows
         loss = torch.empty(3, dtype=torch.float32, device=logits.device)
         is_bf16 = int(logits.dtype == torch.bfloat16)
         _lib.check(lib.oess_task_loss_fwd(_ptr(logits), is_bf16, _ptr(target), P, pps, sb, sp, sc, K, ignore_index,

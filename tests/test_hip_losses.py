@@ -49,6 +49,29 @@ def test_task_loss_full_size_vs_oracle():
     np.testing.assert_allclose(x.grad.float().cpu().numpy(), ref_in.grad.numpy(), rtol=1e-2, atol=1e-9)
 
 
+@pytest.mark.parametrize("B,K,H,W", [(2, 11, 440, 640), (1, 11, 37, 53), (3, 6, 20, 31), (1, 16, 16, 16)])
+def test_task_loss_dense_nhwc_fp32_equals_plane_layout(B, K, H, W):
+    """fp32 channels_last logits (what the decoder's classifier conv writes) take the LDS-staged kernels; same loss and gradient as
+    the NCHW layout through the generic kernels (identical per-pixel arithmetic; only the grouping of the partial sums differs),
+    with ignored pixels, pixel counts that are not a multiple of the 256-pixel tile and an upstream scale."""
+    from openess_amd import hip
+    torch.manual_seed(K + H)
+    lg = (torch.randn(B, K, H, W, device="cuda") * 3)
+    tgt = torch.randint(0, K, (B, H, W), device="cuda")
+    tgt[torch.rand(B, H, W, device="cuda") < 0.1] = 255
+    a = lg.clone().requires_grad_(True)
+    b = lg.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    la, pa = hip.task_loss(a, tgt, K)
+    lb, pb = hip.task_loss(b, tgt, K)
+    (la * 0.7).backward()
+    (lb * 0.7).backward()
+    np.testing.assert_allclose(lb.item(), la.item(), rtol=2e-6)
+    np.testing.assert_allclose(pb[0].item(), pa[0].item(), rtol=2e-6)
+    assert b.grad.is_contiguous(memory_format=torch.channels_last) or b.grad.shape == a.grad.shape
+    np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.cpu().numpy(), rtol=2e-5, atol=1e-10)
+    assert float(b.grad[(tgt == 255)[:, None].expand_as(b.grad)].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_superpixel_pool_golden(golden_losses, tag):
     from openess_amd import hip
