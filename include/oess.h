@@ -32,7 +32,10 @@ extern "C" {
 
 typedef void* oess_stream_t; /* hipStream_t */
 
-/* Library / device identification.  oess_abi_version() changes when a signature changes. */
+/* Library / device identification.  OESS_ABI_VERSION is bumped whenever a signature of this header changes or an entry point
+ * is removed; oess_abi_version() returns the value the library was built with and the ctypes binding (openess_amd/_lib.py,
+ * ABI_VERSION) refuses a library whose value differs. */
+#define OESS_ABI_VERSION 4
 int oess_abi_version(void);
 const char* oess_build_info(void);           /* "liboess <ver> gfx950 hipcc <ver>" */
 const char* oess_strerror(int code);
@@ -93,9 +96,11 @@ int oess_event_histogram_i64(const int64_t* events, const int64_t* seg_offsets, 
  * K2  Masked (non-zero) normalisation of a whole tensor.
  * Replaces EventPreprocessor.__call__ normalisation (e2vid/utils/inference_utils.py:78-85) and
  * normalize_voxel_grid (datasets/data_util.py:38-48).  in/out: n float32 (may alias).
- * stats: 4 doubles of caller-owned device scratch {sum, sumsq, nnz, -}; zeroed by the call.
+ * stats: oess_masked_stats_doubles(1) doubles of caller-owned device scratch: the totals {sum, sumsq, nnz, -} first, then one
+ * row of partial sums per workgroup, added in a fixed order by a finalize launch (deterministic: no floating-point atomics).
  * No host sync: the "if num_nonzeros > 0" test happens on the device.
  * ------------------------------------------------------------------------------------------ */
+size_t oess_masked_stats_doubles(int n_slices);
 int oess_masked_normalize_f32(const float* in, float* out, int64_t n, double* stats, oess_stream_t stream);
 /* Strided variant for a channel slice [B, c0:c0+Cs, H, W] of a [B, Ctot, H, W] tensor (the 5-bin
  * sub-window slice event[:, 5i:5i+5], training/pretrain_trainer.py:437-440). out is dense B x Cs x HW. */
@@ -110,9 +115,14 @@ int oess_masked_normalize_slice_f32(const float* in, float* out, int B, int Ctot
  * (pixels_per_sample = H*W).  k: [S x Cf] float32, count: [S] float32, both fully written.
  * Pixels whose offset id is outside [0, S) are an error in the reference (S = max id + 1) and are
  * ignored here.
+ * Deterministic (bit-repeatable): partial sums meet as 64-bit fixed-point integers (2^-32 units; 96-bit global
+ * accumulators in `workspace`, oess_segment_mean_fwd_workspace_bytes(S, Cf) bytes, 16-byte aligned).  Range
+ * contract: finite features with |x| < 32768; anything else makes the WHOLE of k NaN.
  * ------------------------------------------------------------------------------------------ */
+size_t oess_segment_mean_fwd_workspace_bytes(int S, int Cf);
 int oess_segment_mean_fwd(const void* feat, int is_bf16, const int64_t* ids, int64_t P, int64_t pixels_per_sample,
-                          int superpixel_size, int Cf, int S, float* k, float* count, oess_stream_t stream);
+                          int superpixel_size, int Cf, int S, float* k, float* count, void* workspace,
+                          size_t workspace_bytes, oess_stream_t stream);
 /* grad_feat[p, :] = grad_k[id(p), :] / (count[id(p)] + 1e-6)  (float32 or bf16 output).  workspace (nullable): S * Cf *
  * sizeof(output element) bytes, 16-byte aligned: the S x Cf quotients are then formed once and the per-pixel pass is a row gather. */
 int oess_segment_mean_bwd(const float* grad_k, const float* count, const int64_t* ids, int64_t P,
@@ -303,7 +313,8 @@ int oess_conv5x5s2_group_bf16(const oess_conv_s2_desc_t* problems, int n, oess_s
 
 /* Statistics of a channel slice without the apply pass (first half of K2): stats = {sum, sumsq, nnz, -}. */
 /* ... and of n_slices consecutive Cs-channel slices in ONE launch (the 20 sub-windows of a pre-training sample are known up
- * front, pretrain_trainer.py:437-441): stats[4 z ..] = {sum, sumsq, nnz, -} of in[:, z*Cs : (z+1)*Cs]. */
+ * front, pretrain_trainer.py:437-441): stats[4 z ..] = {sum, sumsq, nnz, -} of in[:, z*Cs : (z+1)*Cs].
+ * stats holds oess_masked_stats_doubles(n_slices) doubles (1 for the single-slice form): totals first, partial rows behind. */
 int oess_masked_stats_slices_f32(const float* in, int B, int Ctot, int Cs, int n_slices, int64_t HW, double* stats,
                                  oess_stream_t stream);
 int oess_masked_stats_slice_f32(const float* in, int B, int Ctot, int c0, int Cs, int64_t HW, double* stats,

@@ -10,6 +10,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OESS_LIB_PATH") or os.path.join(_HERE, "liboess.so")      # override: A/B builds of the same ABI
 
+ABI_VERSION = 4          # == OESS_ABI_VERSION of include/oess.h (tests/test_abi.py keeps the two equal)
+
 c_i64 = ctypes.c_int64
 c_ll = ctypes.c_longlong
 c_int = ctypes.c_int
@@ -46,9 +48,11 @@ SIGNATURES = {
     "oess_voxelize_nearest_f64": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_vp,
                                           c_vp, c_sz, c_vp]),
     "oess_event_histogram_i64": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_int, c_vp, c_vp]),
+    "oess_masked_stats_doubles": (c_sz, [c_int]),
     "oess_masked_normalize_f32": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "oess_masked_normalize_slice_f32": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_i64, c_vp, c_vp]),
-    "oess_segment_mean_fwd": (c_int, [c_vp, c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "oess_segment_mean_fwd_workspace_bytes": (c_sz, [c_int, c_int]),
+    "oess_segment_mean_fwd": (c_int, [c_vp, c_int, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "oess_segment_mean_bwd": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_int, c_vp, c_sz, c_vp]),
     "oess_task_loss_sums_doubles": (c_sz, [c_int]),
     "oess_task_loss_fwd": (c_int, [c_vp, c_int, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp,
@@ -134,6 +138,10 @@ def load():
             raise LibraryMissing(f"liboess.so lacks symbol {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
+    built = lib.oess_abi_version()
+    if built != ABI_VERSION:
+        raise LibraryMissing(f"{LIB_PATH} was built for C-ABI version {built}, the binding expects {ABI_VERSION}: rebuild it "
+                             "(`make -C openess_amd/csrc`)")
     _lib = lib
     return lib
 

@@ -3,7 +3,7 @@
 #include "oess.h"
 
 extern "C" {
-int oess_abi_version(void) { return 1; }
+int oess_abi_version(void) { return OESS_ABI_VERSION; }
 const char* oess_build_info(void) {
     return "liboess 0.1 gfx950 hip " __VERSION__;
 }

@@ -152,12 +152,16 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
         };
         bool last = false;
         while (st == ST_OK && !last) {
+            if (br.over > 8) { st = ST_OVERRUN; break; }
             last = br.get(1) != 0;
             const uint32_t bt = br.get(2);
             if (bt == 0) {                                  // stored
                 br.drop(br.cnt & 7);
                 const uint32_t ln = br.get(16), nl = br.get(16);
                 if ((ln ^ 0xffffu) != nl) { st = ST_BAD_BLOCK; break; }
+                // a stored block longer than what is left of the stream or of the image is corrupt: stop before copying it
+                if (out_n + (int64_t)ln > want) { st = ST_SIZE_MISMATCH; break; }
+                if ((int64_t)ln > (br.end - br.p) + (br.cnt >> 3)) { st = ST_OVERRUN; break; }
                 for (uint32_t i = 0; i < ln; ++i) emit((uint8_t)br.get(8));
                 continue;
             }
@@ -182,6 +186,7 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                 int i = 0;
                 // code lengths of both alphabets, run-length coded (written by lane 0, read back uniformly through LDS)
                 while (i < nl + nd && st == ST_OK) {
+                    if (br.over > 8) { st = ST_OVERRUN; break; }
                     const int sym = decode_sym(br, HL);
                     if (sym < 0) { st = ST_BAD_CODE; break; }
                     if (sym < 16) { if (lane == 0) lens[32 + i] = (uint8_t)sym; ++i; }
@@ -204,7 +209,12 @@ __global__ __launch_bounds__(64) void png_inflate_kernel(const uint8_t* __restri
                 build_huff(HD, lens + 32 + nl, nd, lane);
             }
             // ---- symbols of the block
+            // Every iteration is bounded: once the reader has run more than a tail's worth past the stream (it feeds zeros there,
+            // and the all-zero code is usually a literal, so the loop would never end on its own) or the image is over-full,
+            // the file is corrupt.  Chunk CRC / Adler-32 are not verified, so this is what stops a truncated zlib stream.
             while (st == ST_OK) {
+                if (br.over > 8) { st = ST_OVERRUN; break; }
+                if (out_n > want) { st = ST_SIZE_MISMATCH; break; }
                 int sym = decode_sym(br, HL);
                 if (sym < 0) { st = ST_BAD_CODE; break; }
                 if (sym < 256) { emit((uint8_t)sym); continue; }

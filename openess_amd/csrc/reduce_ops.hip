@@ -21,9 +21,10 @@ __host__ int stream_grid(int64_t work_items, int per_block) {
     return (int)g;
 }
 
-// block-wide sum of NV doubles per thread -> atomicAdd into dst[0..NV)
+// block-wide sum of NV doubles per thread -> dst[0..NV) (plain stores: one row of partial sums per workgroup; fixed order:
+// xor-shuffle tree inside a wave, then the waves in index order)
 template <int NV>
-__device__ __forceinline__ void block_atomic_add(double (&v)[NV], double* dst) {
+__device__ __forceinline__ void block_partial_store(double (&v)[NV], double* dst) {
     __shared__ double red[THREADS / 64][NV];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -35,15 +36,19 @@ __device__ __forceinline__ void block_atomic_add(double (&v)[NV], double* dst) {
     if (threadIdx.x < NV) {
         double s = 0;
         for (int k = 0; k < THREADS / 64; ++k) s += red[k][threadIdx.x];
-        if (s != 0.0) atomicAdd(&dst[threadIdx.x], s);
+        dst[threadIdx.x] = s;
     }
-    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------ K2
 // Tensor viewed as `nchunk` contiguous chunks of L floats; chunk j starts at in + in_off + j*in_stride,
 // out is dense.  (Dense tensor: nchunk = 1.)
 // grid = (blocks per chunk, nchunk): no per-element index division (a 64-bit divide per float4 made this ALU-bound).
+// DETERMINISTIC: every workgroup leaves one row {sum, sum of squares, non-zero count} of double partial sums; a finalize kernel
+// adds the rows of a slice in a fixed order (double atomics on the totals, as before round 4, made the statistics -- and through
+// them every latent of the recurrent encoder -- depend on the order in which workgroups retire).
+// stats layout: totals [n_slices][4] followed by the partial rows [n_slices][K2_MAX_ROWS][4] (oess_masked_stats_doubles).
+constexpr int K2_MAX_ROWS = 1024;
 __global__ __launch_bounds__(THREADS) void norm_stats_kernel(const float* __restrict__ in, int64_t L, int64_t nchunk,
                                                              int64_t in_stride, int64_t in_off, int vec,
                                                              double* __restrict__ stats) {
@@ -51,7 +56,7 @@ __global__ __launch_bounds__(THREADS) void norm_stats_kernel(const float* __rest
     // blockIdx.z = slice of a multi-slice launch (oess_masked_stats_slices_f32): slice z starts z * L floats further and
     // accumulates into stats[4 z ..]
     const float* src = in + in_off + (int64_t)blockIdx.z * L + (int64_t)blockIdx.y * in_stride;
-    stats += 4 * blockIdx.z;
+    double* row = stats + 4 * (int64_t)gridDim.z + 4 * ((int64_t)blockIdx.z * K2_MAX_ROWS + (int64_t)blockIdx.y * gridDim.x + blockIdx.x);
     const int64_t tid = (int64_t)blockIdx.x * THREADS + threadIdx.x, nthr = (int64_t)gridDim.x * THREADS;
     if (vec) {
         // four 16-byte loads in flight per lane; accumulation stays in double (the reference sums in float64-exact order
@@ -88,7 +93,25 @@ __global__ __launch_bounds__(THREADS) void norm_stats_kernel(const float* __rest
             acc[0] += d; acc[1] += d * d; acc[2] += (a != 0.0f) ? 1.0 : 0.0;
         }
     }
-    block_atomic_add<3>(acc, stats);
+    block_partial_store<3>(acc, row);
+}
+
+// one workgroup per slice: rows t, t+256, ... added in sequence by thread t, then a fixed LDS tree
+__global__ __launch_bounds__(THREADS) void norm_stats_finalize_kernel(double* __restrict__ stats, int rows) {
+    __shared__ double red[3][THREADS];
+    const double* part = stats + 4 * (int64_t)gridDim.x + 4 * (int64_t)blockIdx.x * K2_MAX_ROWS;
+    double a[3] = {0.0, 0.0, 0.0};
+    for (int r = threadIdx.x; r < rows; r += THREADS)
+        for (int i = 0; i < 3; ++i) a[i] += part[4 * (int64_t)r + i];
+    for (int i = 0; i < 3; ++i) red[i][threadIdx.x] = a[i];
+    __syncthreads();
+    for (int o = THREADS / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int i = 0; i < 3; ++i) red[i][threadIdx.x] += red[i][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) stats[4 * (int64_t)blockIdx.x + threadIdx.x] = red[threadIdx.x][0];
+    if (threadIdx.x == 3) stats[4 * (int64_t)blockIdx.x + 3] = 0.0;
 }
 
 __global__ __launch_bounds__(THREADS) void norm_apply_kernel(const float* __restrict__ in, float* __restrict__ out,
@@ -126,10 +149,10 @@ __global__ __launch_bounds__(THREADS) void norm_apply_kernel(const float* __rest
     }
 }
 
-// blocks per chunk: >= 8 items per thread, the whole launch <= 256 workgroups (one block reduction + 3 same-address atomics each)
+// blocks per chunk: >= 8 items per thread, at most K2_MAX_ROWS workgroups (= partial rows) per slice
 __host__ dim3 norm_grid(int64_t L, int64_t nchunk, int vec) {
     int64_t gx = (L / (vec ? 4 : 1) + THREADS * 8 - 1) / (THREADS * 8);
-    int64_t cap = 256 / (nchunk < 1 ? 1 : nchunk);      // measured: 2048 workgroups 23.9 us, 256 14.5 us (same-address atomics serialise in L2)
+    int64_t cap = K2_MAX_ROWS / (nchunk < 1 ? 1 : nchunk);
     if (cap < 1) cap = 1;
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
@@ -143,9 +166,10 @@ int run_normalize(const float* in, float* out, int64_t L, int64_t nchunk, int64_
     if (L * nchunk == 0) return OESS_OK;
     const int vec = ((L & 3) == 0) && ((in_stride & 3) == 0) && ((in_off & 3) == 0) &&
                     (((uintptr_t)in & 15) == 0) && (((uintptr_t)out & 15) == 0);
-    if (nchunk > 65535) return OESS_EINVAL;
+    if (nchunk > K2_MAX_ROWS) return OESS_EINVAL;
     const dim3 grid = norm_grid(L, nchunk, vec);
     hipLaunchKernelGGL(norm_stats_kernel, grid, dim3(THREADS), 0, st, in, L, nchunk, in_stride, in_off, vec, stats);
+    hipLaunchKernelGGL(norm_stats_finalize_kernel, dim3(1), dim3(THREADS), 0, st, stats, (int)(grid.x * grid.y));
     hipLaunchKernelGGL(norm_apply_kernel, grid, dim3(THREADS), 0, st, in, out, L, nchunk, in_stride, in_off, vec,
                        stats);
     OESS_HIP(hipGetLastError());
@@ -153,125 +177,96 @@ int run_normalize(const float* in, float* out, int64_t L, int64_t nchunk, int64_
 }
 
 // ------------------------------------------------------------------------------------------ K7
-// Wavefront-segmented scatter-mean.  Feature rows are pixel-major [P][Cf].  A workgroup owns a run
-// of consecutive pixels and a 64-channel slice; lane = channel, the 4 waves take interleaved
-// sub-runs.  Superpixels are spatially coherent, so each lane keeps a RUN accumulator in a register
-// and only touches LDS (ds_add_f32) when the id changes; LDS holds [256 local ids][64 ch].  Touched
-// rows are flushed with one global atomic per (workgroup, id, channel).  Raw ids outside [0,256)
-// (the reference reads uint8 PNGs, so they do not occur there) take a direct global-atomic path.
-constexpr int SEG_CH = 64;
-constexpr int SEG_LOCAL = 256;
-constexpr int SEG_PIX_PER_WG = 4096;
+// Superpixel scatter-mean, forward.  DETERMINISTIC: every partial sum that meets another one does so as a 64-bit fixed-point
+// integer (2^-32 units), so neither the order in which lane groups reach the LDS table nor the order in which workgroups
+// reach the global accumulators can change a bit of the result (integer addition is associative; float addition is not --
+// the fp32 atomics this replaces made the contrastive step repeat only to ~1e-6).
+//   * feature rows are pixel-major [P][Cf]; a workgroup owns a run of consecutive pixels of ONE sample and a 64-channel slice;
+//   * a lane group (64 channels / 16-byte lanes) walks its own contiguous sub-run with a fp32 register run-accumulator (fixed
+//     order: the pixels of the sub-run in sequence) and converts the run sum to fixed point when the superpixel id changes:
+//     ds_add_u64 into the LDS table [256 raw ids][64 channels];
+//   * touched rows leave with one pair of global integer atomics per (workgroup, id, channel): the value is split into its low
+//     32 bits (added to an unsigned accumulator) and its high part (signed accumulator), i.e. a 96-bit global sum: no range
+//     limit on a segment's total;
+//   * the finalize kernel recombines (hi * 2^32 + lo) * 2^-32 in double, rounds once to fp32 and divides by (count + 1e-6) as
+//     pretrain_trainer.py:462 does.
+// Range contract: |feature| < 32768 (a workgroup chunk has at most 65536 pixels, so its per-id sum stays below 2^31 in
+// fixed-point units of 2^-32; intermediate wrap-around is harmless in two's complement).  A non-finite or larger input sets
+// the error word and the WHOLE output becomes NaN (loud), instead of a silently wrong mean.  Resolution: the mean of a segment
+// is exact to 2^-33 absolute before the final fp32 rounding -- tighter than sequential fp32 accumulation for |mean| > 1e-3.
+// Raw ids outside [0,256) (the reference reads uint8 PNGs, so they do not occur there) go straight to the global accumulators.
+constexpr int SEGF_THREADS = 512;                 // 8 waves on the one workgroup a CU can hold (the table is 130 KB)
+constexpr int SEGF_CH = 64;                       // channels per workgroup
+constexpr int SEGF_IDS = 256;                     // raw ids held in LDS
+constexpr int SEGF_ROW = SEGF_CH + 1;             // u64 per table row: one pad entry rotates the banks from row to row
+constexpr int SEGF_MAX_PPW = 65536;
+constexpr size_t SEGF_LDS = (size_t)SEGF_IDS * SEGF_ROW * 8 + (size_t)SEGF_IDS * 4;
+typedef unsigned long long u64_t;
 
-template <bool BF16>
-__device__ __forceinline__ float load_feat(const void* feat, int64_t idx) {
-    if (BF16) return bf16_to_f32(((const uint16_t*)feat)[idx]);
-    return ((const float*)feat)[idx];
+__device__ __forceinline__ long long seg_to_fixed(float v) { return __float2ll_rn(v * 4294967296.0f); }
+
+__device__ __forceinline__ void seg_global_add(u64_t* __restrict__ acc_lo, u64_t* __restrict__ acc_hi, int64_t idx, long long v) {
+    if (v == 0) return;
+    atomicAdd(&acc_lo[idx], (u64_t)v & 0xffffffffull);
+    const long long hi = v >> 32;                                        // arithmetic shift: v = hi * 2^32 + lo, lo in [0, 2^32)
+    if (hi != 0) atomicAdd(&acc_hi[idx], (u64_t)hi);
 }
 
-template <bool BF16>
-__global__ __launch_bounds__(THREADS) void segmean_fwd_kernel(const void* __restrict__ feat,
-                                                              const int64_t* __restrict__ ids, int64_t P, int64_t pps,
-                                                              int sps, int Cf, int S, float* __restrict__ k,
-                                                              float* __restrict__ count) {
-    __shared__ float acc[SEG_LOCAL][SEG_CH];
-    __shared__ int cnt[SEG_LOCAL];
-    __shared__ int touched[SEG_LOCAL];
-    const int slice = blockIdx.y;                        // 64-channel slice
-    const int c = slice * SEG_CH + (threadIdx.x & 63);
-    const bool c_ok = c < Cf;
-    const int wave = threadIdx.x >> 6;
-    // chunk never crosses a sample boundary: chunks are laid out per sample
-    const int64_t chunks_per_sample = (pps + SEG_PIX_PER_WG - 1) / SEG_PIX_PER_WG;
-    const int64_t b = blockIdx.x / chunks_per_sample, ch = blockIdx.x - b * chunks_per_sample;
-    const int64_t p_beg = b * pps + ch * SEG_PIX_PER_WG;
-    int64_t p_end = p_beg + SEG_PIX_PER_WG;
-    if (p_end > (b + 1) * pps) p_end = (b + 1) * pps;
-    if (p_end > P) p_end = P;
-    for (int i = threadIdx.x; i < SEG_LOCAL * SEG_CH; i += THREADS) (&acc[0][0])[i] = 0.0f;
-    for (int i = threadIdx.x; i < SEG_LOCAL; i += THREADS) { cnt[i] = 0; touched[i] = 0; }
-    __syncthreads();
-    const int64_t id_off = b * (int64_t)sps;
-    // each wave walks a contiguous quarter of the chunk so that runs stay long
-    const int64_t len = p_end - p_beg;
-    const int64_t q = (len + 3) / 4;
-    int64_t w_beg = p_beg + wave * q, w_end = w_beg + q;
-    if (w_end > p_end) w_end = p_end;
-    int64_t cur = -1;                                    // current raw id of the run (wave-uniform)
-    float run = 0.0f;
-    int run_n = 0;
-    const int lane = threadIdx.x & 63;
-    auto flush = [&]() {
-        if (run_n == 0) return;
-        if (cur >= 0 && cur < SEG_LOCAL) {
-            if (c_ok) atomicAdd(&acc[cur][lane], run);
-            if (lane == 0) { atomicAdd(&cnt[cur], run_n); touched[cur] = 1; }
-        } else {
-            const int64_t gid = cur + id_off;
-            if (gid >= 0 && gid < S) {
-                if (c_ok) atomicAdd(&k[gid * Cf + c], run);
-                if (lane == 0 && slice == 0) atomicAdd(&count[gid], (float)run_n);
-            }
-        }
-    };
-    constexpr int U = 16;                                // independent loads in flight per wave
-    for (int64_t p = w_beg; p < w_end; p += U) {
-        float v[U];
-        int64_t id[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t pu = p + u;
-            const bool ok = pu < w_end;
-            id[u] = ok ? ids[pu] : cur;                  // wave-uniform address -> scalar load
-            v[u] = (ok && c_ok) ? load_feat<BF16>(feat, pu * Cf + c) : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (p + u < w_end) {
-                if (id[u] != cur) { flush(); cur = id[u]; run = 0.0f; run_n = 0; }
-                run += v[u];
-                run_n += 1;
-            }
-        }
-    }
-    flush();
-    __syncthreads();
-    for (int i = wave; i < SEG_LOCAL; i += THREADS / 64) {
-        if (!touched[i]) continue;
+struct SegGeom { int64_t P, pps; int sps, Cf, S, nslice, pix_per_wg; };
+
+// workgroup -> (sample, pixel chunk, channel slice); the slices of one chunk are neighbours in blockIdx
+__device__ __forceinline__ void seg_chunk(const SegGeom& g, int& slice, int64_t& b, int64_t& p_beg, int64_t& p_end) {
+    slice = blockIdx.x % g.nslice;
+    const int64_t lin = blockIdx.x / g.nslice;
+    const int64_t chunks_per_sample = (g.pps + g.pix_per_wg - 1) / g.pix_per_wg;
+    b = lin / chunks_per_sample;
+    const int64_t ch = lin - b * chunks_per_sample;
+    p_beg = b * g.pps + ch * g.pix_per_wg;
+    p_end = p_beg + g.pix_per_wg;
+    if (p_end > (b + 1) * g.pps) p_end = (b + 1) * g.pps;
+    if (p_end > g.P) p_end = g.P;
+}
+
+// table rows with a non-zero pixel count -> global accumulators.  `pos(ch)` = where channel ch of the slice sits in a row.
+template <typename PosFn>
+__device__ __forceinline__ void seg_flush_table(const SegGeom& g, const u64_t* tab, const int* cnt, int slice, int64_t id_off,
+                                                u64_t* __restrict__ acc_lo, u64_t* __restrict__ acc_hi, int* __restrict__ gcnt, PosFn pos) {
+    const int ch = threadIdx.x & 63;
+    const int c = slice * SEGF_CH + ch;
+    const int ps = pos(ch);
+    for (int i = threadIdx.x >> 6; i < SEGF_IDS; i += SEGF_THREADS / 64) {
+        const int n = cnt[i];
+        if (n == 0) continue;
         const int64_t gid = i + id_off;
-        if (gid < 0 || gid >= S) continue;
-        if (c_ok) atomicAdd(&k[gid * Cf + c], acc[i][threadIdx.x & 63]);
-        if ((threadIdx.x & 63) == 0 && slice == 0) atomicAdd(&count[gid], (float)cnt[i]);
+        if (gid < 0 || gid >= g.S) continue;
+        if (c < g.Cf) seg_global_add(acc_lo, acc_hi, gid * g.Cf + c, (long long)tab[i * SEGF_ROW + ps]);
+        if (ch == 0 && slice == 0) atomicAdd(&gcnt[gid], n);
     }
 }
 
-// Vectorised form (C/CPL lanes per pixel, CPL = 8 bf16 / 4 fp32 channels = one 16-byte load per lane): a wave covers
-// 64/LPP whole pixel rows per load instruction and keeps U of them in flight; each LPP-lane group walks its own
-// contiguous pixel run with a register run-accumulator and only touches the LDS table [VLOCAL ids][C] when the id
-// changes.  One workgroup per CU (the table is up to 128 KB); 8 groups x 8 loads x 512 B = 32 KB in flight per CU.
-
-constexpr int SEGV_THREADS = 512;        // 8 waves on the one workgroup a CU can hold (the LDS table is up to 128 KB)
-template <bool BF16, int LPP>
-__global__ __launch_bounds__(SEGV_THREADS) void segmean_fwd_vec_kernel(const void* __restrict__ feat, const int64_t* __restrict__ ids,
-                                                                  int64_t P, int64_t pps, int sps, int S, int vlocal,
-                                                                  float* __restrict__ k, float* __restrict__ count, int pix_per_wg) {
+// Vectorised form: CPL = 8 bf16 / 4 fp32 channels = one 16-byte load per lane, LPP = 64 / CPL lanes per pixel row, a wave covers
+// 64 / LPP whole pixel rows per load instruction and keeps U of them in flight (software-pipelined).
+template <bool BF16>
+__global__ __launch_bounds__(SEGF_THREADS) void segmean_fwd_fx_kernel(const void* __restrict__ feat, const int64_t* __restrict__ ids,
+                                                                 SegGeom g, u64_t* __restrict__ acc_lo, u64_t* __restrict__ acc_hi,
+                                                                 int* __restrict__ gcnt, int* __restrict__ err) {
     constexpr int CPL = BF16 ? 8 : 4;
-    constexpr int Cf = LPP * CPL;
-    constexpr int GROUPS = SEGV_THREADS / LPP;
+    constexpr int LPP = SEGF_CH / CPL;
+    constexpr int GROUPS = SEGF_THREADS / LPP;
     extern __shared__ __attribute__((aligned(16))) unsigned char seg_smem[];
-    float* acc = reinterpret_cast<float*>(seg_smem);                    // [vlocal][Cf]
-    int* cnt = reinterpret_cast<int*>(acc + (size_t)vlocal * Cf);       // [vlocal]
+    u64_t* tab = reinterpret_cast<u64_t*>(seg_smem);                               // [SEGF_IDS][SEGF_ROW]; channel sub*CPL+c at c*LPP+sub
+    int* cnt = reinterpret_cast<int*>(tab + (size_t)SEGF_IDS * SEGF_ROW);          // [SEGF_IDS]
     const int sub = threadIdx.x % LPP, grp = threadIdx.x / LPP;
-    const int64_t chunks_per_sample = (pps + pix_per_wg - 1) / pix_per_wg;
-    const int64_t b = blockIdx.x / chunks_per_sample, ch = blockIdx.x - b * chunks_per_sample;
-    const int64_t p_beg = b * pps + ch * pix_per_wg;
-    int64_t p_end = p_beg + pix_per_wg;
-    if (p_end > (b + 1) * pps) p_end = (b + 1) * pps;
-    if (p_end > P) p_end = P;
-    for (int i = threadIdx.x; i < vlocal * Cf; i += SEGV_THREADS) acc[i] = 0.0f;
-    for (int i = threadIdx.x; i < vlocal; i += SEGV_THREADS) cnt[i] = 0;
+    int slice;
+    int64_t b, p_beg, p_end;
+    seg_chunk(g, slice, b, p_beg, p_end);
+    const int Cf = g.Cf;
+    const int c0 = slice * SEGF_CH + sub * CPL;                                    // first channel of this lane
+    const bool c_ok = c0 < Cf;                                                      // Cf % CPL == 0: a lane is all in or all out
+    for (int i = threadIdx.x; i < SEGF_IDS * SEGF_ROW; i += SEGF_THREADS) tab[i] = 0ull;
+    for (int i = threadIdx.x; i < SEGF_IDS; i += SEGF_THREADS) cnt[i] = 0;
     __syncthreads();
-    const int64_t id_off = b * (int64_t)sps;
+    const int64_t id_off = b * (int64_t)g.sps;
     const int64_t len = p_end - p_beg;
     const int64_t q = (len + GROUPS - 1) / GROUPS;
     int64_t g_beg = p_beg + grp * q, g_end = g_beg + q;
@@ -281,37 +276,41 @@ __global__ __launch_bounds__(SEGV_THREADS) void segmean_fwd_vec_kernel(const voi
 #pragma unroll
     for (int c = 0; c < CPL; ++c) run[c] = 0.f;
     int run_n = 0;
+    uint32_t amax = 0;                                                              // max |bit pattern| seen (range / finiteness check)
     auto flush = [&]() {
         if (run_n == 0) return;
-        if (cur >= 0 && cur < vlocal) {
+        if (cur >= 0 && cur < SEGF_IDS) {
+            if (c_ok) {
+                u64_t* row = tab + cur * SEGF_ROW + sub;
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) atomicAdd(&acc[cur * Cf + sub * CPL + c], run[c]);
+                for (int c = 0; c < CPL; ++c) atomicAdd(&row[c * LPP], (u64_t)seg_to_fixed(run[c]));
+            }
             if (sub == 0) atomicAdd(&cnt[cur], run_n);
         } else {
             const int64_t gid = cur + id_off;
-            if (gid >= 0 && gid < S) {
+            if (gid >= 0 && gid < g.S) {
+                if (c_ok) {
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) atomicAdd(&k[gid * Cf + sub * CPL + c], run[c]);
-                if (sub == 0) atomicAdd(&count[gid], (float)run_n);
+                    for (int c = 0; c < CPL; ++c) seg_global_add(acc_lo, acc_hi, gid * Cf + c0 + c, seg_to_fixed(run[c]));
+                }
+                if (sub == 0 && slice == 0) atomicAdd(&gcnt[gid], run_n);
             }
         }
     };
     constexpr int U = 8;
-    // Software-pipelined: the U row loads (and ids) of iteration i+1 are issued BEFORE iteration i is walked.  Without it an
-    // iteration was "issue U loads, wait for all of them, walk U pixels" -- one memory latency per 8 pixels of every lane
-    // group, which is why the bf16 features (half the bytes per pixel) took exactly as long as the fp32 ones.
     using RawRow = typename std::conditional<BF16, uint4, float4>::type;
     RawRow cur_r[U], nxt_r[U];
     int64_t cur_id[U], nxt_id[U];
+    const int c0_ld = c_ok ? c0 : 0;                                                // masked lanes load a valid address and drop the value
     auto issue = [&](int64_t p, RawRow (&r)[U], int64_t (&id)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t pu = p + u;
             const bool ok = pu < g_end;
             id[u] = ok ? ids[pu] : (int64_t)-1;
-            const int64_t pc = ok ? pu : (g_end > g_beg ? g_end - 1 : p_beg);          // clamped: always a valid row of this chunk
-            if constexpr (BF16) r[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(feat) + pc * Cf + sub * 8);
-            else r[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(feat) + pc * Cf + sub * 4);
+            const int64_t pc = ok ? pu : (g_end > g_beg ? g_end - 1 : p_beg);      // clamped: always a valid row of this chunk
+            if constexpr (BF16) r[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(feat) + pc * Cf + c0_ld);
+            else r[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(feat) + pc * Cf + c0_ld);
         }
     };
     if (g_beg < g_end) issue(g_beg, cur_r, cur_id);
@@ -322,12 +321,18 @@ __global__ __launch_bounds__(SEGV_THREADS) void segmean_fwd_vec_kernel(const voi
             if (p + u < g_end) {
                 float v[CPL];
                 if constexpr (BF16) {
-                    union { uint4 q4; uint16_t h[8]; } r;
-                    r.q4 = cur_r[u];
+                    const uint32_t w[4] = {cur_r[u].x, cur_r[u].y, cur_r[u].z, cur_r[u].w};
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) v[c] = bf16_to_f32(r.h[c]);
+                    for (int j = 0; j < 4; ++j) {
+                        v[2 * j] = __uint_as_float(w[j] << 16);
+                        v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+                        const uint32_t lo = (w[j] << 16) & 0x7fffffffu, hi = w[j] & 0x7fff0000u;
+                        amax = max(amax, max(lo, hi));
+                    }
                 } else {
                     v[0] = cur_r[u].x; v[1] = cur_r[u].y; v[2] = cur_r[u].z; v[3] = cur_r[u].w;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) amax = max(amax, __float_as_uint(v[c]) & 0x7fffffffu);
                 }
                 if (cur_id[u] != cur) {
                     flush();
@@ -345,23 +350,94 @@ __global__ __launch_bounds__(SEGV_THREADS) void segmean_fwd_vec_kernel(const voi
         for (int u = 0; u < U; ++u) { cur_r[u] = nxt_r[u]; cur_id[u] = nxt_id[u]; }
     }
     flush();
+    if (c_ok && amax >= 0x47000000u) atomicOr(err, 1);                             // |x| >= 32768, inf or NaN
     __syncthreads();
-    for (int i = grp; i < vlocal; i += GROUPS) {
-        const int n = cnt[i];
-        if (n == 0) continue;
-        const int64_t gid = i + id_off;
-        if (gid < 0 || gid >= S) continue;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) atomicAdd(&k[gid * Cf + sub * CPL + c], acc[i * Cf + sub * CPL + c]);
-        if (sub == 0) atomicAdd(&count[gid], (float)n);
-    }
+    seg_flush_table(g, tab, cnt, slice, id_off, acc_lo, acc_hi, gcnt, [](int ch) { return (ch % CPL) * LPP + ch / CPL; });
 }
 
-__global__ __launch_bounds__(THREADS) void segmean_finalize_kernel(float* __restrict__ k, const float* __restrict__ count,
-                                                                   int S, int Cf) {
+// Generic form (any Cf, any alignment): lane = channel of the 64-channel slice, the 8 waves take contiguous eighths of the chunk.
+template <bool BF16>
+__global__ __launch_bounds__(SEGF_THREADS) void segmean_fwd_fx_scalar_kernel(const void* __restrict__ feat, const int64_t* __restrict__ ids,
+                                                                        SegGeom g, u64_t* __restrict__ acc_lo, u64_t* __restrict__ acc_hi,
+                                                                        int* __restrict__ gcnt, int* __restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char seg_smem[];
+    u64_t* tab = reinterpret_cast<u64_t*>(seg_smem);
+    int* cnt = reinterpret_cast<int*>(tab + (size_t)SEGF_IDS * SEGF_ROW);
+    int slice;
+    int64_t b, p_beg, p_end;
+    seg_chunk(g, slice, b, p_beg, p_end);
+    const int Cf = g.Cf;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = slice * SEGF_CH + lane;
+    const bool c_ok = c < Cf;
+    for (int i = threadIdx.x; i < SEGF_IDS * SEGF_ROW; i += SEGF_THREADS) tab[i] = 0ull;
+    for (int i = threadIdx.x; i < SEGF_IDS; i += SEGF_THREADS) cnt[i] = 0;
+    __syncthreads();
+    const int64_t id_off = b * (int64_t)g.sps;
+    constexpr int WAVES = SEGF_THREADS / 64;
+    const int64_t len = p_end - p_beg;
+    const int64_t q = (len + WAVES - 1) / WAVES;
+    int64_t w_beg = p_beg + wave * q, w_end = w_beg + q;
+    if (w_end > p_end) w_end = p_end;
+    int64_t cur = -1;                                    // current raw id of the run (wave-uniform)
+    float run = 0.0f;
+    int run_n = 0;
+    uint32_t amax = 0;
+    auto flush = [&]() {
+        if (run_n == 0) return;
+        if (cur >= 0 && cur < SEGF_IDS) {
+            if (c_ok) atomicAdd(&tab[cur * SEGF_ROW + lane], (u64_t)seg_to_fixed(run));
+            if (lane == 0) atomicAdd(&cnt[cur], run_n);
+        } else {
+            const int64_t gid = cur + id_off;
+            if (gid >= 0 && gid < g.S) {
+                if (c_ok) seg_global_add(acc_lo, acc_hi, gid * Cf + c, seg_to_fixed(run));
+                if (lane == 0 && slice == 0) atomicAdd(&gcnt[gid], run_n);
+            }
+        }
+    };
+    constexpr int U = 16;                                // independent loads in flight per wave
+    for (int64_t p = w_beg; p < w_end; p += U) {
+        float v[U];
+        int64_t id[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t pu = p + u;
+            const bool ok = pu < w_end;
+            id[u] = ok ? ids[pu] : cur;                  // wave-uniform address -> scalar load
+            v[u] = 0.0f;
+            if (ok && c_ok) v[u] = BF16 ? bf16_to_f32(((const uint16_t*)feat)[pu * Cf + c]) : ((const float*)feat)[pu * Cf + c];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (p + u < w_end) {
+                if (id[u] != cur) { flush(); cur = id[u]; run = 0.0f; run_n = 0; }
+                amax = max(amax, __float_as_uint(v[u]) & 0x7fffffffu);
+                run += v[u];
+                run_n += 1;
+            }
+        }
+    }
+    flush();
+    if (amax >= 0x47000000u) atomicOr(err, 1);
+    __syncthreads();
+    seg_flush_table(g, tab, cnt, slice, id_off, acc_lo, acc_hi, gcnt, [](int ch) { return ch; });
+}
+
+// k = fp32( (hi * 2^32 + lo) * 2^-32 ) / (count + 1e-6)   (pretrain_trainer.py:462); count as the fp32 row sum the reference forms
+__global__ __launch_bounds__(THREADS) void segmean_fx_finalize_kernel(const u64_t* __restrict__ acc_lo, const u64_t* __restrict__ acc_hi,
+                                                                      const int* __restrict__ gcnt, const int* __restrict__ err,
+                                                                      float* __restrict__ k, float* __restrict__ count, int S, int Cf) {
     const int64_t n = (int64_t)S * Cf;
-    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS)
-        k[i] = k[i] / __fadd_rn(count[i / Cf], 1e-6f);     // pretrain_trainer.py:462
+    const bool bad = *err != 0;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS) {
+        const int64_t s = i / Cf;
+        const double tot = (double)(long long)acc_hi[i] * 4294967296.0 + (double)acc_lo[i];
+        const float sum = (float)(tot * (1.0 / 4294967296.0));
+        const float cn = (float)gcnt[s];
+        k[i] = bad ? __uint_as_float(0x7fc00000u) : sum / __fadd_rn(cn, 1e-6f);
+        if (i - s * Cf == 0) count[s] = cn;
+    }
 }
 
 template <bool BF16>
@@ -778,6 +854,8 @@ __global__ __launch_bounds__(THREADS) void confusion_kernel(const int64_t* __res
 
 extern "C" {
 
+size_t oess_masked_stats_doubles(int n_slices) { return n_slices > 0 ? (size_t)n_slices * 4 * (1 + K2_MAX_ROWS) : 0; }
+
 int oess_masked_normalize_f32(const float* in, float* out, int64_t n, double* stats, oess_stream_t stream) {
     return run_normalize(in, out, n, 1, 0, 0, stats, (hipStream_t)stream);
 }
@@ -792,92 +870,79 @@ int oess_masked_stats_slice_f32(const float* in, int B, int Ctot, int c0, int Cs
                                 oess_stream_t stream) {
     if (!in || !stats || B <= 0 || Ctot <= 0 || Cs <= 0 || c0 < 0 || c0 + Cs > Ctot || HW <= 0) return OESS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    OESS_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(double), st));
     const int64_t L = (int64_t)Cs * HW, in_stride = (int64_t)Ctot * HW, in_off = (int64_t)c0 * HW;
     const int vec = ((L & 3) == 0) && ((in_stride & 3) == 0) && ((in_off & 3) == 0) && (((uintptr_t)in & 15) == 0);
-    if (B > 65535) return OESS_EINVAL;
-    hipLaunchKernelGGL(norm_stats_kernel, norm_grid(L, B, vec), dim3(THREADS), 0, st, in, L, (int64_t)B, in_stride, in_off, vec, stats);
+    if (B > K2_MAX_ROWS) return OESS_EINVAL;
+    const dim3 grid = norm_grid(L, B, vec);
+    hipLaunchKernelGGL(norm_stats_kernel, grid, dim3(THREADS), 0, st, in, L, (int64_t)B, in_stride, in_off, vec, stats);
+    hipLaunchKernelGGL(norm_stats_finalize_kernel, dim3(1), dim3(THREADS), 0, st, stats, (int)(grid.x * grid.y));
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }
 
 int oess_masked_stats_slices_f32(const float* in, int B, int Ctot, int Cs, int n_slices, int64_t HW, double* stats,
                                  oess_stream_t stream) {
-    if (!in || !stats || B <= 0 || Ctot <= 0 || Cs <= 0 || n_slices <= 0 || (int64_t)n_slices * Cs > Ctot || HW <= 0 || B > 65535 ||
+    if (!in || !stats || B <= 0 || Ctot <= 0 || Cs <= 0 || n_slices <= 0 || (int64_t)n_slices * Cs > Ctot || HW <= 0 || B > K2_MAX_ROWS ||
         n_slices > 65535)
         return OESS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    OESS_HIP(hipMemsetAsync(stats, 0, (size_t)n_slices * 4 * sizeof(double), st));
     const int64_t L = (int64_t)Cs * HW, in_stride = (int64_t)Ctot * HW;
     const int vec = ((L & 3) == 0) && ((in_stride & 3) == 0) && (((uintptr_t)in & 15) == 0);
     dim3 grid = norm_grid(L, B, vec);
-    {   // norm_grid caps a launch at 256 workgroups because all of them add into ONE triple of doubles; here every slice has its
-        // own triple, so the cap applies per slice: up to 4x more workgroups per slice keep the 720 MB pass on the HBM roofline
-        int64_t gx = (L / (vec ? 4 : 1) + THREADS * 8 - 1) / (THREADS * 8);
-        int64_t cap = 1024 / B;
-        if (cap < 1) cap = 1;
-        if (gx > cap) gx = cap;
-        if (gx > (int64_t)grid.x) grid.x = (unsigned)gx;
-    }
     grid.z = (unsigned)n_slices;
     hipLaunchKernelGGL(norm_stats_kernel, grid, dim3(THREADS), 0, st, in, L, (int64_t)B, in_stride, (int64_t)0, vec, stats);
+    hipLaunchKernelGGL(norm_stats_finalize_kernel, dim3((unsigned)n_slices), dim3(THREADS), 0, st, stats, (int)(grid.x * grid.y));
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }
 
+size_t oess_segment_mean_fwd_workspace_bytes(int S, int Cf) {
+    if (S <= 0 || Cf <= 0) return 0;
+    return align_up((size_t)S * Cf * 16 + (size_t)S * 4 + 4, 16);
+}
+
 int oess_segment_mean_fwd(const void* feat, int is_bf16, const int64_t* ids, int64_t P, int64_t pixels_per_sample,
-                          int superpixel_size, int Cf, int S, float* k, float* count, oess_stream_t stream) {
-    if (!feat || !ids || !k || !count || P <= 0 || pixels_per_sample <= 0 || Cf <= 0 || S <= 0) return OESS_EINVAL;
-    if (P % pixels_per_sample != 0) return OESS_EINVAL;
+                          int superpixel_size, int Cf, int S, float* k, float* count, void* workspace, size_t workspace_bytes,
+                          oess_stream_t stream) {
+    if (!feat || !ids || !k || !count || !workspace || P <= 0 || pixels_per_sample <= 0 || Cf <= 0 || S <= 0) return OESS_EINVAL;
+    if (P % pixels_per_sample != 0 || ((uintptr_t)workspace & 15) != 0) return OESS_EINVAL;
+    const size_t need = oess_segment_mean_fwd_workspace_bytes(S, Cf);
+    if (workspace_bytes < need) return OESS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    OESS_HIP(hipMemsetAsync(k, 0, (size_t)S * Cf * sizeof(float), st));
-    OESS_HIP(hipMemsetAsync(count, 0, (size_t)S * sizeof(float), st));
+    OESS_HIP(hipMemsetAsync(workspace, 0, need, st));
+    u64_t* acc_lo = (u64_t*)workspace;
+    u64_t* acc_hi = acc_lo + (size_t)S * Cf;
+    int* gcnt = (int*)(acc_hi + (size_t)S * Cf);
+    int* err = gcnt + S;
     const int64_t B = P / pixels_per_sample;
-    {   // vectorised kernel: Cf = LPP * (8 bf16 | 4 fp32 channels per lane), LPP in {8, 16, 32, 64}, 16-byte aligned rows
-        const int cpl = is_bf16 ? 8 : 4;
-        const int lpp = (Cf % cpl == 0) ? Cf / cpl : 0;
-        if ((lpp == 8 || lpp == 16 || lpp == 32 || lpp == 64) && ((uintptr_t)feat & 15) == 0) {
-            int vlocal = (int)((128 * 1024) / ((size_t)Cf * 4 + 4));      // ids held in the LDS table (<= 128 KB)
-            if (vlocal > 256) vlocal = 256;
-            const size_t lds = (size_t)vlocal * ((size_t)Cf * 4 + 4);
-            // pixels per workgroup: aim at three full rounds of one workgroup per CU (measured at 8 x 440 x 640: 2048 px ->
-            // 0.436 ms, 3072 px -> 0.382 / 0.399 ms bf16 / fp32 = 38 % / 73 % of 8 TB/s)
-            int ppw = 0;
-            {
-                long long chunks = (3 * 256 + B / 2) / B;
-                if (chunks < 1) chunks = 1;
-                long long q = (pixels_per_sample + chunks - 1) / chunks;
-                q = (q + 63) / 64 * 64;
-                if (q < 512) q = 512;
-                if (q > 16384) q = 16384;
-                ppw = (int)q;
-            }
-            const int64_t vchunks = (pixels_per_sample + ppw - 1) / ppw;
-            const dim3 vgrid((unsigned)(B * vchunks));
-#define OESS_SEGV(BF, L)                                                                                                     \
-            {                                                                                                                \
-                (void)hipFuncSetAttribute((const void*)&segmean_fwd_vec_kernel<BF, L>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                hipLaunchKernelGGL((segmean_fwd_vec_kernel<BF, L>), vgrid, dim3(SEGV_THREADS), lds, st, feat, ids, P, pixels_per_sample, \
-                                   superpixel_size, S, vlocal, k, count, ppw);                                              \
-            }
-            if (is_bf16) { if (lpp == 8) OESS_SEGV(true, 8) else if (lpp == 16) OESS_SEGV(true, 16) else if (lpp == 32) OESS_SEGV(true, 32) else OESS_SEGV(true, 64) }
-            else { if (lpp == 8) OESS_SEGV(false, 8) else if (lpp == 16) OESS_SEGV(false, 16) else if (lpp == 32) OESS_SEGV(false, 32) else OESS_SEGV(false, 64) }
-#undef OESS_SEGV
-            hipLaunchKernelGGL(segmean_finalize_kernel, dim3(stream_grid((int64_t)S * Cf, THREADS)), dim3(THREADS), 0, st, k, count, S, Cf);
-            OESS_HIP(hipGetLastError());
-            return OESS_OK;
-        }
+    SegGeom g;
+    g.P = P; g.pps = pixels_per_sample; g.sps = superpixel_size; g.Cf = Cf; g.S = S;
+    g.nslice = (Cf + SEGF_CH - 1) / SEGF_CH;
+    {   // pixels per workgroup: aim at three full rounds of one workgroup per CU over all (chunk, slice) pairs
+        long long chunks = (3LL * num_cus() / g.nslice + B / 2) / B;
+        if (chunks < 1) chunks = 1;
+        long long q = (pixels_per_sample + chunks - 1) / chunks;
+        q = (q + 63) / 64 * 64;
+        if (q < 512) q = 512;
+        if (q > SEGF_MAX_PPW) q = SEGF_MAX_PPW;
+        g.pix_per_wg = (int)q;
     }
-    const int64_t chunks = (pixels_per_sample + SEG_PIX_PER_WG - 1) / SEG_PIX_PER_WG;
-    dim3 grid((unsigned)(B * chunks), (unsigned)((Cf + SEG_CH - 1) / SEG_CH));
-    if (is_bf16)
-        hipLaunchKernelGGL(segmean_fwd_kernel<true>, grid, dim3(THREADS), 0, st, feat, ids, P, pixels_per_sample,
-                           superpixel_size, Cf, S, k, count);
-    else
-        hipLaunchKernelGGL(segmean_fwd_kernel<false>, grid, dim3(THREADS), 0, st, feat, ids, P, pixels_per_sample,
-                           superpixel_size, Cf, S, k, count);
-    hipLaunchKernelGGL(segmean_finalize_kernel, dim3(stream_grid((int64_t)S * Cf, THREADS)), dim3(THREADS), 0, st, k,
-                       count, S, Cf);
+    const int64_t vchunks = (pixels_per_sample + g.pix_per_wg - 1) / g.pix_per_wg;
+    const int64_t nwg = B * vchunks * g.nslice;
+    if (nwg > 0x7fffffffLL) return OESS_EINVAL;
+    const dim3 grid((unsigned)nwg);
+    const int cpl = is_bf16 ? 8 : 4;
+    const bool vec = (Cf % cpl == 0) && ((uintptr_t)feat & 15) == 0;
+#define OESS_SEGF(KERNEL)                                                                                                   \
+    {                                                                                                                       \
+        (void)hipFuncSetAttribute((const void*)&KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SEGF_LDS);       \
+        hipLaunchKernelGGL(KERNEL, grid, dim3(SEGF_THREADS), SEGF_LDS, st, feat, ids, g, acc_lo, acc_hi, gcnt, err);       \
+    }
+    if (vec) { if (is_bf16) OESS_SEGF(segmean_fwd_fx_kernel<true>) else OESS_SEGF(segmean_fwd_fx_kernel<false>) }
+    else { if (is_bf16) OESS_SEGF(segmean_fwd_fx_scalar_kernel<true>) else OESS_SEGF(segmean_fwd_fx_scalar_kernel<false>) }
+#undef OESS_SEGF
+    hipLaunchKernelGGL(segmean_fx_finalize_kernel, dim3(stream_grid((int64_t)S * Cf, THREADS)), dim3(THREADS), 0, st, acc_lo, acc_hi,
+                       gcnt, err, k, count, S, Cf);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }

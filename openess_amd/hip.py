@@ -205,7 +205,7 @@ def masked_normalize(x, out=None):
         raise ValueError("masked_normalize needs a contiguous float32 tensor")
     if out is None:
         out = torch.empty_like(x)
-    stats = torch.empty(4, dtype=torch.float64, device=x.device)
+    stats = torch.empty(lib.oess_masked_stats_doubles(1), dtype=torch.float64, device=x.device)
     _lib.check(lib.oess_masked_normalize_f32(_ptr(x), _ptr(out), x.numel(), _ptr(stats), _stream()),
                "oess_masked_normalize_f32")
     return out
@@ -220,7 +220,7 @@ def masked_normalize_slice(x, c0, cs, out=None):
     B, Ct, H, W = x.shape
     if out is None:
         out = torch.empty((B, cs, H, W), dtype=torch.float32, device=x.device)
-    stats = torch.empty(4, dtype=torch.float64, device=x.device)
+    stats = torch.empty(lib.oess_masked_stats_doubles(1), dtype=torch.float64, device=x.device)
     _lib.check(lib.oess_masked_normalize_slice_f32(_ptr(x), _ptr(out), B, Ct, c0, cs, H * W, _ptr(stats), _stream()),
                "oess_masked_normalize_slice_f32")
     return out
@@ -235,8 +235,10 @@ class _SegmentMean(torch.autograd.Function):
         k = torch.empty((S, Cf), dtype=torch.float32, device=feat_pm.device)
         cnt = torch.empty((S,), dtype=torch.float32, device=feat_pm.device)
         is_bf16 = int(feat_pm.dtype == torch.bfloat16)
+        ws_bytes = lib.oess_segment_mean_fwd_workspace_bytes(S, Cf)           # 96-bit fixed-point accumulators (deterministic sums)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=feat_pm.device)
         _lib.check(lib.oess_segment_mean_fwd(_ptr(feat_pm), is_bf16, _ptr(ids), P, pps, sps, Cf, S, _ptr(k), _ptr(cnt),
-                                             _stream()), "oess_segment_mean_fwd")
+                                             _ptr(ws), ws_bytes, _stream()), "oess_segment_mean_fwd")
         ctx.save_for_backward(ids, cnt)
         ctx.meta = (P, Cf, pps, sps, S, feat_pm.dtype)
         return k
@@ -588,7 +590,7 @@ def e2vid_events_head_enc0(events, c0, cs, normalize, head_packed, head_bias, he
     if normalize and Ct > cs and Ct % cs == 0 and c0 % cs == 0:
         stats = masked_stats_slices(events, cs, refresh=(c0 == 0))[c0 // cs]
     elif normalize:
-        stats = torch.empty(4, dtype=torch.float64, device=events.device)
+        stats = torch.empty(lib.oess_masked_stats_doubles(1), dtype=torch.float64, device=events.device)
         _lib.check(lib.oess_masked_stats_slice_f32(_ptr(events), B, Ct, c0, cs, H * W, _ptr(stats), _stream()),
                    "oess_masked_stats_slice_f32")
     _lib.check(lib.oess_e2vid_events_head_enc0_bf16(_ptr(events), B, Ct, c0, cs, H, W, _ptr(stats), int(bool(normalize)),
@@ -720,9 +722,10 @@ def masked_stats_slices(events, cs, refresh=False):
     if hit is not None and hit[0] == tag and not refresh:
         return hit[1]
     n = Ct // cs
-    stats = torch.empty((n, 4), dtype=torch.float64, device=events.device)
-    _lib.check(lib.oess_masked_stats_slices_f32(_ptr(events), B, Ct, cs, n, H * W, _ptr(stats), _stream()),
+    buf = torch.empty(lib.oess_masked_stats_doubles(n), dtype=torch.float64, device=events.device)   # totals + partial rows
+    _lib.check(lib.oess_masked_stats_slices_f32(_ptr(events), B, Ct, cs, n, H * W, _ptr(buf), _stream()),
                "oess_masked_stats_slices_f32")
+    stats = buf[:4 * n].view(n, 4)
     _SLICE_STATS[key] = (tag, stats)
     return stats
 
@@ -743,7 +746,7 @@ def event_slice_to_nhwc8(events, c0, cs, normalize=True, out=None):
     if normalize and Ct > cs and Ct % cs == 0 and c0 % cs == 0:
         stats = masked_stats_slices(events, cs, refresh=(c0 == 0))[c0 // cs]
     elif normalize:
-        stats = torch.empty(4, dtype=torch.float64, device=events.device)
+        stats = torch.empty(lib.oess_masked_stats_doubles(1), dtype=torch.float64, device=events.device)
         _lib.check(lib.oess_masked_stats_slice_f32(_ptr(events), B, Ct, c0, cs, H * W, _ptr(stats), _stream()),
                    "oess_masked_stats_slice_f32")
     _lib.check(lib.oess_event_slice_to_nhwc8_bf16(_ptr(events), B, Ct, c0, cs, H * W, _ptr(stats), int(normalize),

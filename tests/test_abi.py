@@ -29,7 +29,9 @@ def test_binding_matches_header():
     from openess_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.load()
-    assert lib.oess_abi_version() >= 1
+    header = open(os.path.join(ROOT, "include", "oess.h")).read()
+    declared_version = int(re.search(r"#define\s+OESS_ABI_VERSION\s+(\d+)", header).group(1))
+    assert lib.oess_abi_version() == declared_version == _lib.ABI_VERSION
     assert b"gfx950" in lib.oess_build_info()
     assert lib.oess_strerror(-22) == b"invalid argument"
 
@@ -62,6 +64,32 @@ def test_round3_entry_points_validate_arguments_on_the_host():
                                                     None, 0, 1, 8960, None, 256, None) == -22
     assert lib.oess_norm_stats_finalize_nhwc_bf16(None, 64, 1, 100, 64, 1e-5, None, None, None, None, 0.1, None, None, None, None,
                                                   None, 0, None) == -22
+
+
+def test_stale_library_is_refused(tmp_path, monkeypatch):
+    """A library built for another ABI version must not load (the version, not a missing symbol, is the check)."""
+    import subprocess
+    from openess_amd import _lib
+    src = tmp_path / "fake.c"
+    lines = ["int oess_abi_version(void) { return %d; }" % (_lib.ABI_VERSION - 1)]
+    for name in _lib.SIGNATURES:
+        if name != "oess_abi_version":
+            lines.append(f"void* {name}(void) {{ return 0; }}")
+    src.write_text("\n".join(lines))
+    so = tmp_path / "libfake.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)])
+    monkeypatch.setattr(_lib, "LIB_PATH", str(so))
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.LibraryMissing, match="C-ABI version"):
+        _lib.load()
+
+
+def test_round4_entry_points_validate_arguments_on_the_host():
+    from openess_amd import _lib
+    lib = _lib.load()
+    assert lib.oess_segment_mean_fwd_workspace_bytes(800, 256) >= 800 * 256 * 16 + 800 * 4 + 4
+    assert lib.oess_segment_mean_fwd_workspace_bytes(0, 256) == 0
+    assert lib.oess_segment_mean_fwd(None, 0, None, 100, 100, 100, 256, 100, None, None, None, 0, None) == -22
 
 
 def test_collate_keeps_undecoded_png_maps_as_one_byte_stream():

@@ -85,11 +85,11 @@ def test_reduce_finalize_tile_stats_matches_double_sum_and_repeats():
         np.testing.assert_allclose(outs[0][2].cpu().numpy(), 0.9 + 0.1 * var * count / (count - 1), rtol=1e-6)
 
 
-@pytest.mark.parametrize("option,contr", [("frame2voxel", False), ("frame2recon", False)])
+@pytest.mark.parametrize("option,contr", [("frame2voxel", False), ("frame2recon", False), ("frame2voxel", True), ("frame2recon", True)])
 def test_pretrain_step_bit_repeatable(option, contr):
-    """The same two optimisation steps from the same weights, twice: identical losses, gradients and weights.  (The
-    contrastive configurations add the superpixel scatter-mean, whose cross-workgroup sums are fp32 atomics: those are
-    compared to 1e-5 in test_pretrain_step_contrastive_repeats_within_rounding.)"""
+    """The same two optimisation steps from the same weights, twice: identical losses, gradients and weights -- also for the
+    contrastive configurations (the superpixel scatter-mean sums in 64-bit fixed point since round 4; EventPreprocessor's
+    statistics are fixed-order partial rows)."""
     from openess_amd.training.pretrain_step import PretrainStep
     from tests.synth import damp_residual, fill_by_name
     B, H, W, nwin = 2, 64, 96, 3

@@ -133,6 +133,51 @@ def test_superpixel_pool_random_ids(C, dt):
     np.testing.assert_allclose(f.grad.float().cpu().numpy(), fr.grad.numpy(), rtol=tol, atol=tol * 1e-2)
 
 
+@pytest.mark.parametrize("C,dt", [(256, torch.bfloat16), (256, torch.float32), (40, torch.float32), (96, torch.bfloat16)])
+def test_superpixel_pool_bit_repeatable_and_exact(C, dt):
+    """K7 forward meets its partial sums as 64-bit fixed-point integers: (a) five calls on the same input give identical bits
+    (random ids <= 300: LDS-table path, direct-global path and cross-sample collisions all active), interleaved with other work
+    that perturbs the workgroup schedule; (b) features that are multiples of 2^-8 have exactly representable sums, so the
+    result equals the float64 quotient rounded to fp32 by the same two roundings -- bit for bit."""
+    from openess_amd import hip
+    torch.manual_seed(C)
+    B, H, W, sps = 4, 120, 160, 100
+    q = (torch.randint(-1024, 1024, (B, C, H, W)).float() / 256.0).to(dt).float()   # |x| <= 4, multiples of 2^-8 (also after bf16 rounding)
+    ids = torch.randint(0, 300, (B, H // 4, W // 4)).repeat_interleave(4, 1).repeat_interleave(4, 2)
+    ids[1] = torch.randint(0, 256, (H, W))                                    # one sample without any spatial coherence
+    f = q.to(dt).cuda().contiguous(memory_format=torch.channels_last)
+    idc = ids.cuda()
+    outs = []
+    for rep in range(5):
+        outs.append(hip.superpixel_pool(f, idc, sps).clone())
+        torch.randn(1 << (18 + rep), device="cuda").sum()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    gid = (ids + torch.arange(B)[:, None, None] * sps).reshape(-1)
+    S = int(gid.max()) + 1
+    assert outs[0].shape == (S, C)
+    pm = q.permute(0, 2, 3, 1).reshape(-1, C).double()
+    sums = torch.zeros(S, C, dtype=torch.float64).index_add_(0, gid, pm)
+    cnt = torch.zeros(S, dtype=torch.float64).index_add_(0, gid, torch.ones_like(gid, dtype=torch.float64))
+    ref = sums.float() / (cnt.float() + 1e-6)[:, None]                        # exact sums -> one rounding; fp32 add of 1e-6; fp32 divide
+    assert torch.equal(outs[0].cpu(), ref)
+
+
+def test_superpixel_pool_out_of_range_input_is_loud():
+    """Range contract of the fixed-point sums: a non-finite feature or |x| >= 32768 turns the whole output into NaN."""
+    from openess_amd import hip
+    f = torch.randn(1, 64, 16, 16, device="cuda").contiguous(memory_format=torch.channels_last)
+    ids = torch.zeros(1, 16, 16, dtype=torch.int64, device="cuda")
+    assert torch.isfinite(hip.superpixel_pool(f, ids, 100)).all()
+    for bad in (float("inf"), float("nan"), 4.0e4):
+        g = f.clone()
+        g[0, 3, 5, 7] = bad
+        assert torch.isnan(hip.superpixel_pool(g, ids, 100)).all()
+    g = f.clone()
+    g[0, 3, 5, 7] = 32000.0
+    assert torch.isfinite(hip.superpixel_pool(g, ids, 100)).all()
+
+
 def test_confusion_matrix(golden_losses):
     from openess_amd import hip
     g = golden_losses

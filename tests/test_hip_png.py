@@ -57,3 +57,66 @@ def test_png_decode_flags_bad_files():
     for i in (1, 2, 3, 4):
         assert (got[i] == 255).all()
     assert st[5] != 0 or not np.array_equal(got[5], img)                                # a flipped stream bit never passes silently
+
+
+def _rewrap_with_zlib_stream(good, stream):
+    """The file `good` with its IDAT payload replaced by `stream`: a VALID chunk container (lengths and CRCs right) around it."""
+    import struct
+    pos, head, tail = 8, good[:8], b""
+    out = [head]
+    done = False
+    while pos < len(good):
+        n, typ = struct.unpack(">I4s", good[pos:pos + 8])
+        if typ == b"IDAT":
+            if not done:
+                out.append(op._chunk(b"IDAT", stream))
+                done = True
+        else:
+            out.append(good[pos:pos + 12 + n])
+        pos += 12 + n
+    return b"".join(out)
+
+
+def _idat_stream(good):
+    import struct
+    pos, parts = 8, []
+    while pos < len(good):
+        n, typ = struct.unpack(">I4s", good[pos:pos + 8])
+        if typ == b"IDAT":
+            parts.append(good[pos + 8:pos + 8 + n])
+        pos += 12 + n
+    return b"".join(parts)
+
+
+@pytest.mark.timeout(120)
+def test_png_truncated_zlib_stream_in_valid_container_terminates_and_is_flagged():
+    """A short or bit-flipped zlib stream inside an intact IDAT/IEND container: the reader feeds zeros past the end, and for label
+    maps the all-zero code of the dynamic table is the most frequent literal, so a decoder without an in-loop bound spins forever.
+    Every such file must come back flagged (status 7 overrun / 8 size / a code error), filled with the ignore index, and the
+    call must return."""
+    H, W = 64, 96
+    rng = np.random.default_rng(11)
+    m = png_cases.maps(rng, H, W)
+    files, names = [], []
+    for name in ("labels", "blocks", "noise"):
+        for kw in ({}, {"strategy": __import__("zlib").Z_FIXED}, {"level": 0}):
+            good = op.encode_gray8(m[name], filters=0, **kw)
+            z = _idat_stream(good)
+            for cut in (len(z) // 4, len(z) // 2, len(z) - 12, len(z) - 5):
+                if cut > 8:
+                    files.append(_rewrap_with_zlib_stream(good, z[:cut]))
+                    names.append((name, tuple(kw), cut))
+    # a constant map: one literal + one long run per row, the all-zero code is that literal
+    const = np.full((H, W), 3, np.uint8)
+    good = op.encode_gray8(const, filters=0)
+    z = _idat_stream(good)
+    for cut in range(6, len(z) - 4, max(1, len(z) // 12)):
+        files.append(_rewrap_with_zlib_stream(good, z[:cut]))
+        names.append(("const", (), cut))
+    files.append(good)
+    names.append(("const_good", (), len(z)))
+    got, st = _decode(files, H, W)
+    assert st[-1] == 0 and np.array_equal(got[-1], const)
+    for i in range(len(files) - 1):
+        assert st[i] in (5, 6, 7, 8), (names[i], st[i])
+        assert (got[i] == 255).all(), names[i]
