@@ -134,5 +134,61 @@ class OracleSupervisedStep:
         return {key: loss.detach()}, loss.detach()
 
 
+class OracleOpenESSStep:
+    """OpenESSModel's runnable branch, `frame2recon` (training/openess_trainer.py:478-529; train_step :326-355): two DeepLabv3
+    students (frame and reconstruction), T2E pseudo-label TaskLoss on each (:487-495), L1 feature consistency (:497), cosine
+    logit consistency (:501), and -- under if_spatial_contrastive -- the superpixel InfoNCE with the pooling offset HARD-CODED to
+    30 whatever `superpixel_size` the YAML holds (:506-509; k pools feat_recon, q pools feat_frame :521-527).  Two AdamW
+    optimisers, `optimizer_recon` and `optimizer_frame`, zeroed together and stepped in that order (:337-353)."""
+    POOL_OFFSET = 30
+
+    def __init__(self, num_classes=11, if_spatial_contrastive=True, lr_recon=5e-4, lr_frame=5e-4, output_stride=32,
+                 weight_task_loss=1.0):
+        self.K, self.contr, self.w = num_classes, if_spatial_contrastive, weight_task_loss
+        self.model_recon = on.DeepLabV3(num_classes, output_stride)
+        self.model_frame = on.DeepLabV3(num_classes, output_stride)
+        self.opt_recon = torch.optim.AdamW([p for p in self.model_recon.parameters() if p.requires_grad], lr=lr_recon)
+        self.opt_frame = torch.optim.AdamW([p for p in self.model_frame.parameters() if p.requires_grad], lr=lr_frame)
+
+    def modules(self):
+        return {'model_recon': self.model_recon, 'model_frame': self.model_frame}
+
+    def loss(self, batch):
+        frame, recon, pl = batch[0], batch[2], batch[3]
+        self.model_frame.train()
+        self.model_recon.train()
+        losses, t_loss = {}, 0.
+        logits_frame, feat_frame = self.model_frame(frame)
+        l = ol.task_loss(logits_frame, pl, self.K) * self.w
+        losses['semseg_frame_loss'] = l.detach()
+        t_loss = t_loss + l
+        logits_recon, feat_recon = self.model_recon(recon)
+        l = ol.task_loss(logits_recon, pl, self.K) * self.w
+        losses['semseg_recon_loss'] = l.detach()
+        t_loss = t_loss + l
+        l = torch.nn.functional.l1_loss(feat_frame, feat_recon)
+        losses['cons_feat_loss'] = l.detach()
+        t_loss = t_loss + l
+        l = torch.mean(1 - torch.nn.functional.cosine_similarity(logits_frame, logits_recon, dim=1))
+        losses['cons_pred_loss'] = l.detach()
+        t_loss = t_loss + l
+        if self.contr:
+            k = ol.superpixel_pool(feat_recon, batch[4], self.POOL_OFFSET)
+            q = ol.superpixel_pool(feat_frame, batch[4], self.POOL_OFFSET)
+            l = ol.nce_loss(k, q)
+            losses['contrastive_nce_loss'] = l.detach()
+            t_loss = t_loss + l
+        return t_loss, losses
+
+    def train_step(self, batch):
+        self.opt_recon.zero_grad()
+        self.opt_frame.zero_grad()
+        t_loss, losses = self.loss(batch)
+        t_loss.backward()
+        self.opt_recon.step()
+        self.opt_frame.step()
+        return losses, t_loss.detach()
+
+
 def voxelize_sample(x, y, t, p, rectify_map, nwin, C, H, W, crop):
     return torch.from_numpy(oe.dsec_event_tensor(x, y, t, p, rectify_map, nwin, C, H, W, crop))

@@ -13,7 +13,8 @@ def main():
     args = parser.parse_args()
     seed_everything()
     settings = Settings(args.settings_file, generate_log=True)
-    from openess_amd.training.finetune_trainer import OpenESSFineTuneModel, OpenESSLinearProbeModel
+    from openess_amd.training.finetune_trainer import OpenESSFineTuneModel
+    from openess_amd.training.linear_probe_trainer import OpenESSLinearProbeModel
     trainer = OpenESSLinearProbeModel(settings) if settings.if_linear_probing else OpenESSFineTuneModel(settings)
     metrics = trainer.valEpochs()
     print({k: float(v) for k, v in metrics.items() if k != 'cm'})

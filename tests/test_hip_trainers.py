@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle.step import E2VID_LIGHTWEIGHT_CONFIG, OracleStep, OracleSupervisedStep
+from oracle.step import E2VID_LIGHTWEIGHT_CONFIG, OracleOpenESSStep, OracleStep, OracleSupervisedStep
 from tests.synth import damp_residual, fill_by_name
 
 pytestmark = pytest.mark.gpu
@@ -68,6 +68,63 @@ def test_supervised_step_matches_oracle(option, linear_probing, tmp_path):
         assert d.max() <= 4.5 * lr and np.median(d) <= 0.5 * lr
         assert all(not p.requires_grad for n, p in net.named_parameters()
                    if not n.startswith(('linear_probe', 'decoder_scale_5')))
+
+
+@pytest.mark.parametrize("contr", [True, False])
+def test_openess_model_step_matches_oracle(contr, tmp_path):
+    """OpenESSModel.train_step (train.py's default branch, BASELINE configs[2] "openess_trainer full path",
+    training/openess_trainer.py:326-355,478-529) against OracleOpenESSStep from identical weights over two optimiser steps: the
+    five loss keys, both optimisers' parameter sets, and the pooling offset hard-coded to 30 (ids up to 44 > 30 collide across
+    samples exactly as in the reference; the YAML's superpixel_size = 25 must be ignored)."""
+    import train
+    from openess_amd.config.settings import Settings
+    train.seed_everything()
+    s = Settings(os.path.join(CFG, "openess_dsec_synthetic.yaml"), generate_log=False)
+    s.ckpt_dir = str(tmp_path)
+    s.if_spatial_contrastive = contr
+    assert s.superpixel_size == 25
+    trainer, loop = train.build_trainer(s)
+    assert type(trainer).__name__ == 'OpenESSModel' and loop == 'training'
+    K, (H, W) = s.semseg_num_classes, s.img_size_b
+    ref = OracleOpenESSStep(K, contr, lr_recon=s.lr_recon, lr_frame=s.lr_frame, weight_task_loss=s.weight_task_loss)
+    assert sorted(trainer.optimizers_dict) == ['optimizer_frame', 'optimizer_recon']
+    for name in ('model_recon', 'model_frame'):
+        m = trainer.models_dict[name]
+        fill_by_name(m, 500 + len(name) + (7 if name == 'model_frame' else 0))
+        fill_by_name(ref.modules()[name], 500 + len(name) + (7 if name == 'model_frame' else 0), sorted(m.state_dict().keys()))
+        damp_residual(m), damp_residual(ref.modules()[name])
+        m.classifier.ASPP.project[3].p = 0.0                      # dropout off on both sides (different RNG streams)
+        ref.modules()[name].classifier.ASPP.project[3].p = 0.0
+    for opt_name, ref_opt in (('optimizer_recon', ref.opt_recon), ('optimizer_frame', ref.opt_frame)):
+        mine = [p for grp in trainer.optimizers_dict[opt_name].param_groups for p in grp['params']]
+        theirs = [p for grp in ref_opt.param_groups for p in grp['params']]
+        assert [tuple(p.shape) for p in mine] == [tuple(p.shape) for p in theirs], opt_name
+    torch.manual_seed(8)
+    B = 2
+    frame, recon = torch.rand(B, 3, H, W), torch.rand(B, 3, H, W)
+    pl = torch.randint(0, K, (B, H // 4, W // 4)).repeat_interleave(4, 1).repeat_interleave(4, 2)
+    pl[1, -6:] = 255
+    sp = torch.randint(0, 45, (B, H // 8, W // 8)).repeat_interleave(8, 1).repeat_interleave(8, 2)
+    assert int(sp[0].max()) >= 30                                  # sample 0's ids reach into sample 1's range [30, 60)
+    keys = {'semseg_frame_loss', 'semseg_recon_loss', 'cons_feat_loss', 'cons_pred_loss'} | ({'contrastive_nce_loss'} if contr else set())
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    for it in range(2):
+        losses, _, total = trainer.train_step((frame.cuda(), None, recon.cuda(), pl.cuda(), sp.cuda(), None))
+        lref, tref = ref.train_step((frame, None, recon, pl, sp))
+        assert set(losses) == keys == set(lref)
+        for k in sorted(keys):
+            tol = {'contrastive_nce_loss': 5e-2, 'cons_feat_loss': 3e-2, 'cons_pred_loss': 5e-2}.get(k, 2e-2)
+            assert float(losses[k]) == pytest.approx(float(lref[k]), rel=tol, abs=2e-3), (it, k, float(losses[k]), float(lref[k]))
+        assert float(total) == pytest.approx(float(tref), rel=3e-2)
+    # both students moved, and in the oracle's direction: parameter-wise cosine of the two-step update of the trained 1x1 head
+    for name in ('model_recon', 'model_frame'):
+        mine = dict(trainer.models_dict[name].named_parameters())
+        theirs = dict(ref.modules()[name].named_parameters())
+        w0 = None
+        for pn in ('classifier.ASPP.project.0.weight',):
+            a = mine[pn].detach().float().cpu().numpy().ravel()
+            b = theirs[pn].detach().numpy().ravel()
+            assert np.isfinite(a).all() and float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))) > 0.999, (name, pn)
 
 
 def test_ddd17_shaped_pretrain_step():

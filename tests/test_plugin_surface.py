@@ -46,6 +46,33 @@ def test_every_reference_yaml_loads_and_dispatches(monkeypatch):
     assert {'pre', 'ft'} <= kinds
 
 
+def test_reference_trainer_module_paths_exist():
+    """train.py:4-8 of the reference imports its five trainers from five modules; the import switch of INTEGRATION.md needs
+    every one of those module paths and class names here (import only: constructing a trainer needs the GPU)."""
+    import importlib
+    pairs = [("sup_only_trainer", "SupOnlyModel"), ("pretrain_trainer", "OpenESSPretrainModel"),
+             ("finetune_trainer", "OpenESSFineTuneModel"), ("linear_probe_trainer", "OpenESSLinearProbeModel"),
+             ("openess_trainer", "OpenESSModel")]
+    from openess_amd.training.base_trainer_ov import BaseTrainer
+    classes = []
+    for mod, cls in pairs:
+        m = importlib.import_module(f"openess_amd.training.{mod}")
+        c = getattr(m, cls)
+        assert issubclass(c, BaseTrainer) and c.__module__ == m.__name__, (mod, cls)       # defined there, not re-exported
+        classes.append(c)
+    assert len(set(classes)) == 5
+    # the three stage-2/3 trainers differ exactly where the reference's files differ (constructor flags, AMP branch)
+    from types import SimpleNamespace
+    s = SimpleNamespace(if_linear_probing=True, if_finetuning=True, frozen_backbone=True, use_amp=True)
+    mk = lambda c: c.__new__(c)
+    ft, lp, so = mk(classes[2]), mk(classes[3]), mk(classes[0])
+    for t in (ft, lp, so):
+        t.settings = s
+    assert ft.deeplab_kwargs() == {'if_finetuning': True, 'frozen_backbone': True} and ft.backend_kwargs() == {}
+    assert lp.deeplab_kwargs() == {'if_linear_probing': True} and lp.backend_kwargs() == {'if_linear_probing': True}
+    assert so.deeplab_kwargs() == {} and so.backend_kwargs() == {} and so.amp_requested() and not ft.amp_requested()
+
+
 def test_checkpoint_format_roundtrip(tmp_path):
     from openess_amd.utils.saver import CheckpointSaver
     models = {'back_end': torch.nn.Linear(3, 2), 'model_frame': torch.nn.Linear(2, 2), 'model_recon': torch.nn.Linear(4, 1)}

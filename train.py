@@ -25,7 +25,9 @@ def seed_everything(seed=SEED):
 
 
 def build_trainer(settings):
-    from openess_amd.training.finetune_trainer import OpenESSFineTuneModel, OpenESSLinearProbeModel, SupOnlyModel
+    from openess_amd.training.finetune_trainer import OpenESSFineTuneModel
+    from openess_amd.training.linear_probe_trainer import OpenESSLinearProbeModel
+    from openess_amd.training.sup_only_trainer import SupOnlyModel
     from openess_amd.training.openess_trainer import OpenESSModel
     from openess_amd.training.pretrain_trainer import OpenESSPretrainModel
     if settings.if_supervised_only:
