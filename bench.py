@@ -91,9 +91,37 @@ def _median_time(fn, warm=1, n=3):
     return float(np.median(ts)), ts
 
 
+def _host_cpu():
+    """(model string, physical cores, logical cpus) of this host from /proc/cpuinfo."""
+    model, phys, logical = "unknown", set(), 0
+    try:
+        pid = cid = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name" and model == "unknown":
+                    model = v
+                elif k == "processor":
+                    logical += 1
+                elif k == "physical id":
+                    pid = v
+                elif k == "core id":
+                    cid = v
+                elif not k and pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                    pid = cid = None
+        if pid is not None and cid is not None:
+            phys.add((pid, cid))
+    except OSError:
+        pass
+    return model, (len(phys) or (os.cpu_count() or 1)), (logical or (os.cpu_count() or 1))
+
+
 def cpu_baseline(sample_events, rectify_map):
     """The oracle (CPU port of the reference path, validated against the reference's golden vectors) on this host.
-    Every leg: 1 warm-up + 3 timed, median.  Legs: (i) voxelizer of ONE full-size event-frame -- the reference-faithful
+    SURVEY 8d: voxelizer legs 3 warm-up + 10 timed, the B=1 net step 1 warm-up + 5 timed, the DDD17 step 1 + 3; medians; CPU
+    model string, physical core count and the thread cap are stated in `sample`.  Legs: (i) voxelizer of ONE full-size event-frame -- the reference-faithful
     8-pass masked-scatter algorithm (oracle/events.py = representations.py:15-54, sequential and with the reference's 8
     threads, sequence_ov.py:304-305) and the scalar C port; (ii) fp32 PyTorch-CPU teacher forward + 20 recurrent E2VID
     encoder steps + SemSegE2VID forward/backward + AdamW at B=1 (configs[1] shape); (iii) the CPU-runnable configs[0]:
@@ -114,14 +142,14 @@ def cpu_baseline(sample_events, rectify_map):
     def chunk(i):
         s, e = i * n, (i + 1) * n
         return oe.voxelgrid_trilinear(xy[s:e, 0], xy[s:e, 1], p[s:e].astype(np.float32), oe.dsec_time_normalise(t[s:e]), C, H_SENSOR, W_SENSOR)
-    legs["voxelizer_8pass_numpy_1thread_s"], _ = _median_time(lambda: [chunk(i) for i in range(NWIN)], warm=1, n=3)
+    legs["voxelizer_8pass_numpy_1thread_s"], _ = _median_time(lambda: [chunk(i) for i in range(NWIN)], warm=3, n=10)
     with ThreadPoolExecutor(8) as pool:
-        legs["voxelizer_8pass_numpy_8threads_s"], _ = _median_time(lambda: list(pool.map(chunk, range(NWIN))), warm=1, n=3)
+        legs["voxelizer_8pass_numpy_8threads_s"], _ = _median_time(lambda: list(pool.map(chunk, range(NWIN))), warm=3, n=10)
     ev = None
     try:
         from oracle import cport
         fn = lambda: cport.dsec_event_tensor(x, y, t, p, rectify_map, NWIN, C, H_SENSOR, W_SENSOR, CROP)  # noqa: E731
-        legs["voxelizer_c_port_1thread_s"], _ = _median_time(fn, warm=1, n=3)
+        legs["voxelizer_c_port_1thread_s"], _ = _median_time(fn, warm=3, n=10)
         ev = torch.from_numpy(fn())[None]
     except Exception as e:
         legs["voxelizer_c_port_error"] = repr(e)
@@ -133,7 +161,7 @@ def cpu_baseline(sample_events, rectify_map):
     g = torch.Generator().manual_seed(5)
     frame = torch.rand(1, 3, H_NET, W_SENSOR, generator=g)
     pl = torch.randint(0, 11, (1, H_NET, W_SENSOR), generator=g)
-    t_net, all_net = _median_time(lambda: step.train_step((ev, None, frame, pl)), warm=1, n=3)
+    t_net, all_net = _median_time(lambda: step.train_step((ev, None, frame, pl)), warm=1, n=5)
     legs["net_step_B1_s"] = t_net
     # (iii) BASELINE configs[0]: DDD17-shaped CPU step (200x352, K=6, B=2, 20 sub-windows x 5 bins)
     try:
@@ -146,10 +174,13 @@ def cpu_baseline(sample_events, rectify_map):
     except Exception as e:
         legs["ddd17_config0_error"] = repr(e)
     total = t_vox + t_net
+    model, phys, logical = _host_cpu()
     return {"value": round(1.0 / total, 5), "unit": "event-frames/s", "cores": nthr, "kind": "port",
-            "sample": f"oracle on host CPU ({ncores} cores; {nthr} torch threads used), ONE full-size event-frame, 1 warm-up + 3 timed, "
-                      f"median: fastest CPU voxelizer {t_vox:.3f}s + fp32 teacher fwd / 20 E2VID steps / SemSegE2VID fwd+bwd+AdamW at "
-                      f"B=1 {t_net:.2f}s = {total:.2f}s",
+            "cpu_model": model, "physical_cores": phys, "logical_cpus": logical,
+            "sample": f"oracle on the host CPU ({model}: {phys} physical cores, {logical} logical; {nthr} torch threads used -- more "
+                      f"oversubscribe), ONE full-size event-frame (2 M events -> 100x440x640, B=1 step); voxelizer legs 3 warm-up + 10 "
+                      f"timed, net step 1 + 5, medians: fastest CPU voxelizer {t_vox:.3f}s + fp32 teacher fwd / 20 E2VID steps / "
+                      f"SemSegE2VID fwd+bwd+AdamW at B=1 {t_net:.2f}s = {total:.2f}s",
             "legs": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in legs.items()}}
 
 

@@ -229,10 +229,12 @@ size_t oess_conv2d_fwd_workspace_bytes(int B, int H, int W, int Cin, int Cout, i
  * result (BatchNorm batch statistics straight from the accumulators; bias-free, no activation/residual).
  * oess_norm_reduce_finalize_tile_stats turns them into mean / rstd / scale / shift. */
 
-/* Reduce + finalize (G = 1) in ONE launch, sums and E[x^2] - E[x]^2 in double, slices added in a FIXED order (bit-repeatable):
+/* Reduce + finalize (G = 1), sums and E[x^2] - E[x]^2 in double, slices added in a FIXED order (bit-repeatable):
  * the tile partials of a conv epilogue -> mean / rstd / scale / shift (+ BatchNorm running statistics;
- * models/image_model.py:113-114 leaves the frozen teacher in .train()).  `scratch`: caller-owned double[32 * 2 * C] (any
- * content), `counters`: caller-owned uint32[(C + 31) / 32], ZERO on entry and left zero on return (stream-ordered reuse). */
+ * models/image_model.py:113-114 leaves the frozen teacher in .train()).  One launch for <= 64 tiles, otherwise a slice-sum launch
+ * and a finalize launch (the kernel boundary is the synchronisation).  `scratch`: caller-owned double[32 * 2 * C] (any
+ * content), `counters`: caller-owned uint32[(C + 31) / 32], ZERO on entry and left zero on return (only touched by the opt-in
+ * one-launch ticket protocol, environment OESS_BN_ONE_LAUNCH=1, kept for A/B measurements). */
 int oess_norm_reduce_finalize_tile_stats(const float* tile_stats, int tiles, int C, double* scratch,
                                          unsigned int* counters, float count, float eps, const float* gamma, const float* beta,
                                          float* running_mean, float* running_var, float momentum, float* mean, float* rstd,

@@ -434,17 +434,21 @@ __global__ __launch_bounds__(THREADS) void bilinear_l2_vec_kernel(const uint16_t
     }
 }
 
-// Reduce + finalize the conv epilogue's per-tile partials [tiles][2][C] in ONE launch (the frozen teacher and the DeepLab forward
-// issue 53-59 of these per pass).  Block (channel group x, slice y) sums its slice of the tiles in DOUBLE; with one slice
-// (tiles <= 64) it finalizes directly.  With several slices it parks its pair of sums in scratch[y][2][C] with RETURNING
-// device-scope exchanges (performed at the coherence point once the value is back) and takes a ticket; the block with the
-// last ticket reads all slices back (agent-scope atomic loads) and adds them IN SLICE ORDER, so the statistics do not depend
-// on which block finished first (bit-repeatable; round 2 added the slices with double atomics in arrival order), then computes
-// mean / rstd / scale / shift / running statistics in double and leaves the ticket zero for the next call.
-// NO __threadfence(): an agent-scope release writes back the whole XCD L2, which right after a convolution holds megabytes of
-// dirty output -- measured 25-31 us per call for two versions that used one, against ~10 us for two separate kernels.
+// Reduce + finalize the conv epilogue's per-tile partials [tiles][2][C] (the frozen teacher and the DeepLab forward issue 53-59
+// of these per pass).  Block (channel group x, slice y) sums its slice of the tiles in DOUBLE; with one slice (tiles <= 64) it
+// finalizes directly.  With several slices there are two forms:
+//   MODE 1 + MODE 2 (default, two launches): the slice sums are parked in scratch[y][2][C] with plain stores; a second launch of
+//     one block per channel group adds them IN SLICE ORDER and computes mean / rstd / scale / shift / running statistics in double.
+//     The kernel boundary is the only synchronisation: nothing outside the HIP memory model.
+//   MODE 0 (opt-in, OESS_BN_ONE_LAUNCH=1, kept for A/B): one launch; slice sums parked with RETURNING device-scope exchanges,
+//     a ticket per channel group, the last-ticket block reads the slices back with agent-scope atomic loads and adds them in
+//     slice order.  It passes its stress test but relies on the hardware performing relaxed atomics in program order once their
+//     results are back -- not a guarantee of the memory model (no release / acquire: an agent-scope release writes back the
+//     whole XCD L2, which right after a convolution holds megabytes of dirty output: 25-31 us per call measured).
+// Both are bit-repeatable and give identical bits (same partial sums, same order).
+template <int MODE>
 __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ part, int tiles, int C, double* __restrict__ scratch,
-                                                              unsigned int* __restrict__ counter, float count, float eps,
+                                                              unsigned int* __restrict__ counter, int nslices, float count, float eps,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
                                                               float momentum, float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -454,18 +458,42 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
     const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int t = blockIdx.y * 8 + tl; t < tiles; t += gridDim.y * 8) {
-            s1 += (double)part[((size_t)t * 2) * C + c];
-            s2 += (double)part[((size_t)t * 2 + 1) * C + c];
-        }
-    red[tl][cl][0] = s1; red[tl][cl][1] = s2;
-    __syncthreads();
-    if (tl == 0 && c < C) {
+    if (MODE != 2) {
+        if (c < C)
+            for (int t = blockIdx.y * 8 + tl; t < tiles; t += gridDim.y * 8) {
+                s1 += (double)part[((size_t)t * 2) * C + c];
+                s2 += (double)part[((size_t)t * 2 + 1) * C + c];
+            }
+        red[tl][cl][0] = s1; red[tl][cl][1] = s2;
+        __syncthreads();
+        if (tl == 0 && c < C) {
 #pragma unroll
-        for (int k = 1; k < 8; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }
+            for (int k = 1; k < 8; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }
+        }
     }
-    if (gridDim.y > 1) {
+    if (MODE == 1) {                                             // slice sums out; the next launch adds them
+        if (tl == 0 && c < C) {
+            scratch[((size_t)blockIdx.y * 2) * C + c] = s1;
+            scratch[((size_t)blockIdx.y * 2 + 1) * C + c] = s2;
+        }
+        return;
+    }
+    if (MODE == 2) {                                             // all 256 threads fetch (slice tl, tl+8, ...), then a fixed-order sum
+        double p1 = 0.0, p2 = 0.0;
+        if (c < C)
+            for (int y = tl; y < nslices; y += 8) {
+                p1 += scratch[((size_t)y * 2) * C + c];
+                p2 += scratch[((size_t)y * 2 + 1) * C + c];
+            }
+        red[tl][cl][0] = p1; red[tl][cl][1] = p2;
+        __syncthreads();
+        if (tl == 0 && c < C) {
+            s1 = p1; s2 = p2;
+#pragma unroll
+            for (int k = 1; k < 8; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }
+        }
+    }
+    if (MODE == 0 && gridDim.y > 1) {
         if (tl == 0 && c < C) {
             unsigned long long* slot = reinterpret_cast<unsigned long long*>(scratch) + ((size_t)blockIdx.y * 2) * C + c;
             const unsigned long long r1 = atomicExch(slot, (unsigned long long)__double_as_longlong(s1));
@@ -672,8 +700,18 @@ int oess_norm_reduce_finalize_tile_stats(const float* tile_stats, int tiles, int
     int gy = (tiles + 63) / 64;                    // >= 8 tiles per tile lane
     if (gy > 32) gy = 32;
     if (gy < 1) gy = 1;
-    hipLaunchKernelGGL(reduce_finalize_kernel, dim3((C + 31) / 32, gy), dim3(256), 0, (hipStream_t)stream, tile_stats, tiles, C, scratch,
-                       counters, count, eps, gamma, beta, running_mean, running_var, momentum, mean, rstd, scale, shift);
+    static const bool one_launch = [] { const char* e = getenv("OESS_BN_ONE_LAUNCH"); return e && e[0] == '1'; }();
+    const dim3 g1((C + 31) / 32, gy), g2((C + 31) / 32, 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (gy == 1 || one_launch) {
+        hipLaunchKernelGGL(reduce_finalize_kernel<0>, g1, dim3(256), 0, st, tile_stats, tiles, C, scratch, counters, gy, count, eps, gamma, beta,
+                           running_mean, running_var, momentum, mean, rstd, scale, shift);
+    } else {
+        hipLaunchKernelGGL(reduce_finalize_kernel<1>, g1, dim3(256), 0, st, tile_stats, tiles, C, scratch, counters, gy, count, eps, gamma, beta,
+                           running_mean, running_var, momentum, mean, rstd, scale, shift);
+        hipLaunchKernelGGL(reduce_finalize_kernel<2>, g2, dim3(256), 0, st, tile_stats, tiles, C, scratch, counters, gy, count, eps, gamma, beta,
+                           running_mean, running_var, momentum, mean, rstd, scale, shift);
+    }
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }

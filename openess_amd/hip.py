@@ -86,7 +86,7 @@ def voxelize_trilinear(x, y, p, t, seg_offsets, C, H, W, crop_rows=0, count_mode
     if out is None:
         out = torch.empty((n_seg * C, H - crop_rows, W), dtype=torch.float32, device=x.device)
     nbytes = lib.oess_voxelize_workspace_bytes(x.numel(), n_seg, max_len, C, H, W, crop_rows)
-    ws = _workspace(nbytes, x.device)
+    ws = _workspace(nbytes, x.device, tag=("vox", torch.cuda.current_stream(x.device).cuda_stream))
     _lib.check(lib.oess_voxelize_trilinear_f32(_ptr(x), _ptr(y), _ptr(p), _ptr(t), _ptr(dev), n_seg, max_len, C, H, W,
                                                crop_rows, int(count_mode), _ptr(out), _ptr(ws), ws.numel(), _stream()),
                "oess_voxelize_trilinear_f32")
@@ -114,7 +114,7 @@ def voxelize_dsec_raw(x, y, t_us, p, rectify_maps, seg_map, seg_offsets, C, H, W
     if out is None:
         out = torch.empty((n_seg * C, H - crop_rows, W), dtype=torch.float32, device=x.device)
     nbytes = lib.oess_voxelize_workspace_bytes(x.numel(), n_seg, max_len, C, H, W, crop_rows)
-    ws = _workspace(nbytes, x.device)
+    ws = _workspace(nbytes, x.device, tag=("vox", torch.cuda.current_stream(x.device).cuda_stream))
     _lib.check(lib.oess_voxelize_dsec_raw(_ptr(x), _ptr(y), _ptr(t_us), _ptr(p), _ptr(rectify_maps.contiguous()),
                                           _ptr(seg_map), rectify_maps.shape[0], _ptr(dev), n_seg, max_len, C, H, W,
                                           crop_rows, int(count_mode), _ptr(out), _ptr(ws), ws.numel(), _stream()),
@@ -138,7 +138,7 @@ def voxelize_nearest(events, seg_offsets, nbins, H, W, crop_rows=0, separate_pol
     if out is None:
         out = torch.empty((n_seg * ch, H - crop_rows, W), dtype=torch.float32, device=events.device)
     nbytes = lib.oess_voxelize_workspace_bytes(events.shape[0], n_seg, max_len, 2 * nbins, H, W, crop_rows)
-    ws = _workspace(nbytes, events.device)
+    ws = _workspace(nbytes, events.device, tag=("vox", torch.cuda.current_stream(events.device).cuda_stream))
     if events.dtype == torch.int64:
         fn, name = lib.oess_voxelize_nearest_i64, "oess_voxelize_nearest_i64"
     elif events.dtype == torch.float64:
@@ -588,7 +588,7 @@ def e2vid_events_head_enc0(events, c0, cs, normalize, head_packed, head_bias, he
         raise ValueError(f"bad output shape {tuple(out.shape)} != {(B, Ho, Wo, 64)}")
     stats = None
     if normalize and Ct > cs and Ct % cs == 0 and c0 % cs == 0:
-        stats = masked_stats_slices(events, cs, refresh=(c0 == 0))[c0 // cs]
+        stats = masked_stats_slices(events, cs, index=c0 // cs)
     elif normalize:
         stats = torch.empty(lib.oess_masked_stats_doubles(1), dtype=torch.float64, device=events.device)
         _lib.check(lib.oess_masked_stats_slice_f32(_ptr(events), B, Ct, c0, cs, H * W, _ptr(stats), _stream()),
@@ -710,24 +710,29 @@ def conv5x5s2_group(problems):
 _SLICE_STATS = {}
 
 
-def masked_stats_slices(events, cs, refresh=False):
+def masked_stats_slices(events, cs, index=None):
     """{sum, sumsq, nnz, -} of every cs-channel slice of a contiguous fp32 [B, Ctot, H, W] tensor in ONE launch -> float64
-    [Ctot // cs, 4].  Cached per (storage, version, shape); `refresh` recomputes (slice 0 of a sub-window loop always does, so
-    that a tensor rewritten through a raw pointer without a version bump cannot be served stale statistics)."""
+    [Ctot // cs, 4]; with `index` the row of that slice.
+    The table is cached ONLY for the access pattern it exists for -- a sub-window loop walking the slices of one tensor in order
+    (0, 1, 2, ...): a request is served from the cache iff the tensor's (pointer, version, shape) are unchanged AND `index` is
+    exactly the successor of the previous request.  Anything else -- slice 0 (a new loop: the voxelizer rewrites the same
+    allocation every batch with the same version), a loop entered in the middle, a repeated or skipped slice, `index=None` --
+    recomputes, so stale statistics of a previous batch cannot be served to a caller that does not start at slice 0."""
     lib = _lib.load()
     B, Ct, H, W = events.shape
     key = (events.device.index, torch.cuda.current_stream(events.device).cuda_stream)
     tag = (events.data_ptr(), events._version, tuple(events.shape), cs)
     hit = _SLICE_STATS.get(key)
-    if hit is not None and hit[0] == tag and not refresh:
-        return hit[1]
+    if hit is not None and hit[0] == tag and index is not None and index > 0 and index == hit[2]:
+        hit[2] = index + 1
+        return hit[1][index]
     n = Ct // cs
     buf = torch.empty(lib.oess_masked_stats_doubles(n), dtype=torch.float64, device=events.device)   # totals + partial rows
     _lib.check(lib.oess_masked_stats_slices_f32(_ptr(events), B, Ct, cs, n, H * W, _ptr(buf), _stream()),
                "oess_masked_stats_slices_f32")
     stats = buf[:4 * n].view(n, 4)
-    _SLICE_STATS[key] = (tag, stats)
-    return stats
+    _SLICE_STATS[key] = [tag, stats, (index + 1) if index is not None else -1]
+    return stats if index is None else stats[index]
 
 
 def event_slice_to_nhwc8(events, c0, cs, normalize=True, out=None):
@@ -744,7 +749,7 @@ def event_slice_to_nhwc8(events, c0, cs, normalize=True, out=None):
         out = torch.empty((B, H, W, 8), dtype=torch.bfloat16, device=events.device)
     stats = None
     if normalize and Ct > cs and Ct % cs == 0 and c0 % cs == 0:
-        stats = masked_stats_slices(events, cs, refresh=(c0 == 0))[c0 // cs]
+        stats = masked_stats_slices(events, cs, index=c0 // cs)
     elif normalize:
         stats = torch.empty(lib.oess_masked_stats_doubles(1), dtype=torch.float64, device=events.device)
         _lib.check(lib.oess_masked_stats_slice_f32(_ptr(events), B, Ct, c0, cs, H * W, _ptr(stats), _stream()),

@@ -134,6 +134,8 @@ class DeepLabHead(nn.Module):
 
 
 class deeplabv3_resnet50(nn.Module):
+    feats_fp32 = False
+
     def __init__(self, num_classes, text_embeddings_path, output_stride, pretrained_backbone, if_linear_probing=False,
                  if_finetuning=False, frozen_backbone=False):
         super().__init__()
@@ -168,7 +170,9 @@ class deeplabv3_resnet50(nn.Module):
             features = self.backbone(x)
             logist, feats = self.classifier(features)
         logist = hip.bilinear_resize(logist.float(), size=input_shape, align_corners=False)      # deeplabv3.py:183
-        feats = hip.bilinear_resize(feats, size=input_shape, align_corners=False)                # deeplabv3.py:184
+        # deeplabv3.py:184.  feats_fp32: the full-resolution 256-channel map leaves in fp32 (interpolated from the bf16 OS16 map
+        # without a second rounding): what the superpixel pooling / InfoNCE / L1 consistency losses consume
+        feats = hip.bilinear_resize(feats.float() if self.feats_fp32 else feats, size=input_shape, align_corners=False)
         if self.if_linear_probing:
             logist = self.linear_probe(logist)
         return logist, feats

@@ -29,6 +29,7 @@ class BaseTrainer(object):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.do_val_training_epoch = True
+        self._png_pending = []                   # (slot, status tensor, file names) of device-decoded PNG maps not yet checked
         # Precision contract (INTEGRATION.md "Precision"): the reference's `use_amp` switches torch.autocast(fp16) + GradScaler
         # (pretrain_trainer.py:344-353).  This build has ONE numeric mode whatever the flag says: bf16 storage of activations /
         # activation gradients / MFMA weight operands, fp32 accumulation, fp32 master weights, optimiser state and losses; no
@@ -86,6 +87,8 @@ class BaseTrainer(object):
             if i_batch % 20 == 0 and self.rank == 0:
                 self.log_train(i_batch, n, out[0])
             self.step_count += 1
+            self.check_png_status()
+        self.check_png_status(force=True)
 
     def device_batches(self, loader, split='train'):
         """Ingest pipeline (north_star: "straight from pinned host event buffers"): yields device batches whose host -> device
@@ -116,17 +119,46 @@ class BaseTrainer(object):
                 ready.record(side)
             return batch, ready
 
-        nxt = produce()
-        while nxt is not None:
-            batch, ready = nxt
-            main = torch.cuda.current_stream(self.device)
-            main.wait_event(ready)
-            for t in batch:
-                if torch.is_tensor(t) and t.is_cuda:
-                    t.record_stream(main)
-            yield batch                              # the caller enqueues step i here ...
-            nxt = produce()                          # ... and batch i+1 is copied + voxelized under it
-        torch.cuda.current_stream(self.device).wait_stream(side)
+        try:
+            nxt = produce()
+            while nxt is not None:
+                batch, ready = nxt
+                main = torch.cuda.current_stream(self.device)
+                main.wait_event(ready)
+                for t in batch:
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(main)
+                yield batch                              # the caller enqueues step i here ...
+                nxt = produce()                          # ... and batch i+1 is copied + voxelized under it
+        finally:
+            # also on an early `break` of the consumer (GeneratorExit) or an exception in its step: a prefetched batch's copies and
+            # voxelizer launches may still be in flight on the side stream, and the next user of the main stream must be ordered
+            # after them
+            torch.cuda.current_stream(self.device).wait_stream(side)
+
+    _PNG_STATUS_TEXT = {1: 'bad signature', 2: 'bad IHDR', 3: 'unsupported (not 8-bit gray / palette, or interlaced)', 4: 'bad zlib header',
+                        5: 'bad DEFLATE block', 6: 'bad Huffman code', 7: 'stream overrun', 8: 'size mismatch', 9: 'bad filter type'}
+
+    def check_png_status(self, force=False):
+        """device_png: a file the GPU decoder could not decode became an all-255 map (for a superpixel slot 255 is an ordinary id,
+        not an ignore value), so training on it must not pass silently.  Every decoded slot's status vector is queued by
+        prepare_batch; here they are reduced with ONE device sync per `settings.png_check_every` batches (default 50) and at epoch
+        end, and a bad file raises with its slot, path and reason."""
+        pend = self._png_pending
+        every = int(getattr(self.settings, 'png_check_every', 50))
+        if not pend or (not force and len(pend) < 3 * every):
+            return
+        self._png_pending = []
+        allst = torch.cat([st.reshape(-1) for _, st, _ in pend])
+        if not bool((allst != 0).any()):                           # the one sync
+            return
+        bad = []
+        for slot, st, paths in pend:
+            for j, code in enumerate(st.tolist()):
+                if code:
+                    bad.append(f"batch slot {slot}, sample {paths[j] if paths else j}: {self._PNG_STATUS_TEXT.get(code, code)}")
+        raise RuntimeError("device_png: undecodable label / pseudo-label / superpixel PNG(s) were replaced by all-255 maps:\n  "
+                           + "\n  ".join(bad[:20]) + "\nRe-encode them as 8-bit grayscale or turn device_png off.")
 
     def log_train(self, i_batch, n, losses):
         msg = 'epoch: [{0}][{1}/{2}], '.format(self.epoch_count, i_batch, n) + ', '.join(
@@ -190,7 +222,9 @@ class BaseTrainer(object):
                 maps, status = hip.png_decode_gray8_batch(hip.h2d_async(t['png_bytes'], self.device), t['png_lengths'],
                                                           t['hw'][0], t['hw'][1], t['flip'])
                 rest[i] = maps
-                self.png_status = status        # device tensor, non-zero = that map was filled with the ignore index (inspect off the hot path)
+                # per slot: device tensor, non-zero = that map was filled with the ignore index.  Kept (with the file names) for
+                # check_png_status(), which runs off the hot path -- one .any() sync per `png_check_every` batches and at epoch end
+                self._png_pending.append((i + 1, status, list(sample_batched[-1]) if isinstance(sample_batched[-1], (list, tuple)) else None))
         ds = self._voxel_ds[split]
         if isinstance(first, dict) and 'events_list' in first:            # DDD17: int64 [N,4] rows per sample
             first = ds.voxelize_batch(first['events_list'], self.device, flips=first.get('flip'))
@@ -227,6 +261,12 @@ class BaseTrainer(object):
             sps = getattr(s, 'superpixel_size', 100)          # host-side row count: no device sync in the step
             if torch.is_tensor(sample_batched[4]):
                 S = int((sample_batched[4] + torch.arange(sample_batched[4].shape[0])[:, None, None] * sps).max()) + 1
+            else:
+                # device_png: the ids only exist on the device.  The row count is data dependent (S = max id + 1 exactly as
+                # sparse_coo_tensor sizes it, pretrain_trainer.py:450-453), so one read-back is unavoidable -- it happens HERE, on
+                # the ingest stream under the previous step, instead of inside the step
+                off = torch.arange(0, sp.shape[0] * sps, sps, device=sp.device)[:, None, None]
+                S = int((sp + off).max().item()) + 1
         return (first, *rest, S)
 
     # ------------------------------------------------------------------ loops (base_trainer_ov.py:358-448)

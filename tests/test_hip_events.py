@@ -309,3 +309,13 @@ def test_masked_stats_slices_equal_per_slice_and_track_rewrites():
             sl = ev[:, i * cs:(i + 1) * cs].double()
             np.testing.assert_allclose(st[i, :3], [float(sl.sum()), float((sl * sl).sum()), float((sl != 0).sum())], rtol=1e-12)
         ev.view(-1)[::2].mul_(1.7)                                     # in-place rewrite between the two passes
+    # the cache serves only an in-order walk: a raw-pointer rewrite (no version bump, same allocation -- what the voxelizer does
+    # every batch) followed by a loop that does NOT start at slice 0 must see the new data
+    for i in range(n):
+        hip.event_slice_to_nhwc8(ev, i * cs, cs)
+    hip._lib.check(hip._lib.load().oess_masked_normalize_f32(ev.data_ptr(), ev.data_ptr(), ev.numel(),
+                                                              torch.empty(hip._lib.load().oess_masked_stats_doubles(1), dtype=torch.float64,
+                                                                          device="cuda").data_ptr(), None), "rewrite")
+    for i in (2, 3, 1):
+        got = hip.event_slice_to_nhwc8(ev, i * cs, cs)
+        assert torch.equal(got, hip.event_slice_to_nhwc8(ev[:, i * cs:(i + 1) * cs].contiguous(), 0, cs)), i

@@ -82,6 +82,7 @@ def test_openess_model_step_matches_oracle(contr, tmp_path):
     s = Settings(os.path.join(CFG, "openess_dsec_synthetic.yaml"), generate_log=False)
     s.ckpt_dir = str(tmp_path)
     s.if_spatial_contrastive = contr
+    s.lr_recon = s.lr_frame = 1e-4          # as the pre-training step tests: AdamW's first update is +-lr per weight whatever the gradient
     assert s.superpixel_size == 25
     trainer, loop = train.build_trainer(s)
     assert type(trainer).__name__ == 'OpenESSModel' and loop == 'training'
