@@ -109,23 +109,35 @@ def test_openess_model_step_matches_oracle(contr, tmp_path):
     assert int(sp[0].max()) >= 30                                  # sample 0's ids reach into sample 1's range [30, 60)
     keys = {'semseg_frame_loss', 'semseg_recon_loss', 'cons_feat_loss', 'cons_pred_loss'} | ({'contrastive_nce_loss'} if contr else set())
     torch.set_num_threads(max(torch.get_num_threads(), 8))
+    # Tolerances (measured, tools/exp_openess_tol.py -> profiles/r04_exp_openess_tolerances.txt, three seeds x three learning rates):
+    #   step 0 (same weights on both sides): TaskLoss / L1 within 0.3 %, cosine logit consistency within 1.3 %, InfoNCE within 5.1 %
+    #   (the loss is ~100-150: un-normalised 256-channel ASPP features at T = 0.07, logits in the thousands -- the fp32 oracle with
+    #   bf16 rounding points moves by up to 4.7 % against itself there);
+    #   step 1 (after one AdamW update of +-lr per weight): InfoNCE is ill-conditioned -- the oracle's OWN bf16-storage emulation
+    #   lands 0.1 .. 23 % away from it depending on the seed, this pipeline 5 .. 25 %; fp32 full-resolution features change nothing
+    #   (same file) -- so the second step bounds it at 30 % and pins the well-conditioned quantities instead: TaskLoss 2 %,
+    #   L1 3 %, cosine consistency 10 %, and the step-0 gradients by direction.
+    tol = [{'contrastive_nce_loss': 6e-2, 'cons_feat_loss': 1e-2, 'cons_pred_loss': 3e-2},
+           {'contrastive_nce_loss': 3e-1, 'cons_feat_loss': 3e-2, 'cons_pred_loss': 1e-1}]
+    grads = {}
     for it in range(2):
         losses, _, total = trainer.train_step((frame.cuda(), None, recon.cuda(), pl.cuda(), sp.cuda(), None))
         lref, tref = ref.train_step((frame, None, recon, pl, sp))
         assert set(losses) == keys == set(lref)
         for k in sorted(keys):
-            tol = {'contrastive_nce_loss': 5e-2, 'cons_feat_loss': 3e-2, 'cons_pred_loss': 5e-2}.get(k, 2e-2)
-            assert float(losses[k]) == pytest.approx(float(lref[k]), rel=tol, abs=2e-3), (it, k, float(losses[k]), float(lref[k]))
-        assert float(total) == pytest.approx(float(tref), rel=3e-2)
-    # both students moved, and in the oracle's direction: parameter-wise cosine of the two-step update of the trained 1x1 head
-    for name in ('model_recon', 'model_frame'):
-        mine = dict(trainer.models_dict[name].named_parameters())
-        theirs = dict(ref.modules()[name].named_parameters())
-        w0 = None
-        for pn in ('classifier.ASPP.project.0.weight',):
-            a = mine[pn].detach().float().cpu().numpy().ravel()
-            b = theirs[pn].detach().numpy().ravel()
-            assert np.isfinite(a).all() and float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))) > 0.999, (name, pn)
+            assert float(losses[k]) == pytest.approx(float(lref[k]), rel=tol[it].get(k, 2e-2)), (it, k, float(losses[k]), float(lref[k]))
+        if it == 0:
+            assert float(total) == pytest.approx(float(tref), rel=5e-2 if contr else 2e-2)
+            for name in ('model_recon', 'model_frame'):
+                mine, theirs = dict(trainer.models_dict[name].named_parameters()), dict(ref.modules()[name].named_parameters())
+                for pn in ('classifier.ASPP.project.0.weight', 'classifier.classifier.0.weight', 'classifier.ASPP.convs.0.0.weight'):
+                    a, b = mine[pn].grad.float().cpu().numpy().ravel(), theirs[pn].grad.numpy().ravel()
+                    grads[(name, pn)] = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+    # the head gradients of both students point the oracle's way (InfoNCE on: its ill-conditioned part dominates the feature
+    # gradient -- measured 0.85 .. 0.93 there -- so the bound is looser)
+    print("step-0 gradient cosines vs oracle:", grads)
+    for key, c in grads.items():
+        assert c > (0.80 if contr else 0.95), (key, grads)
 
 
 def test_ddd17_shaped_pretrain_step():
