@@ -191,6 +191,25 @@ def test_ddd17_dataset_matches_reference(g, ddd17_root, tag):
         check_item(g, "ddd17_aug_0", item, ddd17_root, 6, first_override=oracle_ddd17_voxels(ds, item[0]['events'], True))
 
 
+def test_ddd17_label_resize_cv2_nearest_rule_unpinned():
+    """UNPINNED (cv2 is absent in the build image, so no vector generated by the reference's own `cv2.resize(..., INTER_NEAREST)`
+    exists for ddd17_events_loader.py:131-136,234-236,260-262): the restatement `_io.resize_nearest_cv2` is checked against
+    OpenCV's documented rule src = min(floor(dst * src_size / dst_size), src_size - 1) on hand-computed indices for the sizes the
+    loader uses (260 x 346 -> 200 x 352), and against the pixel-centre rule it must NOT be (PIL / torch `nearest`)."""
+    from openess_amd.datasets import _io
+    src = np.arange(260 * 346, dtype=np.int64).reshape(260, 346)
+    out = _io.resize_nearest_cv2(src, (352, 200))
+    assert out.shape == (200, 352)
+    ys, xs = out // 346, out % 346
+    # rows: scale 260 / 200 = 1.3 -> 0, 1, 2, 3, 5, 6, 7, 9, ...; columns: 346 / 352 -> 0, 0, 1, 2, ... (dst 1 -> floor(0.983) = 0)
+    assert ys[:8, 0].tolist() == [0, 1, 2, 3, 5, 6, 7, 9] and ys[-1, 0] == 258
+    assert xs[0, :5].tolist() == [0, 0, 1, 2, 3] and xs[0, -1] == 345 and xs[0, 59] == 57 and xs[0, 60] == 58
+    centre = np.floor((np.arange(352) + 0.5) * 346 / 352).astype(np.int64)      # the rule cv2 does not use
+    assert (centre != xs[0]).any()
+    rgb = np.stack([src, src + 1, src + 2], -1)
+    assert np.array_equal(_io.resize_nearest_cv2(rgb, (352, 200))[..., 1], out + 1)
+
+
 def test_colour_augmentations_match_torchvision_semantics():
     """torchvision is absent here: adjust_brightness / adjust_contrast are restated (openess_amd/datasets/_io.py) and checked
     against hand-computed values of torchvision's documented blend rule."""
