@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copy the judged summaries of tools/final_run.sh from gpurun_out/fin/ into profiles/ (tracked), named per round."""
 import json, os, shutil, subprocess, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src, dst = "gpurun_out/fin", "profiles"
 pairs = {f"prof_frame2voxel_pixel_distill/step_kernel_stats.csv": f"{R}_step_pixel_distill_kernel_stats.csv",
          f"prof_frame2voxel_full/step_kernel_stats.csv": f"{R}_step_frame2voxel_full_kernel_stats.csv",
@@ -19,7 +19,7 @@ subprocess.run([sys.executable, "tools/mfma_util.py", os.path.join(src, "pmc_mfm
                check=True, stdout=subprocess.DEVNULL)
 # plain-text outputs quoted in DESIGN / EXPERIMENTS (present from round 3 on)
 with open(os.path.join(dst, f"{R}_misc_outputs.txt"), "w") as f:
-    for name in ("pytest_gpu.txt", "smoke.txt", "bench_no_skew.txt", "bench_torchrun_world1.txt", "train_loop.txt", "png.txt", "deeplab_breakdown.txt",
+    for name in ("pytest_gpu.txt", "pytest_gpu_run2.txt", "smoke.txt", "bench_no_skew.txt", "bench_torchrun_world1.txt", "train_loop.txt", "png.txt", "deeplab_breakdown.txt",
                  "segmean.txt", "voxelizer_pmc.txt", "stage_deeplab_fwd.txt", "stage_maskclip_fwd.txt", "stage_teacher_fwd.txt",
                  "vox_raw1.txt", "vox_raw0.txt", "enc_s2.txt", "probe_1x1.txt", "gap_probe.txt", "insitu_probe.txt", "step_sequence.txt"):
         p = os.path.join(src, name)
