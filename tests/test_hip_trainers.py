@@ -135,7 +135,7 @@ def test_openess_model_step_matches_oracle(contr, tmp_path):
                     grads[(name, pn)] = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
     # The head gradients of both students point the oracle's way as well as bf16 storage allows: the yardstick is the fp32
     # oracle with bf16 rounding points (oracle.nets.emulate_bf16_storage) run from the same weights -- on this random-weight,
-    # train-mode-BatchNorm net its own step-0 head gradients have cosine 0.7 .. 0.9 against the plain oracle.
+    # train-mode-BatchNorm net its own step-0 head gradients have cosine 0.87 .. 0.96 against the plain oracle.
     from oracle import nets as on
     emu = OracleOpenESSStep(K, contr, lr_recon=s.lr_recon, lr_frame=s.lr_frame, weight_task_loss=s.weight_task_loss)
     for name in ('model_recon', 'model_frame'):
@@ -157,7 +157,8 @@ def test_openess_model_step_matches_oracle(contr, tmp_path):
         cos_e[(name, pn)] = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
     print("step-0 head-gradient cosines vs the fp32 oracle: HIP", grads, "bf16-storage emulation", cos_e)
     for key, c in grads.items():
-        assert c > 0.6 and c > cos_e[key] - 0.2, (key, c, cos_e[key])      # measured: HIP 0.72 .. 0.87, emulation 0.85 .. 0.94
+        # measured (gpurun_out r4j): HIP 0.815 .. 0.929, emulation 0.868 .. 0.961, HIP within 0.02 .. 0.10 of the emulation
+        assert c > 0.75 and c > cos_e[key] - 0.15, (key, c, cos_e[key])
 
 
 def test_ddd17_shaped_pretrain_step():
