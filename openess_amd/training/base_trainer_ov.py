@@ -306,6 +306,7 @@ class BaseTrainer(object):
             out = self.val_step(batch[:-4], sensor_name, i_batch, -1, sample_batched[-1])
             for k, v in out[0].items():
                 cumulative[k] = cumulative.get(k, 0) + v
+        self.check_png_status(force=True)          # device_png: undecodable maps of the validation set raise here
         if self.world > 1 and self.metrics_semseg_b.metrics_acc is not None:      # 968-byte confusion-matrix sum
             dist.all_reduce(self.metrics_semseg_b.metrics_acc)
         metrics = self.metrics_semseg_b.get_metrics_summary()

@@ -73,6 +73,25 @@ def test_reference_trainer_module_paths_exist():
     assert so.deeplab_kwargs() == {} and so.backend_kwargs() == {} and so.amp_requested() and not ft.amp_requested()
 
 
+def test_png_status_queue_raises_with_slot_and_file_name():
+    """device_png: per-slot decode status vectors are queued and checked off the hot path; a non-zero status raises and names the
+    slot, the sample and the reason; an all-zero queue is consumed silently; below the check interval nothing is read."""
+    from types import SimpleNamespace
+    from openess_amd.training.base_trainer_ov import BaseTrainer
+    t = BaseTrainer.__new__(BaseTrainer)
+    t.settings = SimpleNamespace(png_check_every=2)
+    ok = torch.zeros(2, dtype=torch.int32)
+    t._png_pending = [(2, ok, ['a.png', 'b.png']), (4, ok, None)]
+    t.check_png_status()                                          # 2 entries < 3 * 2: not checked yet
+    assert len(t._png_pending) == 2
+    t.check_png_status(force=True)
+    assert t._png_pending == []
+    t._png_pending = [(2, ok, ['a.png', 'b.png']), (5, torch.tensor([0, 3], dtype=torch.int32), ['c.png', 'd.png'])]
+    with pytest.raises(RuntimeError, match=r"batch slot 5, sample d\.png: unsupported"):
+        t.check_png_status(force=True)
+    assert t._png_pending == []
+
+
 def test_checkpoint_format_roundtrip(tmp_path):
     from openess_amd.utils.saver import CheckpointSaver
     models = {'back_end': torch.nn.Linear(3, 2), 'model_frame': torch.nn.Linear(2, 2), 'model_recon': torch.nn.Linear(4, 1)}
