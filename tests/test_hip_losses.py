@@ -163,6 +163,36 @@ def test_superpixel_pool_bit_repeatable_and_exact(C, dt):
     assert torch.equal(outs[0].cpu(), ref)
 
 
+def test_superpixel_pool_baseline_size_conservation_and_repeat():
+    """BASELINE size (B = 8 x 256 ch x 440 x 640, bf16, SAM-like irregular uint8 regions that collide across samples): size-
+    independent properties of the scatter-mean -- (a) conservation: sum_s k[s] * count[s] equals the per-channel sum of all
+    features (every pixel lands in exactly one row), (b) the counts add up to the pixel count, (c) two calls give identical bits,
+    (d) the backward of sum(k * w) hands every pixel the row w[id] / (count + 1e-6)."""
+    from openess_amd import hip
+    torch.manual_seed(3)
+    B, C, H, W, sps = 8, 256, 440, 640, 100
+    feat = (torch.randint(-512, 512, (B, H, W, C), device="cuda").float() / 128.0).bfloat16().permute(0, 3, 1, 2).requires_grad_(True)
+    coarse = torch.randint(0, 256, (B, H // 20, W // 20), device="cuda")
+    ids = coarse.repeat_interleave(20, 1).repeat_interleave(20, 2)
+    ids = torch.roll(ids, shifts=(7, 13), dims=(1, 2)).contiguous()                 # regions not aligned to the pixel chunks
+    S = int((ids + torch.arange(B, device="cuda")[:, None, None] * sps).max()) + 1
+    k = hip.superpixel_pool(feat, ids, sps, S=S)
+    k2 = hip.superpixel_pool(feat.detach(), ids, sps, S=S)
+    assert torch.equal(k.detach(), k2)
+    gid = (ids + torch.arange(B, device="cuda")[:, None, None] * sps).reshape(-1)
+    cnt = torch.bincount(gid, minlength=S).double()
+    assert int(cnt.sum()) == B * H * W
+    total = feat.detach().permute(0, 2, 3, 1).reshape(-1, C).double().sum(0)       # exact: multiples of 2^-7, |x| <= 4
+    back = (k.detach().double() * (cnt.float() + 1e-6).double()[:, None]).sum(0)
+    np.testing.assert_allclose(back.cpu().numpy(), total.cpu().numpy(), rtol=0, atol=2e-2)       # 800 rows x fp32 rounding of k
+    w = torch.randn(S, C, device="cuda")
+    (k * w).sum().backward()
+    p = torch.randint(0, B * H * W, (4096,), device="cuda")
+    g = feat.grad.permute(0, 2, 3, 1).reshape(-1, C)[p].float()
+    want = (w / (cnt.float() + 1e-6)[:, None])[gid[p]]
+    np.testing.assert_allclose(g.cpu().numpy(), want.bfloat16().float().cpu().numpy(), rtol=0, atol=0)
+
+
 def test_superpixel_pool_out_of_range_input_is_loud():
     """Range contract of the fixed-point sums: a non-finite feature or |x| >= 32768 turns the whole output into NaN."""
     from openess_amd import hip

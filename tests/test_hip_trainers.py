@@ -14,24 +14,31 @@ pytestmark = pytest.mark.gpu
 CFG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")
 
 
-def _trainer(option, linear_probing, tmp_path):
+def _trainer(option, linear_probing, tmp_path, sup_only=False):
     import train
     from openess_amd.config.settings import Settings
     train.seed_everything()
     s = Settings(os.path.join(CFG, "finetune_dsec_synthetic.yaml"), generate_log=False)
     s.ckpt_dir = str(tmp_path)
     s.config_option = option
-    s.if_finetuning, s.if_linear_probing = (not linear_probing), linear_probing
+    s.if_finetuning, s.if_linear_probing = (not linear_probing and not sup_only), linear_probing
+    s.if_supervised_only = sup_only
     trainer, loop = train.build_trainer(s)
     assert loop == 'training'
-    assert type(trainer).__name__ == ('OpenESSLinearProbeModel' if linear_probing else 'OpenESSFineTuneModel')
+    want = 'SupOnlyModel' if sup_only else ('OpenESSLinearProbeModel' if linear_probing else 'OpenESSFineTuneModel')
+    assert type(trainer).__name__ == want and type(trainer).__module__.endswith(
+        {'SupOnlyModel': 'sup_only_trainer', 'OpenESSLinearProbeModel': 'linear_probe_trainer', 'OpenESSFineTuneModel': 'finetune_trainer'}[want])
     return trainer, s
 
 
-@pytest.mark.parametrize("option,linear_probing", [("frame2recon", False), ("frame2voxel", False),
-                                                   ("frame2voxel", True), ("frame2recon", True)])
-def test_supervised_step_matches_oracle(option, linear_probing, tmp_path):
-    trainer, s = _trainer(option, linear_probing, tmp_path)
+@pytest.mark.parametrize("option,linear_probing,sup_only", [("frame2recon", False, False), ("frame2voxel", False, False),
+                                                            ("frame2voxel", True, False), ("frame2recon", True, False),
+                                                            ("frame2recon", False, True), ("frame2voxel", False, True)])
+def test_supervised_step_matches_oracle(option, linear_probing, sup_only, tmp_path):
+    """Fine-tune, linear-probe and supervised-only trainers (the three stage-2/3 modules of train.py:4-8) built through
+    train.py's own dispatch: the step of each equals OracleSupervisedStep from identical weights."""
+    trainer, s = _trainer(option, linear_probing, tmp_path, sup_only)
+    assert trainer.scaler is None
     K, nwin, (H, W) = s.semseg_num_classes, s.nr_events_data_b, s.img_size_b
     lr = s.lr_voxel if option == "frame2voxel" else s.lr_recon
     ref = OracleSupervisedStep(option, K, nwin, 5, linear_probing, lr=lr)
