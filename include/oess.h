@@ -35,7 +35,7 @@ typedef void* oess_stream_t; /* hipStream_t */
 /* Library / device identification.  OESS_ABI_VERSION is bumped whenever a signature of this header changes or an entry point
  * is removed; oess_abi_version() returns the value the library was built with and the ctypes binding (openess_amd/_lib.py,
  * ABI_VERSION) refuses a library whose value differs. */
-#define OESS_ABI_VERSION 4
+#define OESS_ABI_VERSION 5
 int oess_abi_version(void);
 const char* oess_build_info(void);           /* "liboess <ver> gfx950 hipcc <ver>" */
 const char* oess_strerror(int code);
@@ -376,8 +376,11 @@ int oess_zero_insert_nhwc_bf16(const void* in, long long in_pix_stride, int B, i
                                void* out, long long out_pix_stride, oess_stream_t stream);
 int oess_downsample_sum2x_nhwc_bf16(const void* gout, long long gout_pix_stride, int B, int H, int W, int C, void* gin,
                                     long long gin_pix_stride, oess_stream_t stream);
+/* nn.Upsample(scale, bilinear, align_corners=True) + F.normalize(dim=1) in one pass (models/image_model.py:121-143).  inv_norm
+ * (nullable, needs normalize != 0): [B * H*scale * W*scale] fp32, 1 / max(|x|, 1e-12) of every output pixel -- what
+ * oess_l2norm_nhwc_bwd needs, so the differentiable head never materialises the un-normalised full-resolution tensor. */
 int oess_bilinear_l2norm_nhwc_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int C, int scale,
-                                   int normalize, void* out, long long out_pix_stride, oess_stream_t stream);
+                                   int normalize, void* out, long long out_pix_stride, float* inv_norm, oess_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Bilinear resampling (any size, both align_corners modes) and channel L2 normalisation, forward + adjoint.

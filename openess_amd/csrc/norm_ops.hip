@@ -325,7 +325,7 @@ __global__ __launch_bounds__(THREADS) void down2_sum_kernel(const uint16_t* __re
 // one wave per output pixel, lane handles C/64 channels (C = 256 -> 4).
 __global__ __launch_bounds__(THREADS) void bilinear_l2_kernel(const uint16_t* __restrict__ in, int64_t ips, int B, int H,
                                                               int W, int C, int scale, int normalize,
-                                                              uint16_t* __restrict__ out, int64_t ops) {
+                                                              uint16_t* __restrict__ out, int64_t ops, float* __restrict__ inv_out) {
     const int Ho = H * scale, Wo = W * scale;
     const float ry = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
     const float rx = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
@@ -360,6 +360,7 @@ __global__ __launch_bounds__(THREADS) void bilinear_l2_kernel(const uint16_t* __
         }
         uint16_t* o = out + opix * ops + lane * cpl;
         for (int k = 0; k < cpl; ++k) o[k] = f32_to_bf16(v[k] * inv);
+        if (inv_out && lane == 0) inv_out[opix] = inv;
     }
 }
 
@@ -368,7 +369,8 @@ __global__ __launch_bounds__(THREADS) void bilinear_l2_kernel(const uint16_t* __
 template <int LPP>
 __global__ __launch_bounds__(THREADS) void bilinear_l2_vec_kernel(const uint16_t* __restrict__ in, int64_t ips, int B, int H,
                                                                   int W, int scale, int normalize,
-                                                                  uint16_t* __restrict__ out, int64_t ops, int run_len) {
+                                                                  uint16_t* __restrict__ out, int64_t ops, int run_len,
+                                                                  float* __restrict__ inv_out) {
     const int Ho = H * scale, Wo = W * scale;
     const float ry = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
     const float rx = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
@@ -429,6 +431,7 @@ __global__ __launch_bounds__(THREADS) void bilinear_l2_vec_kernel(const uint16_t
             const float inv = rsqrtf(fmaxf(ss, 1e-24f));           // = 1 / max(sqrt(ss), 1e-12)
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] *= inv;
+            if (inv_out && sub == 0) inv_out[orow + ox] = inv;     // the L2 adjoint's 1 / |x| (training form)
         }
         *reinterpret_cast<uint4*>(out + (orow + ox) * ops + sub * 8) = pack_bf16x8(v);
     }
@@ -830,7 +833,8 @@ int oess_downsample_sum2x_nhwc_bf16(const void* gout, long long gout_pix_stride,
 }
 
 int oess_bilinear_l2norm_nhwc_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int C, int scale,
-                                   int normalize, void* out, long long out_pix_stride, oess_stream_t stream) {
+                                   int normalize, void* out, long long out_pix_stride, float* inv_norm, oess_stream_t stream) {
+    if (inv_norm && !normalize) return OESS_EINVAL;
     if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 63) || C > 512 || scale <= 0) return OESS_EINVAL;
     const int64_t total = (int64_t)B * H * scale * W * scale;
     const int lpp = C / 8;
@@ -844,7 +848,7 @@ int oess_bilinear_l2norm_nhwc_bf16(const void* in, long long in_pix_stride, int 
 #define OESS_BL(LPP_)                                                                                                  \
         hipLaunchKernelGGL(bilinear_l2_vec_kernel<LPP_>, dim3((unsigned)gv), dim3(THREADS), 0, (hipStream_t)stream,    \
                            (const uint16_t*)in, (int64_t)in_pix_stride, B, H, W, scale, normalize, (uint16_t*)out,      \
-                           (int64_t)out_pix_stride, run_len)
+                           (int64_t)out_pix_stride, run_len, inv_norm)
         if (lpp == 8) OESS_BL(8); else if (lpp == 16) OESS_BL(16); else if (lpp == 32) OESS_BL(32); else OESS_BL(64);
 #undef OESS_BL
         OESS_HIP(hipGetLastError());
@@ -853,7 +857,7 @@ int oess_bilinear_l2norm_nhwc_bf16(const void* in, long long in_pix_stride, int 
     int64_t g = (total + 3) / 4;
     if (g > 16384) g = 16384;
     hipLaunchKernelGGL(bilinear_l2_kernel, dim3((unsigned)g), dim3(THREADS), 0, (hipStream_t)stream, (const uint16_t*)in,
-                       (int64_t)in_pix_stride, B, H, W, C, scale, normalize, (uint16_t*)out, (int64_t)out_pix_stride);
+                       (int64_t)in_pix_stride, B, H, W, C, scale, normalize, (uint16_t*)out, (int64_t)out_pix_stride, inv_norm);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }

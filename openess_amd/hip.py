@@ -1076,9 +1076,54 @@ def bilinear_l2norm(x, scale=4, normalize=True):
     xn = x.permute(0, 2, 3, 1)
     B, H, W, C, ps = _nhwc_geom(xn)
     out = torch.empty((B, H * scale, W * scale, C), dtype=torch.bfloat16, device=x.device)
-    _lib.check(lib.oess_bilinear_l2norm_nhwc_bf16(_ptr(xn), ps, B, H, W, C, scale, int(normalize), _ptr(out), C, _stream()),
+    _lib.check(lib.oess_bilinear_l2norm_nhwc_bf16(_ptr(xn), ps, B, H, W, C, scale, int(normalize), _ptr(out), C, None, _stream()),
                "oess_bilinear_l2norm_nhwc_bf16")
     return out.permute(0, 3, 1, 2)
+
+
+class _BilinearL2NormTrain(torch.autograd.Function):
+    """Differentiable nn.Upsample(scale, bilinear, align_corners=True) + F.normalize(dim=1) as ONE node: the forward is the fused
+    inference kernel (which also leaves 1 / |x| per output pixel), so the un-normalised full-resolution tensor -- 1.15 GB at the
+    BASELINE size -- is never written or re-read; the backward is the L2 adjoint on (y, g, 1 / |x|) followed by the
+    deterministic two-pass bilinear adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        lib = _lib.load()
+        xn = x.permute(0, 2, 3, 1)
+        B, H, W, C, ps = _nhwc_geom(xn)
+        y = torch.empty((B, H * scale, W * scale, C), dtype=torch.bfloat16, device=x.device)
+        inv = torch.empty(B * H * scale * W * scale, dtype=torch.float32, device=x.device)
+        _lib.check(lib.oess_bilinear_l2norm_nhwc_bf16(_ptr(xn), ps, B, H, W, C, scale, 1, _ptr(y), C, _ptr(inv), _stream()),
+                   "oess_bilinear_l2norm_nhwc_bf16")
+        ctx.save_for_backward(y, inv)
+        ctx.meta = (B, H, W, C, scale)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        y, inv = ctx.saved_tensors
+        B, H, W, C, scale = ctx.meta
+        Ho, Wo = H * scale, W * scale
+        gn = _nhwc_any(g.to(torch.bfloat16))
+        gup = torch.empty_like(y)
+        _lib.check(lib.oess_l2norm_nhwc_bwd(_ptr(y), C, _ptr(gn), _pix_stride(gn), _ptr(inv), B * Ho * Wo, C, 1, 1e-12, _ptr(gup), C,
+                                            _stream()), "oess_l2norm_nhwc_bwd")
+        gin = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=g.device)
+        nbytes = lib.oess_resize_bilinear_bwd_workspace_bytes(B, W, C, Ho)
+        ws = _workspace(nbytes, g.device, tag="resize")
+        _lib.check(lib.oess_resize_bilinear_nhwc_bwd(_ptr(gup), C, B, H, W, C, 1, Ho, Wo, 1, _ptr(ws), ws.numel(), _ptr(gin), C, _stream()),
+                   "oess_resize_bilinear_nhwc_bwd")
+        return gin.permute(0, 3, 1, 2), None
+
+
+def bilinear_l2norm_train(x, scale=4):
+    """Differentiable form of bilinear_l2norm (normalisation on) for a channels_last bf16 tensor with C % 64 == 0."""
+    _need_gpu(x)
+    if x.dtype != torch.bfloat16 or x.shape[1] % 64 or x.shape[1] > 512:
+        raise ValueError("bilinear_l2norm_train needs bf16 with C % 64 == 0, C <= 512")
+    return _BilinearL2NormTrain.apply(x, int(scale))
 
 
 def _nhwc_any(x):

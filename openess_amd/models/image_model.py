@@ -45,7 +45,9 @@ class DilationFeatureExtractor(nn.Module):
             x = self.encoder(x)
         x = self.decoder[0](x)
         if torch.is_grad_enabled() and x.requires_grad:
-            # differentiable path (contrastive loss active): resize + normalise kernels with their adjoints
+            # differentiable path (contrastive loss active)
+            if self.normalize_feature and x.dtype == torch.bfloat16 and x.shape[1] % 64 == 0 and x.shape[1] <= 512:
+                return hip.bilinear_l2norm_train(x, 4)            # one fused forward kernel + (L2 adjoint, bilinear adjoint)
             x = hip.bilinear_resize(x, scale_factor=4, align_corners=True)
             return hip.l2_normalize(x) if self.normalize_feature else x
         return hip.bilinear_l2norm(x, 4, self.normalize_feature)

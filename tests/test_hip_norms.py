@@ -87,6 +87,31 @@ def test_bilinear_l2norm(C):
     np.testing.assert_allclose(y2.float().cpu().numpy(), ref2.cpu().numpy(), rtol=1e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("C", [64, 256, 192])              # 192: scalar fallback kernel
+def test_bilinear_l2norm_train_fwd_bwd(C):
+    """The differentiable teacher head as one node (models/image_model.py:121-143: x4 bilinear, align_corners=True, then
+    F.normalize): forward equals the inference kernel bit for bit and torch's fp32 result to bf16 accuracy; the input gradient
+    equals torch's autograd through interpolate + normalize (bf16 tolerance) and the two-node path it replaces."""
+    from openess_amd import hip
+    torch.manual_seed(C)
+    x = cl(torch.randn(2, C, 11, 16, device="cuda")).requires_grad_(True)
+    y = hip.bilinear_l2norm_train(x, 4)
+    assert torch.equal(y.detach(), hip.bilinear_l2norm(x.detach(), 4, True))
+    xr = x.detach().float().requires_grad_(True)
+    ref = F.normalize(F.interpolate(xr, scale_factor=4, mode="bilinear", align_corners=True), p=2, dim=1)
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-2, atol=2e-3)
+    g = cl(torch.randn_like(ref).bfloat16())
+    y.backward(g)
+    ref.backward(g.float())
+    a, b = x.grad.float().cpu().numpy(), xr.grad.cpu().numpy()
+    assert float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b))) > 0.9995
+    np.testing.assert_allclose(a, b, rtol=5e-2, atol=5e-2 * np.abs(b).max())
+    x2 = x.detach().clone().requires_grad_(True)
+    hip.l2_normalize(hip.bilinear_resize(x2, scale_factor=4, align_corners=True)).backward(g)
+    c = x2.grad.float().cpu().numpy()
+    assert float((a * c).sum() / (np.linalg.norm(a) * np.linalg.norm(c))) > 0.9995
+
+
 @pytest.mark.parametrize("case", [
     # B, C, H, W, Ho, Wo, align, dtype
     (2, 256, 7, 10, 110, 160, False, torch.bfloat16),     # DeepLabv3 features: OS16 -> input size (vector path)
