@@ -289,19 +289,19 @@ def test_nce_loss_golden(golden_losses):
     np.testing.assert_allclose(k.grad.cpu().numpy(), g["nce_gk"], rtol=2e-5, atol=1e-5)
     np.testing.assert_allclose(q.grad.cpu().numpy(), g["nce_gq"], rtol=2e-5, atol=1e-5)
     torch.manual_seed(2)
-    S, C = 800, 256
-    kk = torch.nn.functional.normalize(torch.randn(S, C), dim=1)
-    qq = torch.nn.functional.normalize(torch.randn(S, C), dim=1)
-    kk[5] = 0; qq[7] = 0                                     # empty superpixels: zero rows still enter the loss
-    kr, qr = kk.clone().requires_grad_(True), qq.clone().requires_grad_(True)
-    ref = ol.nce_loss(kr, qr, 0.07)
-    ref.backward()
-    kd, qd = kk.cuda().requires_grad_(True), qq.cuda().requires_grad_(True)
-    out = NCELoss(temperature=0.07)(kd, qd)
-    (out * 3.0).backward()
-    np.testing.assert_allclose(out.item(), ref.item(), rtol=1e-5)
-    np.testing.assert_allclose(kd.grad.cpu().numpy(), 3.0 * kr.grad.numpy(), rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(qd.grad.cpu().numpy(), 3.0 * qr.grad.numpy(), rtol=1e-4, atol=1e-6)
+    for S, C in ((800, 256), (37, 64), (9, 6)):              # BASELINE size; odd S (ragged last row pair); C % 4 != 0: generic kernel
+        kk = torch.nn.functional.normalize(torch.randn(S, C), dim=1)
+        qq = torch.nn.functional.normalize(torch.randn(S, C), dim=1)
+        kk[5] = 0; qq[7] = 0                                     # empty superpixels: zero rows still enter the loss
+        kr, qr = kk.clone().requires_grad_(True), qq.clone().requires_grad_(True)
+        ref = ol.nce_loss(kr, qr, 0.07)
+        ref.backward()
+        kd, qd = kk.cuda().requires_grad_(True), qq.cuda().requires_grad_(True)
+        out = NCELoss(temperature=0.07)(kd, qd)
+        (out * 3.0).backward()
+        np.testing.assert_allclose(out.item(), ref.item(), rtol=1e-5)
+        np.testing.assert_allclose(kd.grad.cpu().numpy(), 3.0 * kr.grad.numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(qd.grad.cpu().numpy(), 3.0 * qr.grad.numpy(), rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.gpu

@@ -15,7 +15,7 @@ fused = hip.bilinear_l2norm_train
 two_node = lambda x, scale=4: hip.l2_normalize(hip.bilinear_resize(x, scale_factor=scale, align_corners=True))
 wl = bench.Workload("frame2voxel_full", 0, 1, dev, inputs)
 for rep in range(3):
-    for name, fn in (("fused", fused), ("two-node", two_node)):
+    for name, fn in (("fused", fused), ("two-node", two_node)) if os.environ.get("AB_TWO_NODE") else (("fused", fused),):
         hip.bilinear_l2norm_train = fn
         dt, loss, _ = wl.timed(20, 3)
         print(f"{name:9s} {8 * 20 / dt:7.2f} event-frames/s  {dt / 20 * 1e3:7.3f} ms/step  loss {loss:.4f}", flush=True)
