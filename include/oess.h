@@ -214,6 +214,17 @@ int oess_confusion_accumulate(const int64_t* pred, const int64_t* label, int64_t
 size_t oess_conv2d_packed_bytes(int Cout, int Cin, int R, int S, int flip_for_dgrad);
 int oess_conv2d_pack_weight(const float* w_oihw, int Cout, int Cin, int R, int S, int flip_for_dgrad, void* packed,
                             size_t packed_bytes, oess_stream_t stream);
+/* The same packing for n weights in ONE launch (all trainable convolutions of a model after an optimiser step); Cout % 8 == 0
+ * and Cin % 8 == 0.  table_dev: n rows of eight 64-bit words in DEVICE memory, the last one the problem's first workgroup
+ * (problem p owns oess_conv2d_pack_multi_blocks(...) workgroups; total_blocks = their sum).
+ *   flip_from_packed == 0: rows {w_oihw fp32, packed forward operand, Cout, Cin, R, S, 0, first block};
+ *   flip_from_packed == 1: rows {packed forward operand, packed data-gradient operand, Cout, Cin, R, S, 0, first block}: the
+ *                          flip_for_dgrad = 1 operand formed from the (already current) forward operand by tile transposes.
+ * Only the valid region of a destination is written: it must have been packed once by oess_conv2d_pack_weight (zero padding).
+ * The caller uploads the table (and may cache it while the pointers repeat). */
+long long oess_conv2d_pack_multi_blocks(int Cout, int Cin, int R, int S, int flip_from_packed);
+int oess_conv2d_pack_weight_multi(const long long* table_dev, int n, long long total_blocks, int flip_from_packed,
+                                  oess_stream_t stream);
 int oess_conv2d_fwd_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int Cin, const void* w_packed,
                          const float* bias, int Cout, int R, int S, int stride, int pad, int dil, int relu,
                          const void* residual, long long res_pix_stride, void* out_bf16, float* out_f32,

@@ -99,6 +99,8 @@ SIGNATURES = {
     "oess_bilinear_l2norm_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_ll, c_vp, c_vp]),
     "oess_conv2d_wgrad_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp, c_ll, c_int, c_int, c_int, c_int,
                                        c_int, c_int, c_int, c_vp, c_vp, c_sz, c_vp]),
+    "oess_conv2d_pack_multi_blocks": (c_ll, [c_int, c_int, c_int, c_int, c_int]),
+    "oess_conv2d_pack_weight_multi": (c_int, [c_vp, c_int, c_ll, c_int, c_vp]),
     "oess_conv2d_packed_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     "oess_conv2d_pack_weight": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
     "oess_e2vid_events_head_enc0_bf16": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_ll, c_vp]),

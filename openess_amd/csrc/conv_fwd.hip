@@ -1815,9 +1815,108 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, uint16_t* __rest
     }
 }
 
+// Many weights in ONE launch (every trainable conv of a model after an optimiser step: ~125 separate 6 us launches per
+// frame2recon step otherwise).  Two table-driven kernels; table[p] = eight 64-bit words in device memory, the last one the
+// problem's first workgroup; a workgroup finds its problem by a binary search over that column (problems differ by 500x in
+// size: a fixed number of workgroups per problem left the chip idle behind the two largest operands).
+//   pack_fwd_multi_kernel : {w OIHW fp32, packed, Cout, Cin, R, S, -, first block}: a thread forms 8 consecutive k of one packed
+//                           row (same output channel, same tap, 8 input channels) -> ONE 16-byte store and one index decode per
+//                           8 elements (the single-weight kernel above decodes every element with a 64-bit division).
+//   pack_flip_multi_kernel: {packed forward operand, packed data-gradient operand, Cout, Cin, R, S, -, first block}: the
+//                           data-gradient operator Wf[ci][(R-1-r, S-1-s), co] is the forward operand W[co][(r, s), ci] with
+//                           (co, ci) transposed per tap -- a 64 x 64 bf16 tile transpose through LDS, both sides in 128-byte
+//                           rows (from the fp32 OIHW tensor every element would be a separate 32-byte sector).
+// Both need Cout % 8 == 0 and Cin % 8 == 0 (no channel padding inside a row) and only write the valid region: the zero
+// padding of the buffers was written by the first, single-weight packing and is never touched again.
+constexpr int PACK_CHUNK = 256 * 8 * 4;               // packed elements per workgroup of the forward kernel
+__device__ __forceinline__ const long long* pack_find(const long long* table, int n) {
+    int lo = 0, hi = n;                                   // largest p with first_block[p] <= blockIdx.x
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (table[(size_t)mid * 8 + 7] <= (long long)blockIdx.x) lo = mid; else hi = mid;
+    }
+    return table + (size_t)lo * 8;
+}
+__global__ __launch_bounds__(256) void pack_fwd_multi_kernel(const long long* __restrict__ table, int n) {
+    const long long* d = pack_find(table, n);
+    const float* w = reinterpret_cast<const float*>(d[0]);
+    uint16_t* wp = reinterpret_cast<uint16_t*>(d[1]);
+    const int Cout = (int)d[2], Cin = (int)d[3], R = (int)d[4], S = (int)d[5];
+    const int RS = R * S;
+    const int Kpad = (RS * Cin + BK - 1) / BK * BK;                    // Cin % 8 == 0: Cin_pad == Cin
+    const int k8_per_row = RS * Cin / 8;                                // valid 8-element groups of a packed row
+    const long long groups = (long long)Cout * k8_per_row;
+    const long long g0 = ((long long)blockIdx.x - d[7]) * (PACK_CHUNK / 8);
+#pragma unroll
+    for (int u = 0; u < PACK_CHUNK / 8 / 256; ++u) {
+        const long long gi = g0 + u * 256 + threadIdx.x;
+        if (gi >= groups) break;
+        const int nn = (int)(gi / k8_per_row), k8 = (int)(gi - (long long)nn * k8_per_row);
+        const int k = k8 * 8, tap = k / Cin, ci = k - tap * Cin;
+        const float* src = w + ((long long)nn * Cin + ci) * RS + tap;   // element (nn, ci + q, tap) at src[q * RS]
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = src[(long long)q * RS];
+        *reinterpret_cast<uint4*>(wp + (long long)nn * Kpad + k) = pack_bf16x8(v);
+    }
+}
+__global__ __launch_bounds__(256) void pack_flip_multi_kernel(const long long* __restrict__ table, int n) {
+    __shared__ uint16_t tile[64][64 + 8];
+    const long long* d = pack_find(table, n);
+    const uint16_t* wf = reinterpret_cast<const uint16_t*>(d[0]);       // forward operand [co][tap * Cin + ci]
+    uint16_t* wb = reinterpret_cast<uint16_t*>(d[1]);                   // data-gradient operand [ci][tap' * Cout + co]
+    const int Cout = (int)d[2], Cin = (int)d[3], R = (int)d[4], S = (int)d[5];
+    const int RS = R * S;
+    const int KpadF = (RS * Cin + BK - 1) / BK * BK, KpadB = (RS * Cout + BK - 1) / BK * BK;
+    const int tco = (Cout + 63) / 64, tci = (Cin + 63) / 64;
+    int b = (int)((long long)blockIdx.x - d[7]);                        // (tap, co tile, ci tile)
+    const int ci_t = b % tci; b /= tci;
+    const int co_t = b % tco; const int tap = b / tco;
+    const int co0 = co_t * 64, ci0 = ci_t * 64;
+    // load: rows co0 .. co0+63, 64 ci each (8 chunks of 16 bytes): 512 chunks, two per thread
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int c = u * 256 + threadIdx.x, row = c >> 3, ch = c & 7;
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        if (co0 + row < Cout && ci0 + ch * 8 < Cin)
+            q = *reinterpret_cast<const uint4*>(wf + (long long)(co0 + row) * KpadF + (long long)tap * Cin + ci0 + ch * 8);
+        *reinterpret_cast<uint4*>(&tile[row][ch * 8]) = q;
+    }
+    __syncthreads();
+    const int tapb = RS - 1 - tap;                                      // (R-1-r) * S + (S-1-s)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int c = u * 256 + threadIdx.x, row = c >> 3, ch = c & 7;  // row = ci within the tile, ch = group of 8 co
+        if (ci0 + row < Cin && co0 + ch * 8 < Cout) {
+            union { uint4 q; uint16_t h[8]; } o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.h[e] = tile[ch * 8 + e][row];
+            *reinterpret_cast<uint4*>(wb + (long long)(ci0 + row) * KpadB + (long long)tapb * Cout + co0 + ch * 8) = o.q;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+long long oess_conv2d_pack_multi_blocks(int Cout, int Cin, int R, int S, int flip_from_packed) {
+    if (Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0 || (Cout & 7) || (Cin & 7)) return 0;
+    if (flip_from_packed) return (long long)R * S * ((Cout + 63) / 64) * ((Cin + 63) / 64);
+    const long long groups = (long long)Cout * (R * S * Cin / 8);
+    return (groups + PACK_CHUNK / 8 - 1) / (PACK_CHUNK / 8);
+}
+
+int oess_conv2d_pack_weight_multi(const long long* table_dev, int n, long long total_blocks, int flip_from_packed,
+                                  oess_stream_t stream) {
+    if (!table_dev || n <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffll) return OESS_EINVAL;
+    if (flip_from_packed)
+        hipLaunchKernelGGL(pack_flip_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, table_dev, n);
+    else
+        hipLaunchKernelGGL(pack_fwd_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, table_dev, n);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
 
 int oess_conv2d_pack_weight(const float* w_oihw, int Cout, int Cin, int R, int S, int flip_for_dgrad, void* packed,
                             size_t packed_bytes, oess_stream_t stream) {

@@ -6,6 +6,8 @@ uniform pixel stride; `nhwc(x)` is a free view.  Convolutions run on the hand-wr
 (openess_amd/csrc/conv_fwd.hip); master weights stay fp32 nn.Parameters and are packed to the
 kernel's bf16 operand format lazily (re-packed when the parameter's version counter changes).
 """
+import weakref
+
 import torch
 import torch.nn.functional as F
 
@@ -48,13 +50,25 @@ def zeros_cl(B, C, H, W, device, dtype=torch.bfloat16):
 
 class PackedWeight:
     """bf16 packed operand of a conv weight (optionally with an eval-mode BatchNorm folded in),
-    cached per (parameter versions)."""
+    cached per (parameter versions).
+
+    Group refresh: after an optimiser step EVERY trainable conv weight of a model is stale at once, and packing them one by one
+    is ~125 launches of ~6 us per frame2recon step (53 forward operands, 53 data-gradient operands, ...).  Plain weights
+    (fp32, contiguous, no folded BatchNorm, no channel padding) therefore register here; the first stale one found by get()
+    repacks ALL stale registered weights -- forward operands and the data-gradient operands that exist -- with ONE launch
+    (oess_conv2d_pack_weight_multi) into their existing buffers (stream-ordered: everything that read the old operands was
+    enqueued before)."""
+    _registry = weakref.WeakSet()
+    group_enabled = True                    # False: every stale operand is packed by its own launch (A/B, tools/ab_pack_group.py)
+    _table_cache = {}                       # (device index, forward / flip) -> (key tuple, device table)
 
     def __init__(self):
         self.key = None
         self.packed = None
         self.bias = None
         self.packed_flip = None
+        self._wref = None                   # weakref to the plain weight this operand was packed from (groupable members only)
+        self._bref = None
 
     def flip(self):
         """Packed data-gradient operator of the currently packed weight (stride-1 convs)."""
@@ -62,10 +76,55 @@ class PackedWeight:
             self.packed_flip = hip.pack_conv_weight(self._w_for_flip, flip=True)
         return self.packed_flip
 
+    @classmethod
+    def refresh_stale(cls):
+        """Repack every registered operand whose weight has a new version: one launch for the forward operands and one for
+        the data-gradient operands (tile transposes of the fresh forward operands).  Returns the number of operands packed."""
+        lib = hip._lib.load()
+        rows = ([], [])                      # forward rows, flip rows
+        nblk = [0, 0]
+        members = []
+        for pw in list(cls._registry):
+            w = pw._wref() if pw._wref is not None else None
+            if w is None or pw.packed is None or not w.is_cuda or w._version == pw.key[0]:
+                continue
+            members.append((pw, w))
+            Cout, Cin, R, S = w.shape
+            rows[0].append((w.data_ptr(), pw.packed.data_ptr(), Cout, Cin, R, S, 0, nblk[0]))
+            nblk[0] += lib.oess_conv2d_pack_multi_blocks(Cout, Cin, R, S, 0)
+            if pw.packed_flip is not None:
+                rows[1].append((pw.packed.data_ptr(), pw.packed_flip.data_ptr(), Cout, Cin, R, S, 0, nblk[1]))
+                nblk[1] += lib.oess_conv2d_pack_multi_blocks(Cout, Cin, R, S, 1)
+        if not members:
+            return 0
+        dev = members[0][1].device
+        for which in (0, 1):
+            if not rows[which]:
+                continue
+            key = tuple(rows[which])
+            hit = cls._table_cache.get((dev.index, which))
+            if hit is None or hit[0] != key:
+                table = hip.h2d_async(torch.tensor(rows[which], dtype=torch.int64), dev)
+                cls._table_cache[(dev.index, which)] = (key, table)
+            else:
+                table = hit[1]
+            hip._lib.check(lib.oess_conv2d_pack_weight_multi(table.data_ptr(), len(rows[which]), nblk[which], which, hip._stream()),
+                           "oess_conv2d_pack_weight_multi")
+        for pw, w in members:
+            b = pw._bref() if pw._bref is not None else None
+            pw.key = (w._version, None if b is None else b._version, None, pw.key[3])
+            pw._w_for_flip = w.detach()
+        return len(rows[0]) + len(rows[1])
+
     def get(self, weight, bias=None, bn=None, need_flip=False, cin_pad=None, ver=None):
         key = (weight._version if ver is None else ver, None if bias is None else bias._version,
                None if bn is None else (bn.weight._version, bn.bias._version, bn.running_mean._version,
                                         bn.running_var._version), cin_pad)
+        if PackedWeight.group_enabled and key != self.key and self.packed is not None and self._wref is not None and self._wref() is weight and \
+                self.key is not None and self.key[2:] == key[2:]:
+            PackedWeight.refresh_stale()            # this operand and every other stale registered one, in one launch
+            if self.key[0] == key[0]:
+                self.key = key                      # (bias version: the fp32 bias tensor shares the parameter's storage)
         if key != self.key:
             with torch.no_grad():
                 w = weight.detach().float()
@@ -81,6 +140,17 @@ class PackedWeight:
                 self.packed_flip = None
                 self._w_for_flip = w
                 self.bias = None if b is None else b.contiguous()
+                # plain weights join the group refresh: the operand is a pure function of the parameter's own storage
+                plain = (ver is None and bn is None and weight.dtype == torch.float32 and weight.is_contiguous() and weight.is_cuda
+                         and w.data_ptr() == weight.data_ptr() and weight.requires_grad
+                         and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0
+                         and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous())))
+                if plain:
+                    self._wref = weakref.ref(weight)
+                    self._bref = None if bias is None else weakref.ref(bias)
+                    PackedWeight._registry.add(self)
+                else:
+                    self._wref = self._bref = None
             self.key = key
         if need_flip and self.packed_flip is None:
             self.packed_flip = hip.pack_conv_weight(self._w_for_flip, flip=True)
@@ -200,7 +270,8 @@ class _ConvBNTrainFn(torch.autograd.Function):
         gps = hip._nhwc_geom(gn)[4]
         dy = torch.empty((B, Ho, Wo, C), dtype=torch.bfloat16, device=y.device)                # gradient w.r.t. the raw conv output
         dres = torch.empty((B, Ho, Wo, C), dtype=torch.bfloat16, device=y.device) if (has_res and relu) else None
-        dgb = torch.empty((2, C), dtype=torch.float32, device=y.device)
+        # two separate allocations: AccumulateGrad steals a whole tensor, a view it would have to copy
+        dgb = (torch.empty(C, dtype=torch.float32, device=y.device), torch.empty(C, dtype=torch.float32, device=y.device))
         g32 = gamma.detach().float().contiguous()
         ws, wsn = hip._norm_partials(1, M, C, y.device, backward=True)
         hip._lib.check(lib.oess_batchnorm_bwd_nhwc_bf16(y.data_ptr(), C, gn.data_ptr(), gps, None if out is None else out.data_ptr(), C,

@@ -945,7 +945,9 @@ class _BatchNormTrainFn(torch.autograd.Function):
         _, _, _, _, gps = _nhwc_geom(gn)
         dx = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=x.device)
         dres = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=x.device) if (ctx.has_res and ctx.relu) else None
-        dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        # d(beta), d(gamma) as two separate allocations: AccumulateGrad steals a whole tensor but has to COPY a view (one tiny
+        # copy kernel per BatchNorm parameter and step otherwise)
+        dgb = (torch.empty(C, dtype=torch.float32, device=x.device), torch.empty(C, dtype=torch.float32, device=x.device))
         g32 = gamma.detach().float().contiguous()
         ws, wsn = _norm_partials(1, B * H * W, C, x.device, backward=True)
         _lib.check(lib.oess_batchnorm_bwd_nhwc_bf16(_ptr(xn), xps, _ptr(gn), gps, None if out is None else _ptr(out), C, _ptr(mean),

@@ -535,3 +535,40 @@ def test_conv5x5s2_group_equals_separate_launches(B, H, W):
         hip.conv5x5s2_group([(xh1[..., :128], p2, b2, 256, False, xh2[..., :256]), (h0[..., 64:], p1, b1, 128, True, xh1[..., :128])])
     with pytest.raises(ValueError):
         hip.conv5x5s2_group([(h0[..., 64:], p1, b1, 128, True, xh1[..., :64])])
+
+
+def test_packed_weight_group_refresh_equals_individual_packing():
+    """engine.PackedWeight: after an in-place update of several conv weights (an optimiser step) the first stale operand that is
+    asked for repacks ALL stale registered operands -- forward and existing data-gradient operands -- with one launch into their
+    existing buffers; the operands equal freshly packed ones bit for bit, frozen and derived weights are left alone, and the
+    second step reuses the cached device table."""
+    from openess_amd import engine, hip
+    torch.manual_seed(0)
+    convs = [torch.nn.Parameter(torch.randn(co, ci, k, k, device="cuda") * 0.1) for co, ci, k in ((64, 32, 3), (136, 64, 1), (72, 200, 3), (32, 64, 5))]
+    frozen = torch.nn.Parameter(torch.randn(16, 8, 3, 3, device="cuda"), requires_grad=False)
+    pws = [engine.PackedWeight() for _ in convs]
+    pwf = engine.PackedWeight()
+    x = [torch.randn(2, c.shape[1], 9, 11, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last) for c in convs]
+    for rep in range(3):
+        outs = []
+        for w, pw, xi in zip(convs, pws, x):
+            xi = xi.clone().requires_grad_(True)
+            y = engine.conv2d_train(xi, w, None, pw, w.shape[2], 1, w.shape[2] // 2, 1)
+            y.float().sum().backward()                       # creates / uses the data-gradient operand
+            outs.append(y.detach())
+        pwf.get(frozen, None, None, cin_pad=8)
+        buffers = [(pw.packed.data_ptr(), pw.packed_flip.data_ptr()) for pw in pws]
+        for w, pw, o, xi in zip(convs, pws, outs, x):
+            assert torch.equal(pw.packed, hip.pack_conv_weight(w)) and torch.equal(pw.packed_flip, hip.pack_conv_weight(w, flip=True))
+            ref = hip.conv2d_nhwc(xi.permute(0, 2, 3, 1), hip.pack_conv_weight(w), None, w.shape[0], w.shape[2], w.shape[2], 1, w.shape[2] // 2, 1)
+            assert torch.equal(o.permute(0, 2, 3, 1), ref)
+        with torch.no_grad():
+            for w in convs:
+                w.add_(torch.randn_like(w) * 0.01)             # the "optimiser step": every weight stale at once
+                w.grad = None
+        if rep > 0:
+            assert [(pw.packed.data_ptr(), pw.packed_flip.data_ptr()) for pw in pws] == buffers      # repacked in place
+    # one call repacks everything that is stale, and nothing when nothing is
+    n = engine.PackedWeight.refresh_stale()
+    assert n == 2 * len(convs) and engine.PackedWeight.refresh_stale() == 0
+    assert pwf._wref is None                                                                       # frozen weights never register

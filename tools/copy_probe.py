@@ -6,7 +6,7 @@ import bench
 from torch.utils._python_dispatch import TorchDispatchMode
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
-wl = bench.Workload("frame2voxel_pixel_distill", 0, 1, dev, bench.make_inputs(0, dev))
+wl = bench.Workload(sys.argv[1] if len(sys.argv) > 1 else "frame2voxel_pixel_distill", 0, 1, dev, bench.make_inputs(0, dev))
 for _ in range(3):
     wl.one_step()
 torch.cuda.synchronize()
@@ -18,7 +18,7 @@ class Spy(TorchDispatchMode):
         name = str(func)
         if any(k in name for k in ("copy", "fill", "zero", "add", "mul", "clone", "contiguous", "cat", "stack", "index", "slice_scatter")):
             t = next((a for a in args if torch.is_tensor(a)), None)
-            if t is not None and (t.numel() <= 4096 or "copy" in name or "clone" in name):
+            if t is not None and (t.numel() <= 4096 or "copy" in name or "clone" in name or "add" in name or "mul" in name):
                 fr = [f"{os.path.basename(f.filename)}:{f.lineno}" for f in traceback.extract_stack()[:-1]
                       if "/root/repo" in f.filename or "openess_amd" in f.filename][-3:]
                 cnt[(name, str(t.device), tuple(t.shape), " <- ".join(fr))] += 1
