@@ -1224,6 +1224,38 @@ def conv2d_wgrad(x, gy, Cout, Cin, R, S, stride=1, pad=0, dil=1):
     return dw
 
 
+class _GlobalAvgPool(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d(1) on a channels_last bf16 map -> fp32 [B, C, 1, 1] (models/deeplabv3.py ASPPPooling): per-sample
+    channel sums straight from the bf16 map by the deterministic statistics kernel (G = B groups) -- no fp32 copy of the map;
+    the backward hands autograd the [B, C, 1, 1] quotient EXPANDED over H x W (stride 0, channels-last compatible), so the sum
+    with the other ASPP branches' gradients reads it as a broadcast instead of a materialised, NCHW-ordered tensor."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        xn = x.permute(0, 2, 3, 1)
+        B, H, W, C, ps = _nhwc_geom(xn)
+        st = torch.empty((2, B, C), dtype=torch.float32, device=x.device)
+        ws, wsn = _norm_partials(B, H * W, C, x.device)
+        _lib.check(lib.oess_norm_stats_nhwc_bf16(_ptr(xn), ps, B, H * W, C, _ptr(st[0]), _ptr(st[1]), _ptr(ws), wsn, _stream()),
+                   "oess_norm_stats_nhwc_bf16")
+        ctx.meta = (H, W, x.dtype)
+        return (st[0] * (1.0 / (H * W))).view(B, C, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        H, W, dtype = ctx.meta
+        return (g * (1.0 / (H * W))).to(dtype).expand(-1, -1, H, W)
+
+
+def global_avg_pool(x):
+    """Mean over H x W of a logical B x C x H x W channels_last bf16 tensor -> fp32 [B, C, 1, 1], differentiable."""
+    _need_gpu(x)
+    if x.dtype != torch.bfloat16 or x.stride(1) != 1:
+        raise ValueError("global_avg_pool needs a channels_last bf16 tensor")
+    return _GlobalAvgPool.apply(x)
+
+
 def channel_sum(x_nhwc):
     """Per-channel sum over all pixels of an NHWC bf16 view (bias gradient) -> fp32 [C]."""
     lib = _lib.load()

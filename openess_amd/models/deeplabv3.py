@@ -60,7 +60,10 @@ class ASPPPooling(nn.Sequential):
 
     def forward(self, x, out=None):
         size = x.shape[-2:]
-        y = x.float().mean(dim=(2, 3), keepdim=True)                       # AdaptiveAvgPool2d(1)
+        if x.is_cuda and x.dtype == torch.bfloat16 and x.stride(1) == 1:
+            y = hip.global_avg_pool(x)                                     # AdaptiveAvgPool2d(1) without an fp32 copy of the map
+        else:
+            y = x.float().mean(dim=(2, 3), keepdim=True)
         y = torch.matmul(y.flatten(1), self[1].weight.flatten(1).t())[:, :, None, None]   # B x C x 1 x 1: a GEMV, not a conv
         y = F.relu(self[2](y))
         y = y.to(x.dtype).expand(-1, -1, size[0], size[1])                 # bilinear from 1x1 == broadcast

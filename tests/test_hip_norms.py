@@ -202,3 +202,20 @@ def test_batch_norm_train_fwd_bwd(relu, with_res):
     np.testing.assert_allclose(bn.bias.grad.cpu().numpy(), ref_bn.bias.grad.cpu().numpy(), rtol=2e-2, atol=5e-2)
     if with_res:
         np.testing.assert_allclose(res.grad.float().cpu().numpy(), rr.grad.cpu().numpy(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("shape", [(8, 2048, 28, 40), (2, 64, 7, 5)])
+def test_global_avg_pool_fwd_bwd(shape):
+    """nn.AdaptiveAvgPool2d(1) of ASPPPooling (models/deeplabv3.py) on the bf16 map: values vs the fp32 mean of the same bf16
+    numbers; the gradient is the broadcast quotient (an expanded view: no H x W tensor is materialised)."""
+    from openess_amd import hip
+    torch.manual_seed(1)
+    x = cl(torch.randn(*shape, device="cuda")).requires_grad_(True)
+    y = hip.global_avg_pool(x)
+    assert y.shape == (shape[0], shape[1], 1, 1) and y.dtype == torch.float32
+    ref = x.detach().float().mean(dim=(2, 3), keepdim=True)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    g = torch.randn_like(y)
+    (gx,) = torch.autograd.grad(y, x, g)
+    assert gx.stride(2) == 0 and gx.stride(3) == 0
+    np.testing.assert_allclose(gx.float().cpu().numpy(), (g / (shape[2] * shape[3])).bfloat16().float().expand(*shape).cpu().numpy(), rtol=0, atol=0)
