@@ -88,6 +88,10 @@ class PackedWeight:
             w = pw._wref() if pw._wref is not None else None
             if w is None or pw.packed is None or not w.is_cuda or w._version == pw.key[0]:
                 continue
+            if w.dtype != torch.float32 or not w.is_contiguous() or w.device != pw.packed.device:
+                pw._wref = None              # no longer a plain operand (module cast / moved): get() repacks it on its own
+                cls._registry.discard(pw)
+                continue
             members.append((pw, w))
             Cout, Cin, R, S = w.shape
             rows[0].append((w.data_ptr(), pw.packed.data_ptr(), Cout, Cin, R, S, 0, nblk[0]))
