@@ -558,6 +558,19 @@ def main():
             out["train_loop"]["vs_headline"] = round(out["train_loop"]["value"] / out["value"], 3)
         except Exception as e:      # never cost the headline
             out["train_loop"] = {"error": repr(e)[:300]}
+    if rank == 0 and extras and world == 1 and a.workload == "frame2voxel_pixel_distill":
+        # BASELINE configs[2] (openess_trainer full path) and configs[4] (fine-tune / linear-probe): the stage-2/3 trainers and
+        # OpenESSModel built through train.py's dispatch at the BASELINE size, train_step on a resident batch (tools/bench_stage2.py)
+        try:
+            torch.cuda.empty_cache()
+            import contextlib
+            if os.path.join(ROOT, "tools") not in sys.path:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_stage2
+            with contextlib.redirect_stdout(sys.stderr):
+                out["configs"].update({"stage2:" + k: v for k, v in bench_stage2.measure(steps=max(10, a.steps // 5)).items()})
+        except Exception as e:      # never cost the headline
+            out["configs"]["stage2_error"] = repr(e)[:300]
     if rank == 0:
         if world == 1 and not a.no_pmc and out["roofline"] is not None:
             torch.cuda.empty_cache()
