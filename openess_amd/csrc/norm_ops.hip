@@ -253,6 +253,80 @@ __global__ __launch_bounds__(THREADS) void in_bwd_apply_kernel(const uint16_t* _
     }
 }
 
+// BatchNorm backward, second half, for C % 64 == 0 and <= 512 partial rows: the fixed-order reduction of stats_kernel<1>'s
+// partials AND the apply pass in ONE launch (a frame2recon / fine-tune step has 59 BatchNorm backwards: 59 fewer launches).
+// Workgroup (64-channel group x, pixel chunk y) first adds the partial rows of ITS 64 channels -- same order as
+// partials_reduce_kernel (chunk lane tl adds rows tl, tl + 16, ... in double, the 16 lane sums are added 0..15), so d(beta),
+// d(gamma) and dx are bit-identical to the three-launch path; chunk 0 publishes d(beta) / d(gamma).  Redundant work per
+// workgroup: chunks x 512 bytes of L2-resident partials.  Then 8 lanes own a pixel's 64 channels (one 16-byte access per tensor).
+__global__ __launch_bounds__(THREADS) void bn_bwd_reduce_apply_kernel(const float* __restrict__ part, int chunks, int C,
+                                                                      const uint16_t* __restrict__ x, int64_t xps,
+                                                                      const uint16_t* __restrict__ dy, int64_t dps,
+                                                                      const uint16_t* __restrict__ yout, int64_t yps,
+                                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                      const float* __restrict__ gamma, int relu, int64_t pixels, int64_t ppc,
+                                                                      float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                                      uint16_t* __restrict__ dx, int64_t gps,
+                                                                      uint16_t* __restrict__ dres, int64_t drps) {
+    __shared__ double red[16][64][2];
+    __shared__ float s_a1[64], s_a2[64];
+    const int cg = blockIdx.x * 64;
+    {
+        const int c4 = (threadIdx.x & 15) * 4, tl = threadIdx.x >> 4;
+        double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+        const float* p0 = part + cg + c4;
+#pragma unroll 4
+        for (int t = tl; t < chunks; t += 16) {
+            const float4 u = *reinterpret_cast<const float4*>(p0 + ((size_t)t * 2) * C);
+            const float4 w = *reinterpret_cast<const float4*>(p0 + ((size_t)t * 2 + 1) * C);
+            a1[0] += (double)u.x; a1[1] += (double)u.y; a1[2] += (double)u.z; a1[3] += (double)u.w;
+            a2[0] += (double)w.x; a2[1] += (double)w.y; a2[2] += (double)w.z; a2[3] += (double)w.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red[tl][c4 + k][0] = a1[k]; red[tl][c4 + k][1] = a2[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double s1 = red[0][threadIdx.x][0], s2 = red[0][threadIdx.x][1];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { s1 += red[k][threadIdx.x][0]; s2 += red[k][threadIdx.x][1]; }
+        const float f1 = (float)s1, f2 = (float)s2;                  // d(beta), d(gamma): the fp32 values the apply pass uses
+        s_a1[threadIdx.x] = f1; s_a2[threadIdx.x] = f2;
+        if (blockIdx.y == 0) { dbeta[cg + threadIdx.x] = f1; dgamma[cg + threadIdx.x] = f2; }
+    }
+    __syncthreads();
+    const int sub = threadIdx.x & 7, pl = threadIdx.x >> 3;           // 8 lanes per pixel, 32 pixels per iteration
+    const int c0 = cg + sub * 8;
+    const float invn = 1.0f / (float)pixels;
+    float mu[8], rs[8], a1[8], a2[8], gr[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mu[k] = mean[c0 + k]; rs[k] = rstd[c0 + k];
+        a1[k] = s_a1[sub * 8 + k] * invn; a2[k] = s_a2[sub * 8 + k] * invn;
+        gr[k] = (gamma ? gamma[c0 + k] : 1.0f) * rs[k];
+    }
+    const int64_t p_beg = (int64_t)blockIdx.y * ppc;
+    int64_t p_end = p_beg + ppc;
+    if (p_end > pixels) p_end = pixels;
+    for (int64_t pix = p_beg + pl; pix < p_end; pix += 32) {
+        Pack8 v, d, yo;
+        float od[8], og[8];
+        v.q = *reinterpret_cast<const uint4*>(x + pix * xps + c0);
+        d.q = *reinterpret_cast<const uint4*>(dy + pix * dps + c0);
+        if (relu && yout) yo.q = *reinterpret_cast<const uint4*>(yout + pix * yps + c0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float xh = (bf16_to_f32(v.h[k]) - mu[k]) * rs[k];
+            float gg = bf16_to_f32(d.h[k]);
+            if (relu && !(yout ? bf16_to_f32(yo.h[k]) > 0.f : xh > 0.f)) gg = 0.f;
+            od[k] = gr[k] * (gg - a1[k] - xh * a2[k]);
+            og[k] = gg;
+        }
+        *reinterpret_cast<uint4*>(dx + pix * gps + c0) = pack_bf16x8(od);
+        if (dres) *reinterpret_cast<uint4*>(dres + pix * drps + c0) = pack_bf16x8(og);
+    }
+}
+
 // nearest x2: out[b, 2y+dy, 2x+dx, :] = in[b, y, x, :]   (F.interpolate(scale_factor=2, mode='nearest'))
 __global__ __launch_bounds__(THREADS) void up2_kernel(const uint16_t* __restrict__ in, int64_t ips, int B, int H, int W,
                                                       int C, uint16_t* __restrict__ out, int64_t ops) {
@@ -791,6 +865,24 @@ int oess_batchnorm_bwd_nhwc_bf16(const void* x, long long x_pix_stride, const vo
     const int chunks = launch_stats<1>(st, x, x_pix_stride, dy, dy_pix_stride, mean, rstd, relu, 1, pixels, C, partials, partials_bytes,
                                        y_out, y_pix_stride);
     if (!chunks) return OESS_EINVAL;
+    static const bool three_launches = [] { const char* e = getenv("OESS_BN_BWD_THREE_LAUNCHES"); return e && e[0] == '1'; }();   // A/B only
+    if ((C & 63) == 0 && chunks <= 512 && !three_launches) {
+        // reduce + apply in one launch (bit-identical to the path below)
+        const int groups = C / 64;
+        int64_t pch = (2048 + groups - 1) / groups;                     // ~2048 workgroups, >= 128 pixels each
+        const int64_t maxc = (pixels + 127) / 128;
+        if (pch > maxc) pch = maxc;
+        if (pch < 1) pch = 1;
+        int64_t ppc = (pixels + pch - 1) / pch;
+        ppc = (ppc + 31) / 32 * 32;
+        pch = (pixels + ppc - 1) / ppc;
+        hipLaunchKernelGGL(bn_bwd_reduce_apply_kernel, dim3((unsigned)groups, (unsigned)pch), dim3(THREADS), 0, st, partials, chunks, C,
+                           (const uint16_t*)x, (int64_t)x_pix_stride, (const uint16_t*)dy, (int64_t)dy_pix_stride,
+                           (const uint16_t*)y_out, (int64_t)y_pix_stride, mean, rstd, gamma, relu, (int64_t)pixels, ppc, dbeta, dgamma,
+                           (uint16_t*)dx, (int64_t)dx_pix_stride, (uint16_t*)dresidual, (int64_t)dres_pix_stride);
+        OESS_HIP(hipGetLastError());
+        return OESS_OK;
+    }
     hipLaunchKernelGGL(partials_reduce_kernel<false>, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, st, partials, chunks, 1, C, dbeta,
                        dgamma, 1.f, 0.f, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(in_bwd_apply_kernel, apply_grid(pixels, 1, C), dim3(THREADS), 0, st, (const uint16_t*)x,

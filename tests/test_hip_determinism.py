@@ -123,3 +123,39 @@ def test_pretrain_step_bit_repeatable(option, contr):
         assert torch.equal(runs[0][1][n], runs[1][1][n]), n
         a, b = runs[0][2][n], runs[1][2][n]
         assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), n
+
+
+def test_batchnorm_backward_merged_launch_equals_three_launch_path(tmp_path):
+    """oess_batchnorm_bwd_nhwc_bf16: for C % 64 == 0 the fixed-order reduction of the partial sums and the apply pass run in one
+    launch (bn_bwd_reduce_apply_kernel); d(gamma), d(beta), dx and d(residual) must be bit-identical to the three-launch path,
+    which a child process runs with OESS_BN_BWD_THREE_LAUNCHES=1 on the same tensors."""
+    import os
+    import subprocess
+    import sys
+    script = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from openess_amd import hip
+torch.manual_seed(0)
+outs = {}
+for tag, (B, C, H, W, relu, res) in {"a": (8, 1024, 28, 40, True, True), "b": (2, 64, 37, 53, True, False), "c": (3, 192, 9, 11, False, False),
+                                     "d": (8, 256, 110, 160, True, True)}.items():
+    bn = torch.nn.BatchNorm2d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_()
+    x = torch.randn(B, C, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    r = torch.randn(B, C, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True) if res else None
+    y = hip.batch_norm_train(x, bn, relu=relu, residual=r)
+    g = torch.randn(B, C, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    y.backward(g)
+    outs[tag] = [x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()] + ([r.grad.clone()] if res else [])
+torch.save({k: [t.cpu() for t in v] for k, v in outs.items()}, sys.argv[1])
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for name, env in (("merged", {}), ("three", {"OESS_BN_BWD_THREE_LAUNCHES": "1"})):
+        out = str(tmp_path / f"{name}.pt")
+        subprocess.run([sys.executable, "-c", script, out], check=True, env=dict(os.environ, **env), timeout=600)
+        got[name] = torch.load(out)
+    for tag in got["merged"]:
+        for a, b in zip(got["merged"][tag], got["three"][tag]):
+            assert torch.equal(a, b), tag
