@@ -60,7 +60,7 @@ class ASPPPooling(nn.Sequential):
 
     def forward(self, x, out=None):
         size = x.shape[-2:]
-        if x.is_cuda and x.dtype == torch.bfloat16 and x.stride(1) == 1:
+        if x.is_cuda and x.dtype == torch.bfloat16 and x.stride(1) == 1 and x.shape[1] % 8 == 0 and x.shape[1] <= 2048:
             y = hip.global_avg_pool(x)                                     # AdaptiveAvgPool2d(1) without an fp32 copy of the map
         else:
             y = x.float().mean(dim=(2, 3), keepdim=True)
