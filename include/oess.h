@@ -35,7 +35,7 @@ typedef void* oess_stream_t; /* hipStream_t */
 /* Library / device identification.  OESS_ABI_VERSION is bumped whenever a signature of this header changes or an entry point
  * is removed; oess_abi_version() returns the value the library was built with and the ctypes binding (openess_amd/_lib.py,
  * ABI_VERSION) refuses a library whose value differs. */
-#define OESS_ABI_VERSION 5
+#define OESS_ABI_VERSION 6
 int oess_abi_version(void);
 const char* oess_build_info(void);           /* "liboess <ver> gfx950 hipcc <ver>" */
 const char* oess_strerror(int code);
@@ -456,6 +456,17 @@ size_t oess_png_decode_scratch_bytes(long long total_file_bytes, int n_images, i
 int oess_png_decode_gray8_batch(const uint8_t* files, const int64_t* offsets, long long total_file_bytes, int n_images, int H, int W,
                                 const uint8_t* flip, int64_t* out, void* scratch, size_t scratch_bytes, const int64_t* scratch_offsets,
                                 int* status, oess_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Linear probe: nn.Conv2d(K, K, 1) on the fp32 logits (models/style_networks.py:113-133,169-170; models/deeplabv3.py:162-170,
+ * 186-187), K <= 32.  x, y, grad_*: dense NHWC fp32 [P x K]; w: [K x K] (Conv2d.weight viewed [out, in]); bias nullable in the
+ * forward.  Backward: grad_x nullable (frozen producer); grad_w / grad_bias from per-workgroup double partial rows added in a fixed order (bit-repeatable);
+ * partials: oess_linear_probe_partials_bytes(K) bytes of caller scratch.
+ * ------------------------------------------------------------------------------------------ */
+size_t oess_linear_probe_partials_bytes(int K);
+int oess_linear_probe_fwd_f32(const float* x, const float* w, const float* bias, long long P, int K, float* y, oess_stream_t stream);
+int oess_linear_probe_bwd_f32(const float* x, const float* grad_y, const float* w, long long P, int K, float* grad_x, float* grad_w,
+                              float* grad_bias, void* partials, size_t partials_bytes, oess_stream_t stream);
 
 #ifdef __cplusplus
 }

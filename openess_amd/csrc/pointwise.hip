@@ -83,6 +83,118 @@ __global__ __launch_bounds__(THREADS) void norm_to_nhwc8_kernel(const float* __r
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Linear probe: nn.Conv2d(K, K, 1) on the fp32 logits (models/style_networks.py:169-170, models/deeplabv3.py:186-187), K <= 32.
+// Dense NHWC fp32 rows [P][K] (K = 11: 44-byte rows), so everything moves through LDS tiles of LP_TP pixels with coalesced
+// 4-byte accesses.  MIOpen resolved this layer's weight gradient to a naive kernel (565 ms on first use) and its bias gradient
+// to a 2.9 ms ATen reduction at 8 x 440 x 640.
+//   forward : y[p][j] = b[j] + sum_i W[j][i] x[p][i]
+//   backward: gx[p][i] = sum_j W[j][i] g[p][j];  gW[j][i] = sum_p g[p][j] x[p][i];  gb[j] = sum_p g[p][j]
+//             -- per-workgroup partial rows [K*K + K] in double, added in a fixed order by the finalize kernel (bit-repeatable).
+// ---------------------------------------------------------------------------------------------
+constexpr int LP_TP = 256;                  // pixels per tile = threads per workgroup
+constexpr int LP_KMAX = 32;
+constexpr int LP_MAX_ROWS = 1024;           // backward workgroups = partial rows
+
+__global__ __launch_bounds__(LP_TP) void probe_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, int64_t P, int K, float* __restrict__ y) {
+    extern __shared__ float lp_s[];                      // [K*K] weights, [K] bias, [LP_TP * K] tile (in place: x then y)
+    float* sw = lp_s; float* sb = sw + K * K; float* tile = sb + K;
+    for (int i = threadIdx.x; i < K * K; i += LP_TP) sw[i] = w[i];
+    for (int i = threadIdx.x; i < K; i += LP_TP) sb[i] = b ? b[i] : 0.f;
+    for (int64_t p0 = (int64_t)blockIdx.x * LP_TP; p0 < P; p0 += (int64_t)gridDim.x * LP_TP) {
+        const int np = (int)((P - p0 < LP_TP) ? P - p0 : LP_TP);
+        __syncthreads();
+        for (int i = threadIdx.x; i < np * K; i += LP_TP) tile[i] = x[p0 * K + i];
+        __syncthreads();
+        float out[LP_KMAX];
+        if ((int)threadIdx.x < np) {
+            const float* r = tile + threadIdx.x * K;
+            for (int j = 0; j < K; ++j) {
+                float acc = sb[j];
+                for (int i = 0; i < K; ++i) acc += sw[j * K + i] * r[i];
+                out[j] = acc;
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < np)
+            for (int j = 0; j < K; ++j) tile[threadIdx.x * K + j] = out[j];
+        __syncthreads();
+        for (int i = threadIdx.x; i < np * K; i += LP_TP) y[p0 * K + i] = tile[i];
+    }
+}
+
+__global__ __launch_bounds__(LP_TP) void probe_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                          const float* __restrict__ w, int64_t P, int K, float* __restrict__ gx,
+                                                          double* __restrict__ part) {
+    extern __shared__ float lp_s[];                      // [K*K] weights, [LP_TP * K] x tile, [LP_TP * K] g tile (gx written over it)
+    float* sw = lp_s; float* tx = sw + K * K; float* tg = tx + LP_TP * K;
+    for (int i = threadIdx.x; i < K * K; i += LP_TP) sw[i] = w[i];
+    const int nacc = K * K + K;                          // pair t < K*K: (j, i) = (t / K, t % K); t >= K*K: bias j = t - K*K
+    double acc[(LP_KMAX * LP_KMAX + LP_KMAX + LP_TP - 1) / LP_TP];
+    for (int a = 0; a < (int)(sizeof(acc) / sizeof(acc[0])); ++a) acc[a] = 0.0;
+    for (int64_t p0 = (int64_t)blockIdx.x * LP_TP; p0 < P; p0 += (int64_t)gridDim.x * LP_TP) {
+        const int np = (int)((P - p0 < LP_TP) ? P - p0 : LP_TP);
+        __syncthreads();
+        for (int i = threadIdx.x; i < np * K; i += LP_TP) { tx[i] = x[p0 * K + i]; tg[i] = g[p0 * K + i]; }
+        __syncthreads();
+        // weight / bias gradient partials of this tile: thread t owns accumulators t, t + 256, ...; pixels in order
+        for (int a = 0, t = threadIdx.x; t < nacc; t += LP_TP, ++a) {
+            // four interleaved running sums (pixels p % 4), joined in a fixed order: independent LDS reads in flight
+            const bool pair = t < K * K;
+            const int j = pair ? t / K : t - K * K;
+            const float* pg = tg + j;
+            const float* px = pair ? tx + (t - j * K) : nullptr;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int p = 0;
+            if (pair) {
+                for (; p + 4 <= np; p += 4) {
+                    s0 += pg[(p + 0) * K] * px[(p + 0) * K];
+                    s1 += pg[(p + 1) * K] * px[(p + 1) * K];
+                    s2 += pg[(p + 2) * K] * px[(p + 2) * K];
+                    s3 += pg[(p + 3) * K] * px[(p + 3) * K];
+                }
+                for (; p < np; ++p) s0 += pg[p * K] * px[p * K];
+            } else {
+                for (; p + 4 <= np; p += 4) {
+                    s0 += pg[(p + 0) * K]; s1 += pg[(p + 1) * K]; s2 += pg[(p + 2) * K]; s3 += pg[(p + 3) * K];
+                }
+                for (; p < np; ++p) s0 += pg[p * K];
+            }
+            acc[a] += (double)((s0 + s1) + (s2 + s3));
+        }
+        if (!gx) continue;                               // frozen producer (the linear-probe protocol): no input gradient
+        float out[LP_KMAX];
+        if ((int)threadIdx.x < np) {
+            const float* r = tg + threadIdx.x * K;
+            for (int i = 0; i < K; ++i) {
+                float v = 0.f;
+                for (int j = 0; j < K; ++j) v += sw[j * K + i] * r[j];
+                out[i] = v;
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < np)
+            for (int i = 0; i < K; ++i) tg[threadIdx.x * K + i] = out[i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < np * K; i += LP_TP) gx[p0 * K + i] = tg[i];
+    }
+    for (int a = 0, t = threadIdx.x; t < nacc; t += LP_TP, ++a) part[(size_t)blockIdx.x * nacc + t] = acc[a];
+}
+
+// one wave per accumulator: lane l adds rows l, l + 64, ... in order, then a fixed butterfly over the 64 lanes
+__global__ __launch_bounds__(256) void probe_bwd_finalize_kernel(const double* __restrict__ part, int rows, int K,
+                                                                 float* __restrict__ gw, float* __restrict__ gb) {
+    const int nacc = K * K + K;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= nacc) return;
+    double s = 0.0;
+    for (int r = lane; r < rows; r += 64) s += part[(size_t)r * nacc + t];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) { if (t < K * K) gw[t] = (float)s; else gb[t - K * K] = (float)s; }
+}
+
 }  // namespace
 
 extern "C" {
@@ -112,6 +224,33 @@ int oess_event_slice_to_nhwc8_bf16(const float* in, int B, int Ctot, int c0, int
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(norm_to_nhwc8_kernel, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, in, B, Ctot, c0, Cs,
                        (int64_t)HW, stats, normalize, (uint16_t*)out_nhwc8);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+
+size_t oess_linear_probe_partials_bytes(int K) { return (K > 0 && K <= LP_KMAX) ? (size_t)LP_MAX_ROWS * (K * K + K) * sizeof(double) : 0; }
+
+int oess_linear_probe_fwd_f32(const float* x, const float* w, const float* bias, long long P, int K, float* y, oess_stream_t stream) {
+    if (!x || !w || !y || P <= 0 || K <= 0 || K > LP_KMAX) return OESS_EINVAL;
+    long long g = (P + LP_TP - 1) / LP_TP;
+    if (g > 4096) g = 4096;
+    const size_t lds = ((size_t)K * K + K + (size_t)LP_TP * K) * sizeof(float);
+    hipLaunchKernelGGL(probe_fwd_kernel, dim3((unsigned)g), dim3(LP_TP), lds, (hipStream_t)stream, x, w, bias, (int64_t)P, K, y);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_linear_probe_bwd_f32(const float* x, const float* grad_y, const float* w, long long P, int K, float* grad_x, float* grad_w,
+                              float* grad_bias, void* partials, size_t partials_bytes, oess_stream_t stream) {
+    if (!x || !grad_y || !w || !grad_w || !grad_bias || !partials || P <= 0 || K <= 0 || K > LP_KMAX) return OESS_EINVAL;
+    if (partials_bytes < oess_linear_probe_partials_bytes(K)) return OESS_ENOMEM;
+    long long g = (P + LP_TP - 1) / LP_TP;
+    if (g > LP_MAX_ROWS) g = LP_MAX_ROWS;
+    const size_t lds = ((size_t)K * K + (size_t)2 * LP_TP * K) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(probe_bwd_kernel, dim3((unsigned)g), dim3(LP_TP), lds, st, x, grad_y, w, (int64_t)P, K, grad_x, (double*)partials);
+    hipLaunchKernelGGL(probe_bwd_finalize_kernel, dim3((unsigned)((K * K + K + 3) / 4)), dim3(256), 0, st, (const double*)partials, (int)g, K, grad_w, grad_bias);
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }

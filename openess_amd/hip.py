@@ -1256,6 +1256,53 @@ def global_avg_pool(x):
     return _GlobalAvgPool.apply(x)
 
 
+class _LinearProbe(torch.autograd.Function):
+    """nn.Conv2d(K, K, 1) on the fp32 channels_last logits (models/style_networks.py:169-170, models/deeplabv3.py:186-187):
+    per-pixel K x K product; weight / bias gradients from fixed-order double partial rows (bit-repeatable)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        B, K, H, W = x.shape
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        w2 = weight.detach().reshape(K, K).contiguous()
+        _lib.check(lib.oess_linear_probe_fwd_f32(_ptr(x), _ptr(w2), _ptr(bias.detach()) if bias is not None else None, B * H * W, K,
+                                                 _ptr(y), _stream()), "oess_linear_probe_fwd_f32")
+        ctx.save_for_backward(x, w2)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, w2 = ctx.saved_tensors
+        B, K, H, W = x.shape
+        if not _dense_cl(g):
+            g = g.contiguous(memory_format=torch.channels_last)
+        gx = torch.empty_like(x, memory_format=torch.channels_last) if ctx.needs_input_grad[0] else None
+        gw = torch.empty((K, K, 1, 1), dtype=torch.float32, device=x.device)
+        gb = torch.empty((K,), dtype=torch.float32, device=x.device)
+        nb = lib.oess_linear_probe_partials_bytes(K)
+        ws = _workspace(nb, x.device, tag=("linear_probe", torch.cuda.current_stream(x.device).cuda_stream))
+        _lib.check(lib.oess_linear_probe_bwd_f32(_ptr(x), _ptr(g), _ptr(w2), B * H * W, K, _ptr(gx) if gx is not None else None,
+                                                 _ptr(gw), _ptr(gb), _ptr(ws), nb, _stream()), "oess_linear_probe_bwd_f32")
+        return gx, gw, (gb if ctx.has_bias else None)
+
+
+def _dense_cl(t):
+    B, C, H, W = t.shape
+    return t.dtype == torch.float32 and t.stride() == (H * W * C, 1, W * C, C)
+
+
+def linear_probe(x, conv):
+    """`conv(x)` for the linear-probe nn.Conv2d(K, K, 1) on fp32 channels_last logits [B, K, H, W], differentiable."""
+    _need_gpu(x)
+    K = x.shape[1]
+    if not _dense_cl(x) or K > 32 or tuple(conv.weight.shape) != (K, K, 1, 1) or conv.weight.dtype != torch.float32:
+        raise ValueError("linear_probe needs dense channels_last fp32 logits [B, K <= 32, H, W] and a K x K 1x1 convolution")
+    return _LinearProbe.apply(x, conv.weight, conv.bias)
+
+
 def channel_sum(x_nhwc):
     """Per-channel sum over all pixels of an NHWC bf16 view (bias gradient) -> fp32 [C]."""
     lib = _lib.load()

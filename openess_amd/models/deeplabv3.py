@@ -177,5 +177,5 @@ class deeplabv3_resnet50(nn.Module):
         # without a second rounding): what the superpixel pooling / InfoNCE / L1 consistency losses consume
         feats = hip.bilinear_resize(feats.float() if self.feats_fp32 else feats, size=input_shape, align_corners=False)
         if self.if_linear_probing:
-            logist = self.linear_probe(logist)
+            logist = hip.linear_probe(logist, self.linear_probe)
         return logist, feats

@@ -159,6 +159,6 @@ class SemSegE2VID(nn.Module):
                                          self.decoder_ch512[0].weight, self.decoder_ch512[0].bias, self.text_embeddings))
         logits = engine.conv2d_train(x, wf, bf, self._pw_head, 1, out_f32=True, ver=ver)
         if self.if_linear_probing:
-            logits = self.linear_probe(logits)
+            logits = hip.linear_probe(logits, self.linear_probe)
         self.update_skip_dict(out, logits, sz_in)
         return out, x_ch256

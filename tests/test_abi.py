@@ -90,6 +90,9 @@ def test_round4_entry_points_validate_arguments_on_the_host():
     assert lib.oess_segment_mean_fwd_workspace_bytes(800, 256) >= 800 * 256 * 16 + 800 * 4 + 4
     assert lib.oess_segment_mean_fwd_workspace_bytes(0, 256) == 0
     assert lib.oess_segment_mean_fwd(None, 0, None, 100, 100, 100, 256, 100, None, None, None, 0, None) == -22
+    assert lib.oess_linear_probe_partials_bytes(11) == 1024 * (121 + 11) * 8 and lib.oess_linear_probe_partials_bytes(33) == 0
+    assert lib.oess_linear_probe_fwd_f32(None, None, None, 100, 11, None, None) == -22
+    assert lib.oess_linear_probe_bwd_f32(None, None, None, 100, 11, None, None, None, None, 0, None) == -22
 
 
 def test_collate_keeps_undecoded_png_maps_as_one_byte_stream():

@@ -219,3 +219,38 @@ def test_global_avg_pool_fwd_bwd(shape):
     (gx,) = torch.autograd.grad(y, x, g)
     assert gx.stride(2) == 0 and gx.stride(3) == 0
     np.testing.assert_allclose(gx.float().cpu().numpy(), (g / (shape[2] * shape[3])).bfloat16().float().expand(*shape).cpu().numpy(), rtol=0, atol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,K,H,W,frozen", [(2, 11, 37, 53, False), (1, 6, 8, 300, True), (2, 19, 64, 65, False), (1, 32, 5, 7, False)])
+def test_linear_probe_matches_conv2d(B, K, H, W, frozen):
+    """hip.linear_probe = nn.Conv2d(K, K, 1) on the fp32 logits (reference models/style_networks.py:169-170): forward within
+    fp32 re-association of F.conv2d (1e-5 relative), weight / bias / input gradients within 1e-4 relative of the fp64 result,
+    and bit-identical between two runs (fixed-order partial rows)."""
+    from openess_amd import hip
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(K * 100 + W)
+    conv = torch.nn.Conv2d(K, K, 1).to(dev)
+    x = torch.randn(B, K, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(not frozen)
+    gy = torch.randn(B, K, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    y = hip.linear_probe(x, conv)
+    assert y.is_contiguous(memory_format=torch.channels_last) or K == 1
+    y.backward(gy)
+    got = (y.detach().clone(), conv.weight.grad.clone(), conv.bias.grad.clone(), None if frozen else x.grad.clone())
+    conv.zero_grad(); x.grad = None
+    y2 = hip.linear_probe(x, conv); y2.backward(gy)
+    assert torch.equal(y2, got[0]) and torch.equal(conv.weight.grad, got[1]) and torch.equal(conv.bias.grad, got[2])
+    xd = x.detach().double().requires_grad_(True)
+    wd = conv.weight.detach().double().requires_grad_(True)
+    bd = conv.bias.detach().double().requires_grad_(True)
+    yd = torch.nn.functional.conv2d(xd, wd, bd)
+    yd.backward(gy.double())
+
+    def rel(a, b):
+        return float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    assert rel(got[0], yd.detach()) < 1e-5
+    assert rel(got[1], wd.grad) < 1e-4 and rel(got[2], bd.grad) < 1e-4
+    if not frozen:
+        assert rel(got[3], xd.grad) < 1e-5
+    else:
+        assert x.grad is None
