@@ -241,10 +241,11 @@ class _SegmentMean(torch.autograd.Function):
                                              _ptr(ws), ws_bytes, _stream()), "oess_segment_mean_fwd")
         ctx.save_for_backward(ids, cnt)
         ctx.meta = (P, Cf, pps, sps, S, feat_pm.dtype)
-        return k
+        ctx.mark_non_differentiable(cnt)
+        return k, cnt
 
     @staticmethod
-    def backward(ctx, gk):
+    def backward(ctx, gk, _gcnt):
         lib = _lib.load()
         ids, cnt = ctx.saved_tensors
         P, Cf, pps, sps, S, dtype = ctx.meta
@@ -265,18 +266,54 @@ def segment_mean(feat_pm, ids, pixels_per_sample, superpixel_size, S):
     if feat_pm.shape[1] % 4:
         raise ValueError("channel count must be a multiple of 4")
     ids = ids.reshape(-1).contiguous().to(torch.int64)
-    return _SegmentMean.apply(feat_pm, ids, int(pixels_per_sample), int(superpixel_size), int(S))
+    return _SegmentMean.apply(feat_pm, ids, int(pixels_per_sample), int(superpixel_size), int(S))[0]
 
 
-def superpixel_pool(feat_nchw, superpixels, superpixel_size, S=None):
+def superpixel_pool(feat_nchw, superpixels, superpixel_size, S=None, with_count=False):
     """Drop-in for the inline block of training/pretrain_trainer.py:445-465.  feat_nchw is logically
-    B x C x H x W (any memory format; channels_last is free), superpixels B x H x W int64."""
+    B x C x H x W (any memory format; channels_last is free), superpixels B x H x W int64.
+    with_count: also the fp32 pixel count of every row (not differentiable)."""
+    if isinstance(feat_nchw, PointwiseFeature):
+        return feat_nchw.pool(superpixels, superpixel_size, S)
     B, C, H, W = feat_nchw.shape
     if S is None:   # data-dependent size exactly like sparse_coo_tensor (costs one device sync)
         off = torch.arange(0, B * superpixel_size, superpixel_size, device=superpixels.device)[:, None, None]
         S = int((superpixels + off).max().item()) + 1
     pm = feat_nchw.permute(0, 2, 3, 1).contiguous().view(B * H * W, C)
-    return segment_mean(pm, superpixels, H * W, superpixel_size, S)
+    if not with_count:
+        return segment_mean(pm, superpixels, H * W, superpixel_size, S)
+    _need_gpu(pm, superpixels)
+    ids = superpixels.reshape(-1).contiguous().to(torch.int64)
+    return _SegmentMean.apply(pm, ids, H * W, int(superpixel_size), int(S))
+
+
+class PointwiseFeature:
+    """A full-resolution feature map that is a 1x1 convolution of `x` (SemSegE2VID's 256-channel `x_ch256 = decoder_ch256(x)`,
+    models/style_networks.py:166), kept as the pair (x, conv) because its only consumer in the pre-training step is the
+    superpixel mean of training/pretrain_trainer.py:445-465 -- and the mean commutes with the per-pixel affine map:
+        sum_p (W x_p + b) / (n + 1e-6)  =  W (sum_p x_p / (n + 1e-6)) + b n / (n + 1e-6).
+    Pooling the 32 input channels and applying the convolution to the S pooled rows gives the reference's result without the
+    8 x 256 x 440 x 640 tensor (1.15 GB in bf16), its convolution forward / input- / weight-gradient passes and the 256-channel
+    scatter / gather -- and without that tensor's bf16 rounding.  `materialize()` is the tensor itself for any other consumer."""
+
+    def __init__(self, x, conv):
+        self.x, self.conv = x, conv
+
+    @property
+    def shape(self):
+        B, _, H, W = self.x.shape
+        return torch.Size((B, self.conv.weight.shape[0], H, W))
+
+    def materialize(self):
+        return self.conv(self.x)
+
+    def pool(self, superpixels, superpixel_size, S=None):
+        k_in, cnt = superpixel_pool(self.x, superpixels, superpixel_size, S, with_count=True)
+        w = self.conv.weight.flatten(1).float()                                   # Cout x Cin
+        k = k_in @ w.t()
+        if self.conv.bias is not None:
+            k = k + (cnt / (cnt + 1e-6)).unsqueeze(1) * self.conv.bias.float()
+        return k
 
 
 # ------------------------------------------------------------------------------------------ K9

@@ -153,7 +153,11 @@ class SemSegE2VID(nn.Module):
         self.update_skip_dict(out, x, sz_in)
         x = hip.upsample2x_concat(x)
         x = self.decoder_scale_4(x)
-        x_ch256 = self.decoder_ch256[0](x) if self.materialize_ch256 else None
+        # 'pooled': the 256-channel map only feeds the superpixel mean, which commutes with the 1x1 convolution (hip.PointwiseFeature)
+        if self.materialize_ch256 == 'pooled':
+            x_ch256 = hip.PointwiseFeature(x, self.decoder_ch256[0])
+        else:
+            x_ch256 = self.decoder_ch256[0](x) if self.materialize_ch256 else None
         wf, bf = self._composed_head()
         ver = tuple(p._version for p in (self.decoder_ch256[0].weight, self.decoder_ch256[0].bias,
                                          self.decoder_ch512[0].weight, self.decoder_ch512[0].bias, self.text_embeddings))

@@ -18,6 +18,10 @@ from ..utils.optim import AdamW          # torch.optim.AdamW with its step on th
 
 
 class PretrainStep:
+    # frame2voxel + contrastive: the student's 256-channel map is only pooled over superpixels, and the mean commutes with its 1x1
+    # convolution (hip.PointwiseFeature); False = materialise the map as the reference does (A/B, tests)
+    pooled_student_features = True
+
     def __init__(self, config_option='frame2voxel', num_classes=11, img_size=(440, 640), nr_events_data=20,
                  nr_temporal_bins=5, if_spatial_contrastive=False, if_dense_clip_supervision=True, superpixel_size=100,
                  lr=5e-4, weight_task_loss=1.0, task_loss=('dice', 'cross_entropy'), output_stride=32, device='cuda',
@@ -43,7 +47,9 @@ class PretrainStep:
             self.input_width = math.ceil(img_size[1] / 8.0) * 8
             self.models_dict['front_sensor_b'] = self.front_end_sensor_b
             self.task_backend = SemSegE2VID(input_c=256, output_c=num_classes, skip_connect=True, skip_type='concat',
-                                            text_embeddings_path='', materialize_ch256=if_spatial_contrastive)
+                                            text_embeddings_path='',
+                                            materialize_ch256=('pooled' if self.pooled_student_features else True)
+                                            if if_spatial_contrastive else False)
             self.models_dict['back_end'] = self.task_backend
         elif config_option == 'frame2recon':
             self.model_recon = deeplabv3_resnet50(num_classes=num_classes, text_embeddings_path='',

@@ -332,3 +332,44 @@ def test_adamw_multi_tensor_matches_torch():
         assert float(sd_ref['state'][k]['step']) == float(sd_mine['state'][k]['step'])
         np.testing.assert_allclose(sd_mine['state'][k]['exp_avg_sq'].cpu().numpy(), sd_ref['state'][k]['exp_avg_sq'].cpu().numpy(), rtol=2e-6, atol=1e-12)
     mine.load_state_dict(sd_ref); ref.load_state_dict(sd_mine)         # interchangeable
+
+
+@pytest.mark.gpu
+def test_pointwise_feature_pool_equals_pooling_the_convolved_map():
+    """hip.PointwiseFeature.pool: superpixel mean of a 1x1 convolution = the convolution of the superpixel mean (plus the bias
+    times n / (n + 1e-6)), reference order training/pretrain_trainer.py:445-465 on models/style_networks.py:166's map.
+    Against float64 of the reference order: forward 2e-3 of the largest value (x itself is bf16; the materialised form adds a
+    second bf16 rounding and is checked at 1e-2), weight / bias / input gradients 1e-2; empty superpixels give exact zeros."""
+    from openess_amd import hip
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(77)
+    B, Cin, Cout, H, W, sps = 2, 32, 256, 40, 64, 100
+    conv = torch.nn.Conv2d(Cin, Cout, 1).to(dev)
+    x = torch.randn(B, Cin, H, W, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    sp = torch.randint(0, 60, (B, H, W), generator=g).to(dev)            # ids 60..99 stay empty
+    S = B * sps
+    gk = torch.randn(S, Cout, generator=g).to(dev)
+    k = hip.superpixel_pool(hip.PointwiseFeature(x, conv), sp, sps, S)
+    k.backward(gk)
+    got = (k.detach().clone(), conv.weight.grad.clone(), conv.bias.grad.clone(), x.grad.float().clone())
+    conv.zero_grad(); x.grad = None
+    # reference order in float64
+    xd = x.detach().double().requires_grad_(True)
+    wd = conv.weight.detach().double().requires_grad_(True)
+    bd = conv.bias.detach().double().requires_grad_(True)
+    y = torch.nn.functional.conv2d(xd, wd, bd).permute(0, 2, 3, 1).reshape(B * H * W, Cout)
+    ids = (sp + torch.arange(B, device=dev)[:, None, None] * sps).reshape(-1)
+    one = torch.zeros(S, B * H * W, dtype=torch.float64, device=dev)
+    one[ids, torch.arange(B * H * W, device=dev)] = 1.0
+    kd = (one @ y) / (one.sum(1, keepdim=True) + 1e-6)
+    kd.backward(gk.double())
+
+    def rel(a, b):
+        return float((a.double() - b).abs().max() / b.abs().max())
+    assert rel(got[0], kd.detach()) < 2e-3
+    empty = one.sum(1) == 0
+    assert bool(empty.any()) and float(got[0][empty].abs().max()) == 0.0
+    assert rel(got[1], wd.grad) < 1e-2 and rel(got[2], bd.grad) < 1e-2 and rel(got[3], xd.grad) < 1e-2
+    # the materialised path on the same inputs
+    k2 = hip.superpixel_pool(conv(x.detach().float()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last), sp, sps, S)
+    assert rel(k2.detach(), kd.detach()) < 1e-2
