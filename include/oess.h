@@ -35,7 +35,7 @@ typedef void* oess_stream_t; /* hipStream_t */
 /* Library / device identification.  OESS_ABI_VERSION is bumped whenever a signature of this header changes or an entry point
  * is removed; oess_abi_version() returns the value the library was built with and the ctypes binding (openess_amd/_lib.py,
  * ABI_VERSION) refuses a library whose value differs. */
-#define OESS_ABI_VERSION 6
+#define OESS_ABI_VERSION 7
 int oess_abi_version(void);
 const char* oess_build_info(void);           /* "liboess <ver> gfx950 hipcc <ver>" */
 const char* oess_strerror(int code);
@@ -467,6 +467,18 @@ size_t oess_linear_probe_partials_bytes(int K);
 int oess_linear_probe_fwd_f32(const float* x, const float* w, const float* bias, long long P, int K, float* y, oess_stream_t stream);
 int oess_linear_probe_bwd_f32(const float* x, const float* grad_y, const float* w, long long P, int K, float* grad_x, float* grad_w,
                               float* grad_bias, void* partials, size_t partials_bytes, oess_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backward of k = scatter_mean(F.normalize(nn.Upsample(bilinear)(x)), superpixels) as one node (models/image_model.py:121-143 +
+ * training/pretrain_trainer.py:445-465): feat = the saved normalised full-resolution map [B x Ho x Wo x C] bf16, inv_norm its
+ * 1 / max(|x|, eps) per pixel (both from oess_bilinear_l2norm_nhwc_bf16), ids raw superpixel ids [B*Ho*Wo], grad_k [S x C] fp32,
+ * count [S] (oess_segment_mean_fwd).  grad_in: [B x H x W x C] bf16.  C in {64, 128, 256, 512}.  Deterministic (gather form).
+ * ------------------------------------------------------------------------------------------ */
+size_t oess_bilinear_l2norm_pool_bwd_workspace_bytes(int B, int W, int C, int Ho, int S);
+int oess_bilinear_l2norm_pool_bwd_bf16(const void* feat, long long feat_pix_stride, const float* inv_norm, const int64_t* ids,
+                                       const float* grad_k, const float* count, int superpixel_size, int S, int B, int H, int W, int C,
+                                       int Ho, int Wo, int align_corners, float eps, void* workspace, size_t workspace_bytes,
+                                       void* grad_in, long long gin_pix_stride, oess_stream_t stream);
 
 #ifdef __cplusplus
 }

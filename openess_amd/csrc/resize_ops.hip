@@ -215,6 +215,91 @@ __global__ __launch_bounds__(THREADS) void resize_bwd_y_kernel(const float* __re
     }
 }
 
+// ---- superpixel mean of L2-normalised, bilinearly upsampled features: the backward of
+//      k = scatter_mean(normalize(upsample(x)))            models/image_model.py:121-143 + training/pretrain_trainer.py:445-465
+// in ONE pass over the saved normalised map instead of three full-resolution round trips (row gather of gk / (n + 1e-6) -> L2
+// adjoint -> x pass of the bilinear adjoint: 1.15 GB written, read, written and read again at 8 x 256 x 440 x 640).
+// Every output pixel's gradient row is a row of the S x C quotient table (L2-resident), so the x pass of the bilinear adjoint
+// forms the L2 adjoint  inv * (g - y * <y, g>)  on the fly: the LPP = C / 8 lanes that own one input column hold all C
+// channels of an output pixel, the dot product is a butterfly over those lanes.  Deterministic (no atomics); the y pass is
+// resize_bwd_y_kernel unchanged.
+__global__ __launch_bounds__(THREADS) void pool_table_kernel(const float* __restrict__ gk, const float* __restrict__ count, int S, int C,
+                                                             float* __restrict__ table) {
+    const int64_t n = (int64_t)S * C;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS)
+        table[i] = gk[i] / __fadd_rn(count[i / C], 1e-6f);
+}
+
+// Each output pixel is visited ONCE, by the LPP lanes of its LEFT input column x0: they form its adjoint row and add (1 - lam) of
+// it to their own column's sum A and lam of it to the right neighbour's share B; B reaches the neighbour through an LDS slot
+// (8 columns per iteration + the carry of the previous iteration), tmp[ix] = A(ix) + B(ix - 1): fixed order, no atomics.
+template <int LPP>
+__global__ __launch_bounds__(THREADS) void l2pool_bwd_x_kernel(const uint16_t* __restrict__ feat, int64_t fps, const float* __restrict__ inv,
+                                                               const int64_t* __restrict__ ids, const float* __restrict__ table, int sps,
+                                                               int S, float eps, Axis ay, Axis ax, float* __restrict__ tmp) {
+    constexpr int C = LPP * 8, G = THREADS / LPP;             // G input columns per iteration
+    __shared__ float share[(G + 1) * C];                      // slot g + 1 = column (base + g)'s B; slot 0 = carry
+    const int64_t t = blockIdx.x;                             // t = b * Ho + oy
+    const int64_t id_off = (t / ay.out) * (int64_t)sps;
+    const int sub = threadIdx.x % LPP, grp = threadIdx.x / LPP, c = sub * 8;
+    const float clamp_at = 1.0f / eps;
+    int64_t held = -1;                                        // table row in g[]: neighbouring pixels mostly share their superpixel,
+    float g[8];                                               // so the 1 KB row is fetched once per run, not once per pixel
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { g[k] = 0.f; if (grp == 0) share[c + k] = 0.f; }
+    for (int base = 0; base < ax.in; base += G) {
+        const int ix = base + grp;
+        float A[8], Bq[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { A[k] = 0.f; Bq[k] = 0.f; }
+        if (ix < ax.in) {
+            int lo, hi;
+            candidates(ax, ix, lo, hi);
+            for (int ox = lo; ox <= hi; ++ox) {               // (everything below is uniform over the LPP lanes of this column)
+                int x0, x1; float lam;
+                src_index(ax, ox, x0, x1, lam);
+                if (x0 != ix) continue;
+                const int64_t p = t * ax.out + ox;
+                const int64_t gid = ids[p] + id_off;
+                if (gid < 0 || gid >= S) continue;            // rows outside the table received no gradient
+                float f[8];
+                loadv<true, 8>(feat, p * fps + c, f);
+                if (gid != held) { loadv<false, 8>(table, gid * C + c, g); held = gid; }
+                float dot = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dot += f[k] * g[k];
+#pragma unroll
+                for (int m = LPP / 2; m > 0; m >>= 1) dot += __shfl_xor(dot, m, 64);
+                const float iv = inv[p];
+                if (iv >= clamp_at) dot = 0.f;                // |x| <= eps: y = x / eps, no projection term
+                const float wa = (x1 == x0) ? iv : iv * (1.0f - lam), wb = (x1 == x0) ? 0.f : iv * lam;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float r = g[k] - f[k] * dot;
+                    A[k] += wa * r;
+                    Bq[k] += wb * r;
+                }
+            }
+        }
+        float4* sl = reinterpret_cast<float4*>(share + (grp + 1) * C + c);
+        sl[0] = make_float4(Bq[0], Bq[1], Bq[2], Bq[3]);
+        sl[1] = make_float4(Bq[4], Bq[5], Bq[6], Bq[7]);
+        __syncthreads();
+        const float4* sr = reinterpret_cast<const float4*>(share + grp * C + c);
+        const float4 r0 = sr[0], r1 = sr[1];
+        if (ix < ax.in) {
+            float o[8] = {A[0] + r0.x, A[1] + r0.y, A[2] + r0.z, A[3] + r0.w, A[4] + r1.x, A[5] + r1.y, A[6] + r1.z, A[7] + r1.w};
+            storev<false, 8>(tmp, (t * ax.in + ix) * (int64_t)C + c, o);
+        }
+        __syncthreads();
+        if (grp == G - 1) {                                   // carry into the next iteration's first column
+            float4* s0 = reinterpret_cast<float4*>(share + c);
+            s0[0] = make_float4(Bq[0], Bq[1], Bq[2], Bq[3]);
+            s0[1] = make_float4(Bq[4], Bq[5], Bq[6], Bq[7]);
+        }
+    }
+}
+
 // ---- F.normalize(p=2, dim=channels, eps): y = x / max(|x|, eps); inv = 1 / max(|x|, eps) kept for the backward.
 // one wave per pixel, lanes stride over channels
 template <bool BF16>
@@ -424,5 +509,38 @@ int oess_l2norm_nhwc_bwd(const void* y, long long y_pix_stride, const void* grad
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }
+
+size_t oess_bilinear_l2norm_pool_bwd_workspace_bytes(int B, int W, int C, int Ho, int S) {
+    if (B <= 0 || W <= 0 || C <= 0 || Ho <= 0 || S <= 0) return 0;
+    return (size_t)B * Ho * W * C * sizeof(float) + (((size_t)S * C * sizeof(float) + 255) & ~(size_t)255);
+}
+
+int oess_bilinear_l2norm_pool_bwd_bf16(const void* feat, long long feat_pix_stride, const float* inv_norm, const int64_t* ids,
+                                       const float* grad_k, const float* count, int superpixel_size, int S, int B, int H, int W, int C,
+                                       int Ho, int Wo, int align_corners, float eps, void* workspace, size_t workspace_bytes,
+                                       void* grad_in, long long gin_pix_stride, oess_stream_t stream) {
+    if (!feat || !inv_norm || !ids || !grad_k || !count || !workspace || !grad_in || B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 ||
+        S <= 0 || superpixel_size <= 0 || feat_pix_stride < C || gin_pix_stride < C || eps <= 0.f)
+        return OESS_EINVAL;
+    const int lpp = (C % 8 == 0) ? C / 8 : 0;
+    if (!(lpp == 8 || lpp == 16 || lpp == 32 || lpp == 64) || !vec_ok(feat, feat_pix_stride, C, 1) || !vec_ok(grad_in, gin_pix_stride, C, 1))
+        return OESS_EINVAL;
+    if (workspace_bytes < oess_bilinear_l2norm_pool_bwd_workspace_bytes(B, W, C, Ho, S) || ((uintptr_t)workspace & 15)) return OESS_ENOMEM;
+    const Axis ay = make_axis(H, Ho, align_corners), ax = make_axis(W, Wo, align_corners);
+    hipStream_t st = (hipStream_t)stream;
+    float* tmp = (float*)workspace;
+    float* table = tmp + (size_t)B * Ho * W * C;
+    hipLaunchKernelGGL(pool_table_kernel, dim3(grid_for((int64_t)S * C)), dim3(THREADS), 0, st, grad_k, count, S, C, table);
+    const dim3 gx((unsigned)((int64_t)B * Ho));
+#define OESS_LP(L) hipLaunchKernelGGL((l2pool_bwd_x_kernel<L>), gx, dim3(THREADS), 0, st, (const uint16_t*)feat, (int64_t)feat_pix_stride, \
+                                      inv_norm, ids, (const float*)table, superpixel_size, S, eps, ay, ax, tmp)
+    if (lpp == 8) OESS_LP(8); else if (lpp == 16) OESS_LP(16); else if (lpp == 32) OESS_LP(32); else OESS_LP(64);
+#undef OESS_LP
+    hipLaunchKernelGGL((resize_bwd_y_kernel<true, 8>), dim3((unsigned)((int64_t)B * H)), dim3(THREADS), 0, st, (const float*)tmp, B, C, ay, ax,
+                       grad_in, (int64_t)gin_pix_stride);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
 
 }  // extern "C"

@@ -273,7 +273,7 @@ def superpixel_pool(feat_nchw, superpixels, superpixel_size, S=None, with_count=
     """Drop-in for the inline block of training/pretrain_trainer.py:445-465.  feat_nchw is logically
     B x C x H x W (any memory format; channels_last is free), superpixels B x H x W int64.
     with_count: also the fp32 pixel count of every row (not differentiable)."""
-    if isinstance(feat_nchw, PointwiseFeature):
+    if hasattr(feat_nchw, 'pool') and hasattr(feat_nchw, 'materialize'):      # PointwiseFeature / UpsampledNormalizedFeature
         return feat_nchw.pool(superpixels, superpixel_size, S)
     B, C, H, W = feat_nchw.shape
     if S is None:   # data-dependent size exactly like sparse_coo_tensor (costs one device sync)
@@ -1155,6 +1155,76 @@ class _BilinearL2NormTrain(torch.autograd.Function):
         _lib.check(lib.oess_resize_bilinear_nhwc_bwd(_ptr(gup), C, B, H, W, C, 1, Ho, Wo, 1, _ptr(ws), ws.numel(), _ptr(gin), C, _stream()),
                    "oess_resize_bilinear_nhwc_bwd")
         return gin.permute(0, 3, 1, 2), None
+
+
+class _BilinearL2NormPool(torch.autograd.Function):
+    """k = scatter_mean(F.normalize(nn.Upsample(scale, bilinear, align_corners=True)(x)), superpixels) as ONE node: forward = the
+    fused upsample + normalise kernel followed by K7 on its output; backward = ONE pass over the saved normalised map that gathers
+    gk / (n + 1e-6) rows from the S x C table, forms the L2 adjoint on the fly and does the x pass of the bilinear adjoint,
+    then the y pass -- instead of row gather -> L2 adjoint -> bilinear adjoint through three 1.15 GB tensors."""
+
+    @staticmethod
+    def forward(ctx, x, scale, ids, sps, S):
+        lib = _lib.load()
+        xn = x.permute(0, 2, 3, 1)
+        B, H, W, C, ps = _nhwc_geom(xn)
+        Ho, Wo = H * scale, W * scale
+        y = torch.empty((B, Ho, Wo, C), dtype=torch.bfloat16, device=x.device)
+        inv = torch.empty(B * Ho * Wo, dtype=torch.float32, device=x.device)
+        _lib.check(lib.oess_bilinear_l2norm_nhwc_bf16(_ptr(xn), ps, B, H, W, C, scale, 1, _ptr(y), C, _ptr(inv), _stream()),
+                   "oess_bilinear_l2norm_nhwc_bf16")
+        k = torch.empty((S, C), dtype=torch.float32, device=x.device)
+        cnt = torch.empty((S,), dtype=torch.float32, device=x.device)
+        ws_bytes = lib.oess_segment_mean_fwd_workspace_bytes(S, C)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        _lib.check(lib.oess_segment_mean_fwd(_ptr(y), 1, _ptr(ids), B * Ho * Wo, Ho * Wo, sps, C, S, _ptr(k), _ptr(cnt), _ptr(ws), ws_bytes,
+                                             _stream()), "oess_segment_mean_fwd")
+        ctx.save_for_backward(y, inv, ids, cnt)
+        ctx.meta = (B, H, W, C, scale, sps, S)
+        return k
+
+    @staticmethod
+    def backward(ctx, gk):
+        lib = _lib.load()
+        y, inv, ids, cnt = ctx.saved_tensors
+        B, H, W, C, scale, sps, S = ctx.meta
+        Ho, Wo = H * scale, W * scale
+        gk = gk.contiguous().float()
+        gin = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=gk.device)
+        nbytes = lib.oess_bilinear_l2norm_pool_bwd_workspace_bytes(B, W, C, Ho, S)
+        ws = _workspace(nbytes, gk.device, tag="resize")
+        _lib.check(lib.oess_bilinear_l2norm_pool_bwd_bf16(_ptr(y), C, _ptr(inv), _ptr(ids), _ptr(gk), _ptr(cnt), sps, S, B, H, W, C, Ho, Wo, 1,
+                                                          1e-12, _ptr(ws), ws.numel(), _ptr(gin), C, _stream()),
+                   "oess_bilinear_l2norm_pool_bwd_bf16")
+        return gin.permute(0, 3, 1, 2), None, None, None, None
+
+
+class UpsampledNormalizedFeature:
+    """DilationFeatureExtractor's output  F.normalize(nn.Upsample(x4, bilinear, align_corners=True)(x))  (models/image_model.py:
+    121-143) kept as (x, scale) for a consumer that only pools it over superpixels (training/pretrain_trainer.py:445-465):
+    `pool` is the one-node form above; `materialize()` is the full-resolution tensor for anything else."""
+
+    def __init__(self, x, scale):
+        self.x, self.scale = x, int(scale)
+
+    @property
+    def shape(self):
+        B, C, H, W = self.x.shape
+        return torch.Size((B, C, H * self.scale, W * self.scale))
+
+    def materialize(self):
+        return bilinear_l2norm_train(self.x, self.scale)
+
+    def pool(self, superpixels, superpixel_size, S=None):
+        B, C, Ho, Wo = self.shape
+        _need_gpu(self.x, superpixels)
+        if tuple(superpixels.shape) != (B, Ho, Wo):
+            raise ValueError("superpixel map does not match the upsampled feature size")
+        if S is None:
+            off = torch.arange(0, B * superpixel_size, superpixel_size, device=superpixels.device)[:, None, None]
+            S = int((superpixels + off).max().item()) + 1
+        ids = superpixels.reshape(-1).contiguous().to(torch.int64)
+        return _BilinearL2NormPool.apply(self.x, self.scale, ids, int(superpixel_size), int(S))
 
 
 def bilinear_l2norm_train(x, scale=4):

@@ -36,6 +36,9 @@ class DilationFeatureExtractor(nn.Module):
         self.decoder = nn.Sequential(HipConv2d(2048, 256, 1), nn.Upsample(scale_factor=4, mode="bilinear", align_corners=True))
         self.preprocessing = preprocessing
         self.normalize_feature = True
+        # True: the differentiable path returns hip.UpsampledNormalizedFeature (x, 4) for a consumer that only pools the features
+        # over superpixels (PretrainStep with the contrastive loss); its .materialize() is the tensor this module returns otherwise
+        self.lazy_features = False
 
     def forward(self, x):
         if self.preprocessing:
@@ -47,6 +50,8 @@ class DilationFeatureExtractor(nn.Module):
         if torch.is_grad_enabled() and x.requires_grad:
             # differentiable path (contrastive loss active)
             if self.normalize_feature and x.dtype == torch.bfloat16 and x.shape[1] % 64 == 0 and x.shape[1] <= 512:
+                if self.lazy_features:
+                    return hip.UpsampledNormalizedFeature(x, 4)
                 return hip.bilinear_l2norm_train(x, 4)            # one fused forward kernel + (L2 adjoint, bilinear adjoint)
             x = hip.bilinear_resize(x, scale_factor=4, align_corners=True)
             return hip.l2_normalize(x) if self.normalize_feature else x

@@ -21,6 +21,9 @@ class PretrainStep:
     # frame2voxel + contrastive: the student's 256-channel map is only pooled over superpixels, and the mean commutes with its 1x1
     # convolution (hip.PointwiseFeature); False = materialise the map as the reference does (A/B, tests)
     pooled_student_features = True
+    # contrastive: the teacher's upsampled + normalised features are only pooled too -> hip.UpsampledNormalizedFeature (one-pass
+    # backward); False = the full-resolution tensor goes through autograd as three separate adjoints
+    pooled_teacher_features = True
 
     def __init__(self, config_option='frame2voxel', num_classes=11, img_size=(440, 640), nr_events_data=20,
                  nr_temporal_bins=5, if_spatial_contrastive=False, if_dense_clip_supervision=True, superpixel_size=100,
@@ -58,6 +61,7 @@ class PretrainStep:
         else:
             raise NotImplementedError(config_option)
         self.model_frame = DilationFeatureExtractor(image_weights=None)
+        self.model_frame.lazy_features = bool(if_spatial_contrastive and self.pooled_teacher_features)
         self.models_dict['model_frame'] = self.model_frame
         if text_embeddings is not None:
             tgt = self.task_backend if config_option == 'frame2voxel' else self.model_recon.classifier

@@ -373,3 +373,48 @@ def test_pointwise_feature_pool_equals_pooling_the_convolved_map():
     # the materialised path on the same inputs
     k2 = hip.superpixel_pool(conv(x.detach().float()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last), sp, sps, S)
     assert rel(k2.detach(), kd.detach()) < 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,H,W", [(2, 256, 11, 16), (1, 64, 7, 9), (2, 128, 5, 40)])
+def test_upsampled_normalized_feature_pool(B, C, H, W):
+    """hip.UpsampledNormalizedFeature.pool = scatter_mean(F.normalize(nn.Upsample(x4, bilinear, align_corners=True)(x))) with a
+    one-pass backward (models/image_model.py:121-143 + training/pretrain_trainer.py:445-465).  The forward uses the same two
+    kernels as the composed path (bit-equal); the input gradient is compared with float64 autograd of the reference ops at 1.5e-2
+    of its largest value (bf16 input, bf16 saved map; the composed path, which rounds two more tensors to bf16, at 3e-2) and is
+    bit-identical between two runs."""
+    from openess_amd import hip
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(C + W)
+    sps = 50
+    x = torch.randn(B, C, H, W, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    sp = torch.randint(0, 37, (B, 4 * H, 4 * W), generator=g).to(dev)
+    sp[0, :2] = 49
+    S = B * sps
+    gk = torch.randn(S, C, generator=g).to(dev)
+    k = hip.superpixel_pool(hip.UpsampledNormalizedFeature(x, 4), sp, sps, S)
+    k.backward(gk)
+    gx = x.grad.float().clone(); x.grad = None
+    k2 = hip.superpixel_pool(hip.UpsampledNormalizedFeature(x, 4), sp, sps, S)
+    k2.backward(gk)
+    assert torch.equal(k, k2) and torch.equal(x.grad.float(), gx)
+    x.grad = None
+    kc = hip.superpixel_pool(hip.bilinear_l2norm_train(x, 4), sp, sps, S)
+    kc.backward(gk)
+    gx_c = x.grad.float().clone()
+    assert torch.equal(kc, k)
+    xd = x.detach().double().requires_grad_(True)
+    up = torch.nn.functional.interpolate(xd, scale_factor=4, mode="bilinear", align_corners=True)
+    fn = torch.nn.functional.normalize(up, p=2, dim=1).permute(0, 2, 3, 1).reshape(-1, C)
+    ids = (sp + torch.arange(B, device=dev)[:, None, None] * sps).reshape(-1)
+    sums = torch.zeros(S, C, dtype=torch.float64, device=dev).index_add_(0, ids, fn)
+    cnt = torch.zeros(S, dtype=torch.float64, device=dev).index_add_(0, ids, torch.ones_like(ids, dtype=torch.float64))
+    kd = sums / (cnt[:, None] + 1e-6)
+    kd.backward(gk.double())
+    ref = xd.grad
+
+    def rel(a):
+        return float((a.double() - ref).abs().max() / ref.abs().max())
+    assert float((k.detach().double() - kd.detach()).abs().max()) < 2e-3
+    assert rel(gx) < 1.5e-2, rel(gx)
+    assert rel(gx_c) < 3e-2, rel(gx_c)
