@@ -35,7 +35,7 @@ typedef void* oess_stream_t; /* hipStream_t */
 /* Library / device identification.  OESS_ABI_VERSION is bumped whenever a signature of this header changes or an entry point
  * is removed; oess_abi_version() returns the value the library was built with and the ctypes binding (openess_amd/_lib.py,
  * ABI_VERSION) refuses a library whose value differs. */
-#define OESS_ABI_VERSION 7
+#define OESS_ABI_VERSION 8
 int oess_abi_version(void);
 const char* oess_build_info(void);           /* "liboess <ver> gfx950 hipcc <ver>" */
 const char* oess_strerror(int code);
@@ -479,6 +479,23 @@ int oess_bilinear_l2norm_pool_bwd_bf16(const void* feat, long long feat_pix_stri
                                        const float* grad_k, const float* count, int superpixel_size, int S, int B, int H, int W, int C,
                                        int Ho, int Wo, int align_corners, float eps, void* workspace, size_t workspace_bytes,
                                        void* grad_in, long long gin_pix_stride, oess_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Superpixel mean of a bilinearly upsampled map through its pooling matrix (models/deeplabv3.py:184 F.interpolate(feats, size=
+ * input, bilinear, align_corners=False) followed by training/pretrain_trainer.py:445-465 on it): k[s] = (sum_q M[s][q] y[q]) /
+ * (n[s] + 1e-6) with M[s][q] = the summed bilinear weights of superpixel row s's pixels on low-resolution pixel q.
+ *   build: ids [B x Ho x Wo] raw ids (row = id + sample * superpixel_size, rows outside [0, S) dropped) -> matrix
+ *          (oess_pool_matrix_bytes(S, B, h, w) bytes, 16-byte aligned; 2^-40 fixed-point sums + pixel counts; order-independent)
+ *   fwd:   y [B x h x w x C] bf16 / fp32 -> k [S x C] fp32, count [S] fp32
+ *   bwd:   grad_k [S x C] -> grad_y [B x h x w x C];  C <= 1024.  The full-resolution map is never formed.
+ * ------------------------------------------------------------------------------------------ */
+size_t oess_pool_matrix_bytes(int S, int B, int h, int w);
+int oess_pool_matrix_build(const int64_t* ids, int B, int Ho, int Wo, int h, int w, int align_corners, int superpixel_size, int S,
+                           void* matrix, size_t matrix_bytes, oess_stream_t stream);
+int oess_pool_matrix_fwd(const void* matrix, const void* y, long long y_pix_stride, int is_bf16, int B, int h, int w, int C, int S,
+                         float* k, float* count, oess_stream_t stream);
+int oess_pool_matrix_bwd(const void* matrix, const float* grad_k, int B, int h, int w, int C, int S, void* grad_y, long long gy_pix_stride,
+                         int is_bf16, oess_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OESS_LIB_PATH") or os.path.join(_HERE, "liboess.so")      # override: A/B builds of the same ABI
 
-ABI_VERSION = 7          # == OESS_ABI_VERSION of include/oess.h (tests/test_abi.py keeps the two equal)
+ABI_VERSION = 8          # == OESS_ABI_VERSION of include/oess.h (tests/test_abi.py keeps the two equal)
 
 c_i64 = ctypes.c_int64
 c_ll = ctypes.c_longlong
@@ -102,6 +102,10 @@ SIGNATURES = {
     "oess_bilinear_l2norm_pool_bwd_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     "oess_bilinear_l2norm_pool_bwd_bf16": (c_int, [c_vp, c_ll, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                                    c_f, c_vp, c_sz, c_vp, c_ll, c_vp]),
+    "oess_pool_matrix_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
+    "oess_pool_matrix_build": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
+    "oess_pool_matrix_fwd": (c_int, [c_vp, c_vp, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "oess_pool_matrix_bwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_ll, c_int, c_vp]),
     "oess_linear_probe_partials_bytes": (c_sz, [c_int]),
     "oess_linear_probe_fwd_f32": (c_int, [c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp]),
     "oess_linear_probe_bwd_f32": (c_int, [c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -14,36 +14,11 @@
 #include <stdint.h>
 #include "oess.h"
 #include "oess_common.h"
+#include "bilinear_axis.h"
 
 namespace {
 using namespace oess;
 constexpr int THREADS = 256;
-
-struct Axis { float scale; int align; int in, out; };
-
-__device__ __forceinline__ void src_index(const Axis& ax, int dst, int& i0, int& i1, float& lam) {
-    float s = ax.align ? ax.scale * (float)dst : fmaxf(ax.scale * ((float)dst + 0.5f) - 0.5f, 0.0f);
-    i0 = (int)s;
-    if (i0 > ax.in - 1) i0 = ax.in - 1;
-    i1 = (i0 < ax.in - 1) ? i0 + 1 : i0;
-    lam = s - (float)i0;
-}
-// candidate output range whose footprint can touch input index i (generous by 2 on both sides; exact test follows)
-__device__ __forceinline__ void candidates(const Axis& ax, int i, int& lo, int& hi) {
-    if (ax.scale <= 0.f) { lo = 0; hi = ax.out - 1; return; }
-    const float inv = 1.0f / ax.scale;
-    float a, b;
-    if (ax.align) { a = ((float)i - 1.0f) * inv; b = ((float)i + 1.0f) * inv; }
-    else { a = ((float)i - 0.5f) * inv - 0.5f; b = ((float)i + 1.5f) * inv - 0.5f; }
-    lo = (int)floorf(a) - 2; hi = (int)ceilf(b) + 2;
-    if (lo < 0) lo = 0;
-    if (hi > ax.out - 1) hi = ax.out - 1;
-}
-__device__ __forceinline__ float weight_for(const Axis& ax, int dst, int i) {
-    int i0, i1; float lam;
-    src_index(ax, dst, i0, i1, lam);
-    return (i0 == i ? 1.0f - lam : 0.0f) + (i1 == i ? lam : 0.0f);
-}
 
 // ---- VEC-wide typed access: bf16 x8 / fp32 x4 as one 16-byte access, or scalars
 template <bool BF16, int VEC>
@@ -392,11 +367,6 @@ __global__ __launch_bounds__(THREADS) void l2norm_bwd_vec_kernel(const void* __r
     }
 }
 
-Axis make_axis(int in, int out, int align) {
-    Axis a; a.in = in; a.out = out; a.align = align;
-    a.scale = align ? (out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.0f) : (float)in / (float)out;
-    return a;
-}
 unsigned grid_for(int64_t work) {
     int64_t g = (work + THREADS - 1) / THREADS;
     if (g < 1) g = 1;

@@ -1227,6 +1227,77 @@ class UpsampledNormalizedFeature:
         return _BilinearL2NormPool.apply(self.x, self.scale, ids, int(superpixel_size), int(S))
 
 
+class _PoolMatrixMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, matrix, S):
+        lib = _lib.load()
+        yn = _nhwc_any(y)
+        B, h, w, C = yn.shape
+        k = torch.empty((S, C), dtype=torch.float32, device=y.device)
+        cnt = torch.empty((S,), dtype=torch.float32, device=y.device)
+        _lib.check(lib.oess_pool_matrix_fwd(_ptr(matrix), _ptr(yn), _pix_stride(yn), int(yn.dtype == torch.bfloat16), B, h, w, C, S,
+                                            _ptr(k), _ptr(cnt), _stream()), "oess_pool_matrix_fwd")
+        ctx.save_for_backward(matrix)
+        ctx.meta = (B, h, w, C, S, yn.dtype)
+        return k
+
+    @staticmethod
+    def backward(ctx, gk):
+        lib = _lib.load()
+        (matrix,) = ctx.saved_tensors
+        B, h, w, C, S, dtype = ctx.meta
+        gk = gk.contiguous().float()
+        gy = torch.empty((B, h, w, C), dtype=dtype, device=gk.device)
+        _lib.check(lib.oess_pool_matrix_bwd(_ptr(matrix), _ptr(gk), B, h, w, C, S, _ptr(gy), C, int(dtype == torch.bfloat16), _stream()),
+                   "oess_pool_matrix_bwd")
+        return gy.permute(0, 3, 1, 2), None, None
+
+
+def pool_matrix(superpixels, in_hw, superpixel_size, S, align_corners=False):
+    """Pooling matrix of (bilinear upsample from in_hw to the size of `superpixels`) followed by the superpixel scatter-mean:
+    an opaque device buffer for UpsampledFeature.pool / _PoolMatrixMean (2^-40 fixed-point weight sums + pixel counts)."""
+    lib = _lib.load()
+    _need_gpu(superpixels)
+    B, Ho, Wo = superpixels.shape
+    h, w = int(in_hw[0]), int(in_hw[1])
+    ids = superpixels.reshape(-1).contiguous().to(torch.int64)
+    nbytes = lib.oess_pool_matrix_bytes(int(S), B, h, w)
+    m = torch.empty(nbytes, dtype=torch.uint8, device=superpixels.device)
+    _lib.check(lib.oess_pool_matrix_build(_ptr(ids), B, Ho, Wo, h, w, int(bool(align_corners)), int(superpixel_size), int(S), _ptr(m), nbytes,
+                                          _stream()), "oess_pool_matrix_build")
+    return m
+
+
+class UpsampledFeature:
+    """DeepLabv3's `feats = F.interpolate(feats, size=input_shape, mode='bilinear', align_corners=False)` (models/deeplabv3.py:184)
+    kept as (low-resolution map, size) for a consumer that only pools it over superpixels (training/pretrain_trainer.py:445-465,
+    frame2recon): upsampling and pooling are both linear, so `pool` multiplies the low-resolution map with the pooling matrix of
+    the superpixel map (pool_matrix) -- forward and backward without any full-resolution tensor.  `materialize()` is the tensor."""
+
+    def __init__(self, x, size, align_corners=False):
+        self.x, self.size, self.align_corners = x, (int(size[0]), int(size[1])), bool(align_corners)
+
+    @property
+    def shape(self):
+        B, C = self.x.shape[:2]
+        return torch.Size((B, C, self.size[0], self.size[1]))
+
+    def materialize(self):
+        return bilinear_resize(self.x, size=self.size, align_corners=self.align_corners)
+
+    def pool(self, superpixels, superpixel_size, S=None, matrix=None):
+        B, C, Ho, Wo = self.shape
+        _need_gpu(self.x, superpixels)
+        if tuple(superpixels.shape) != (B, Ho, Wo):
+            raise ValueError("superpixel map does not match the upsampled feature size")
+        if S is None:
+            off = torch.arange(0, B * superpixel_size, superpixel_size, device=superpixels.device)[:, None, None]
+            S = int((superpixels + off).max().item()) + 1
+        if matrix is None:
+            matrix = pool_matrix(superpixels, self.x.shape[2:], superpixel_size, S, self.align_corners)
+        return _PoolMatrixMean.apply(self.x, matrix, int(S))
+
+
 def bilinear_l2norm_train(x, scale=4):
     """Differentiable form of bilinear_l2norm (normalisation on) for a channels_last bf16 tensor with C % 64 == 0."""
     _need_gpu(x)

@@ -138,6 +138,7 @@ class DeepLabHead(nn.Module):
 
 class deeplabv3_resnet50(nn.Module):
     feats_fp32 = False
+    lazy_feats = False            # see forward()
 
     def __init__(self, num_classes, text_embeddings_path, output_stride, pretrained_backbone, if_linear_probing=False,
                  if_finetuning=False, frozen_backbone=False):
@@ -175,7 +176,12 @@ class deeplabv3_resnet50(nn.Module):
         logist = hip.bilinear_resize(logist.float(), size=input_shape, align_corners=False)      # deeplabv3.py:183
         # deeplabv3.py:184.  feats_fp32: the full-resolution 256-channel map leaves in fp32 (interpolated from the bf16 OS16 map
         # without a second rounding): what the superpixel pooling / InfoNCE / L1 consistency losses consume
-        feats = hip.bilinear_resize(feats.float() if self.feats_fp32 else feats, size=input_shape, align_corners=False)
+        if self.lazy_feats and torch.is_grad_enabled():
+            # the consumer only pools the features over superpixels (PretrainStep, frame2recon + contrastive): hip.UpsampledFeature
+            # multiplies the OS16 map with the pooling matrix instead of forming the full-resolution tensor
+            feats = hip.UpsampledFeature(feats.float() if self.feats_fp32 else feats, input_shape, align_corners=False)
+        else:
+            feats = hip.bilinear_resize(feats.float() if self.feats_fp32 else feats, size=input_shape, align_corners=False)
         if self.if_linear_probing:
             logist = hip.linear_probe(logist, self.linear_probe)
         return logist, feats

@@ -58,6 +58,7 @@ class PretrainStep:
             self.model_recon = deeplabv3_resnet50(num_classes=num_classes, text_embeddings_path='',
                                                   output_stride=output_stride, pretrained_backbone='')
             self.models_dict['model_recon'] = self.model_recon
+            self.model_recon.lazy_feats = bool(if_spatial_contrastive and self.pooled_student_features)
         else:
             raise NotImplementedError(config_option)
         self.model_frame = DilationFeatureExtractor(image_weights=None)

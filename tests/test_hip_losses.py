@@ -418,3 +418,44 @@ def test_upsampled_normalized_feature_pool(B, C, H, W):
     assert float((k.detach().double() - kd.detach()).abs().max()) < 2e-3
     assert rel(gx) < 1.5e-2, rel(gx)
     assert rel(gx_c) < 3e-2, rel(gx_c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,h,w,Ho,Wo,dtype", [(2, 256, 7, 10, 110, 160, torch.bfloat16), (1, 64, 5, 6, 37, 53, torch.float32),
+                                                  (3, 300, 4, 4, 64, 64, torch.bfloat16)])
+def test_upsampled_feature_pool_through_the_pooling_matrix(B, C, h, w, Ho, Wo, dtype):
+    """hip.UpsampledFeature.pool = scatter_mean(F.interpolate(y, size, bilinear, align_corners=False)) (models/deeplabv3.py:184 +
+    training/pretrain_trainer.py:445-465) as a product with the pooling matrix.  Against float64 autograd of the reference ops:
+    forward 1e-5 (fp32 input) / 1e-5 (bf16 input: the input is exact in bf16, the arithmetic is fp32) of the largest value,
+    gradient 1e-5 (fp32) / 1e-2 (bf16 output rounding); counts exact; ids beyond superpixel_size land in the next sample's rows,
+    rows beyond S are dropped; bit-identical between two runs (integer weight sums, fixed-order products)."""
+    from openess_amd import hip
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(C + Wo)
+    sps = 40
+    y = torch.randn(B, C, h, w, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    sp = torch.randint(0, 30, (B, Ho, Wo), generator=g).to(dev)
+    sp[:, : Ho // 4, : Wo // 3] = 3                       # one large superpixel
+    sp[0, -2:, :] = 45                                    # id >= superpixel_size: row 45 (sample 1's range, or dropped when B == 1)
+    S = B * sps
+    gk = torch.randn(S, C, generator=g).to(dev)
+    k = hip.superpixel_pool(hip.UpsampledFeature(y, (Ho, Wo)), sp, sps, S)
+    k.backward(gk)
+    gy = y.grad.float().clone(); y.grad = None
+    k2 = hip.superpixel_pool(hip.UpsampledFeature(y, (Ho, Wo)), sp, sps, S)
+    k2.backward(gk)
+    assert torch.equal(k, k2) and torch.equal(y.grad.float(), gy)
+    yd = y.detach().double().requires_grad_(True)
+    up = torch.nn.functional.interpolate(yd, size=(Ho, Wo), mode="bilinear", align_corners=False).permute(0, 2, 3, 1).reshape(-1, C)
+    ids = (sp + torch.arange(B, device=dev)[:, None, None] * sps).reshape(-1)
+    ok = ids < S
+    sums = torch.zeros(S, C, dtype=torch.float64, device=dev).index_add_(0, ids[ok], up[ok])
+    cnt = torch.zeros(S, dtype=torch.float64, device=dev).index_add_(0, ids[ok], torch.ones(int(ok.sum()), dtype=torch.float64, device=dev))
+    kd = sums / (cnt[:, None] + 1e-6)
+    kd.backward(gk.double())
+    assert float((k.detach().double() - kd.detach()).abs().max() / kd.detach().abs().max()) < 1e-5
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert float((gy.double() - yd.grad).abs().max() / yd.grad.abs().max()) < tol
+    # the materialised path (full-resolution tensor -> K7) agrees to its own rounding
+    km = hip.superpixel_pool(hip.UpsampledFeature(y, (Ho, Wo)).materialize(), sp, sps, S)
+    assert float((km.detach().double() - kd.detach()).abs().max() / kd.detach().abs().max()) < (1e-5 if dtype == torch.float32 else 1e-2)
