@@ -57,7 +57,7 @@ __global__ __launch_bounds__(THREADS) void l1_fwd_kernel(const void* __restrict_
                                                          double* __restrict__ partials) {
     double s = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS)
-        s += (double)fabsf(ld<BF16>(a, i) - ld<BF16>(b, i));
+        s += (double)fabsf(ld<BF16>(a, i) - (b ? ld<BF16>(b, i) : 0.f));
     block_partial(s, partials);
 }
 
@@ -67,11 +67,79 @@ __global__ __launch_bounds__(THREADS) void l1_bwd_kernel(const void* __restrict_
                                                          void* __restrict__ gb) {
     const float g = gout[0] * inv_n;
     for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS) {
-        const float d = ld<BF16>(a, i) - ld<BF16>(b, i);
+        const float d = ld<BF16>(a, i) - (b ? ld<BF16>(b, i) : 0.f);
         const float s = d > 0.f ? g : (d < 0.f ? -g : 0.f);          // sign(0) = 0 like torch
         if (ga) st<BF16>(ga, i, s);
         if (gb) st<BF16>(gb, i, -s);
     }
+}
+
+// 16-byte forms (n % VEC elements of tail go through the scalar kernels' arithmetic in the same launch); b == nullptr: mean |a|
+template <bool BF16>
+__device__ __forceinline__ void ldv(const void* p, int64_t i, float (&v)[BF16 ? 8 : 4]) {
+    if constexpr (BF16) {
+        const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p) + i);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+    } else {
+        const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + i);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    }
+}
+template <bool BF16>
+__device__ __forceinline__ void stv(void* p, int64_t i, const float (&v)[BF16 ? 8 : 4]) {
+    if constexpr (BF16) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p) + i) = pack_bf16x8(v);
+    else *reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + i) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(THREADS) void l1_fwd_vec_kernel(const void* __restrict__ a, const void* __restrict__ b, int64_t n,
+                                                             double* __restrict__ partials) {
+    constexpr int VEC = BF16 ? 8 : 4;
+    const int64_t nv = n / VEC;
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < nv; i += (int64_t)gridDim.x * THREADS) {
+        float x[VEC], y[VEC];
+        ldv<BF16>(a, i * VEC, x);
+        if (b) ldv<BF16>(b, i * VEC, y);
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) t += fabsf(b ? x[k] - y[k] : x[k]);
+        s += (double)t;
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = nv * VEC + threadIdx.x; i < n; i += THREADS) s += (double)fabsf(ld<BF16>(a, i) - (b ? ld<BF16>(b, i) : 0.f));
+    block_partial(s, partials);
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(THREADS) void l1_bwd_vec_kernel(const void* __restrict__ a, const void* __restrict__ b, int64_t n,
+                                                             const float* __restrict__ gout, float inv_n, void* __restrict__ ga,
+                                                             void* __restrict__ gb) {
+    constexpr int VEC = BF16 ? 8 : 4;
+    const int64_t nv = n / VEC;
+    const float g = gout[0] * inv_n;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < nv; i += (int64_t)gridDim.x * THREADS) {
+        float x[VEC], y[VEC], sa[VEC], sb[VEC];
+        ldv<BF16>(a, i * VEC, x);
+        if (b) ldv<BF16>(b, i * VEC, y);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float d = b ? x[k] - y[k] : x[k];
+            sa[k] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+            sb[k] = -sa[k];
+        }
+        if (ga) stv<BF16>(ga, i * VEC, sa);
+        if (gb) stv<BF16>(gb, i * VEC, sb);
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = nv * VEC + threadIdx.x; i < n; i += THREADS) {
+            const float d = ld<BF16>(a, i) - (b ? ld<BF16>(b, i) : 0.f);
+            const float sgn = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+            if (ga) st<BF16>(ga, i, sgn);
+            if (gb) st<BF16>(gb, i, -sgn);
+        }
 }
 
 // one wave per pixel, lanes stride over channels; accumulates sum over pixels of cos
@@ -116,6 +184,76 @@ __global__ __launch_bounds__(THREADS) void cos_bwd_kernel(const void* __restrict
             if (ga) st<BF16>(ga, p * gas + c, g * (y * inv - ka * x));
             if (gb) st<BF16>(gb, p * gbs + c, g * (x * inv - kb * y));
         }
+    }
+}
+
+// Dense small-C form (the logits: fp32 [P][K], K = 11 -- a wave per pixel kept 53 of 64 lanes idle and took 0.53 + 0.59 ms at
+// 8 x 440 x 640): a workgroup moves 256 pixels x C floats of both operands through LDS with 16-byte accesses, one thread per pixel
+// (channels added in order), the gradients leave through the same tiles.
+constexpr int COS_CMAX = 24;             // 2 x 256 x 24 floats = 48 KB of LDS
+__device__ __forceinline__ void cos_tile_load(const float* __restrict__ src, int64_t total, float* dst) {
+    const int64_t n4 = total >> 2;
+    for (int64_t j = threadIdx.x; j < n4; j += THREADS) *reinterpret_cast<float4*>(dst + 4 * j) = *reinterpret_cast<const float4*>(src + 4 * j);
+    for (int64_t j = 4 * n4 + threadIdx.x; j < total; j += THREADS) dst[j] = src[j];
+}
+__device__ __forceinline__ void cos_tile_store(float* __restrict__ dst, int64_t total, const float* src) {
+    const int64_t n4 = total >> 2;
+    for (int64_t j = threadIdx.x; j < n4; j += THREADS) *reinterpret_cast<float4*>(dst + 4 * j) = *reinterpret_cast<const float4*>(src + 4 * j);
+    for (int64_t j = 4 * n4 + threadIdx.x; j < total; j += THREADS) dst[j] = src[j];
+}
+
+__global__ __launch_bounds__(THREADS) void cos_fwd_dense_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t P, int C,
+                                                                float eps, double* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float cos_s[];
+    float* sa = cos_s; float* sb = cos_s + THREADS * C;
+    double acc = 0.0;
+    for (int64_t p0 = (int64_t)blockIdx.x * THREADS; p0 < P; p0 += (int64_t)gridDim.x * THREADS) {
+        const int64_t n = (P - p0 < THREADS) ? P - p0 : THREADS;
+        __syncthreads();
+        cos_tile_load(a + p0 * C, n * C, sa);
+        cos_tile_load(b + p0 * C, n * C, sb);
+        __syncthreads();
+        if ((int64_t)threadIdx.x < n) {
+            float ab = 0.f, aa = 0.f, bb = 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float x = sa[threadIdx.x * C + c], y = sb[threadIdx.x * C + c];
+                ab += x * y; aa += x * x; bb += y * y;
+            }
+            acc += (double)(ab / (fmaxf(sqrtf(aa), eps) * fmaxf(sqrtf(bb), eps)));
+        }
+    }
+    block_partial(acc, partials);
+}
+
+__global__ __launch_bounds__(THREADS) void cos_bwd_dense_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t P, int C,
+                                                                float eps, const float* __restrict__ gout, float inv_p,
+                                                                float* __restrict__ ga, float* __restrict__ gb) {
+    extern __shared__ __attribute__((aligned(16))) float cos_s[];
+    float* sa = cos_s; float* sb = cos_s + THREADS * C;
+    const float g = -gout[0] * inv_p;
+    for (int64_t p0 = (int64_t)blockIdx.x * THREADS; p0 < P; p0 += (int64_t)gridDim.x * THREADS) {
+        const int64_t n = (P - p0 < THREADS) ? P - p0 : THREADS;
+        __syncthreads();
+        cos_tile_load(a + p0 * C, n * C, sa);
+        cos_tile_load(b + p0 * C, n * C, sb);
+        __syncthreads();
+        if ((int64_t)threadIdx.x < n) {
+            float* ra = sa + threadIdx.x * C; float* rb = sb + threadIdx.x * C;
+            float ab = 0.f, aa = 0.f, bb = 0.f;
+            for (int c = 0; c < C; ++c) { ab += ra[c] * rb[c]; aa += ra[c] * ra[c]; bb += rb[c] * rb[c]; }
+            const float na = sqrtf(aa), nb = sqrtf(bb);
+            const float ca = fmaxf(na, eps), cb = fmaxf(nb, eps);
+            const float inv = 1.0f / (ca * cb), cosv = ab * inv;
+            const float ka = na > eps ? cosv / (ca * na) : 0.f, kb = nb > eps ? cosv / (cb * nb) : 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float x = ra[c], y = rb[c];
+                ra[c] = g * (y * inv - ka * x);
+                rb[c] = g * (x * inv - kb * y);
+            }
+        }
+        __syncthreads();
+        if (ga) cos_tile_store(ga + p0 * C, n * C, sa);
+        if (gb) cos_tile_store(gb + p0 * C, n * C, sb);
     }
 }
 
@@ -244,10 +382,14 @@ extern "C" {
 size_t oess_loss_partials_bytes(void) { return MAX_PARTIALS * sizeof(double); }
 
 int oess_l1_mean_fwd(const void* a, const void* b, int64_t n, int is_bf16, void* partials, float* loss, oess_stream_t stream) {
-    if (!a || !b || !partials || !loss || n <= 0) return OESS_EINVAL;
-    const int grid = grid_of(n, THREADS * 8);
+    if (!a || !partials || !loss || n <= 0) return OESS_EINVAL;             // b == NULL: mean |a|
     hipStream_t st = (hipStream_t)stream;
-    if (is_bf16) hipLaunchKernelGGL(l1_fwd_kernel<true>, dim3(grid), dim3(THREADS), 0, st, a, b, n, (double*)partials);
+    const bool vec = (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
+    const int grid = vec ? grid_of(n, THREADS * 32) : grid_of(n, THREADS * 8);
+    if (vec) {
+        if (is_bf16) hipLaunchKernelGGL(l1_fwd_vec_kernel<true>, dim3(grid), dim3(THREADS), 0, st, a, b, n, (double*)partials);
+        else hipLaunchKernelGGL(l1_fwd_vec_kernel<false>, dim3(grid), dim3(THREADS), 0, st, a, b, n, (double*)partials);
+    } else if (is_bf16) hipLaunchKernelGGL(l1_fwd_kernel<true>, dim3(grid), dim3(THREADS), 0, st, a, b, n, (double*)partials);
     else hipLaunchKernelGGL(l1_fwd_kernel<false>, dim3(grid), dim3(THREADS), 0, st, a, b, n, (double*)partials);
     hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(THREADS), 0, st, (const double*)partials, grid, 0.0, 1.0 / (double)n, loss);
     OESS_HIP(hipGetLastError());
@@ -256,11 +398,19 @@ int oess_l1_mean_fwd(const void* a, const void* b, int64_t n, int is_bf16, void*
 
 int oess_l1_mean_bwd(const void* a, const void* b, int64_t n, int is_bf16, const float* grad_out, void* grad_a, void* grad_b,
                      oess_stream_t stream) {
-    if (!a || !b || !grad_out || (!grad_a && !grad_b) || n <= 0) return OESS_EINVAL;
+    if (!a || !grad_out || (!grad_a && !grad_b) || n <= 0) return OESS_EINVAL;
     int64_t g = (n + THREADS * 4 - 1) / (THREADS * 4);
     if (g > 65536) g = 65536;
     hipStream_t st = (hipStream_t)stream;
     const float inv_n = (float)(1.0 / (double)n);
+    if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)grad_a | (uintptr_t)grad_b) & 15) == 0) {
+        int64_t gv = (n + THREADS * 16 - 1) / (THREADS * 16);
+        if (gv > 65536) gv = 65536;
+        if (is_bf16) hipLaunchKernelGGL(l1_bwd_vec_kernel<true>, dim3((unsigned)gv), dim3(THREADS), 0, st, a, b, n, grad_out, inv_n, grad_a, grad_b);
+        else hipLaunchKernelGGL(l1_bwd_vec_kernel<false>, dim3((unsigned)gv), dim3(THREADS), 0, st, a, b, n, grad_out, inv_n, grad_a, grad_b);
+        OESS_HIP(hipGetLastError());
+        return OESS_OK;
+    }
     if (is_bf16) hipLaunchKernelGGL(l1_bwd_kernel<true>, dim3((unsigned)g), dim3(THREADS), 0, st, a, b, n, grad_out, inv_n, grad_a, grad_b);
     else hipLaunchKernelGGL(l1_bwd_kernel<false>, dim3((unsigned)g), dim3(THREADS), 0, st, a, b, n, grad_out, inv_n, grad_a, grad_b);
     OESS_HIP(hipGetLastError());
@@ -270,8 +420,16 @@ int oess_l1_mean_bwd(const void* a, const void* b, int64_t n, int is_bf16, const
 int oess_cosine_mean_fwd(const void* a, long long a_pix_stride, const void* b, long long b_pix_stride, int64_t P, int C,
                          int is_bf16, float eps, void* partials, float* loss, oess_stream_t stream) {
     if (!a || !b || !partials || !loss || P <= 0 || C <= 0 || a_pix_stride < C || b_pix_stride < C) return OESS_EINVAL;
-    const int grid = grid_of(P, (THREADS / 64) * 8);
     hipStream_t st = (hipStream_t)stream;
+    if (!is_bf16 && C <= COS_CMAX && a_pix_stride == C && b_pix_stride == C && (((uintptr_t)a | (uintptr_t)b) & 15) == 0) {
+        const int gd = grid_of(P, THREADS * 4);
+        hipLaunchKernelGGL(cos_fwd_dense_kernel, dim3(gd), dim3(THREADS), (size_t)2 * THREADS * C * sizeof(float), st, (const float*)a,
+                           (const float*)b, P, C, eps, (double*)partials);
+        hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(THREADS), 0, st, (const double*)partials, gd, 1.0, -1.0 / (double)P, loss);
+        OESS_HIP(hipGetLastError());
+        return OESS_OK;
+    }
+    const int grid = grid_of(P, (THREADS / 64) * 8);
     if (is_bf16) hipLaunchKernelGGL(cos_fwd_kernel<true>, dim3(grid), dim3(THREADS), 0, st, a, (int64_t)a_pix_stride, b, (int64_t)b_pix_stride, P, C, eps, (double*)partials);
     else hipLaunchKernelGGL(cos_fwd_kernel<false>, dim3(grid), dim3(THREADS), 0, st, a, (int64_t)a_pix_stride, b, (int64_t)b_pix_stride, P, C, eps, (double*)partials);
     hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(THREADS), 0, st, (const double*)partials, grid, 1.0, -1.0 / (double)P, loss);
@@ -287,6 +445,15 @@ int oess_cosine_mean_bwd(const void* a, long long a_pix_stride, const void* b, l
     if (g > 65536) g = 65536;
     hipStream_t st = (hipStream_t)stream;
     const float inv_p = (float)(1.0 / (double)P);
+    if (!is_bf16 && C <= COS_CMAX && a_pix_stride == C && b_pix_stride == C && (!grad_a || ga_pix_stride == C) && (!grad_b || gb_pix_stride == C) &&
+        (((uintptr_t)a | (uintptr_t)b | (uintptr_t)grad_a | (uintptr_t)grad_b) & 15) == 0) {
+        int64_t gd = (P + THREADS * 2 - 1) / (THREADS * 2);
+        if (gd > 65536) gd = 65536;
+        hipLaunchKernelGGL(cos_bwd_dense_kernel, dim3((unsigned)gd), dim3(THREADS), (size_t)2 * THREADS * C * sizeof(float), st, (const float*)a,
+                           (const float*)b, P, C, eps, grad_out, inv_p, (float*)grad_a, (float*)grad_b);
+        OESS_HIP(hipGetLastError());
+        return OESS_OK;
+    }
     if (is_bf16) hipLaunchKernelGGL(cos_bwd_kernel<true>, dim3((unsigned)g), dim3(THREADS), 0, st, a, (int64_t)a_pix_stride, b, (int64_t)b_pix_stride, P, C, eps, grad_out, inv_p, grad_a, (int64_t)ga_pix_stride, grad_b, (int64_t)gb_pix_stride);
     else hipLaunchKernelGGL(cos_bwd_kernel<false>, dim3((unsigned)g), dim3(THREADS), 0, st, a, (int64_t)a_pix_stride, b, (int64_t)b_pix_stride, P, C, eps, grad_out, inv_p, grad_a, (int64_t)ga_pix_stride, grad_b, (int64_t)gb_pix_stride);
     OESS_HIP(hipGetLastError());

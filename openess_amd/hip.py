@@ -386,7 +386,9 @@ class _L1Mean(torch.autograd.Function):
         lib = _lib.load()
         a, b = ctx.saved_tensors
         ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
-        gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        gb = torch.empty_like(b) if b is not None and ctx.needs_input_grad[1] else None
+        if ga is None and gb is None:
+            return None, None
         gdev = g.reshape(1).float().contiguous()
         _lib.check(lib.oess_l1_mean_bwd(_ptr(a), _ptr(b), a.numel(), int(a.dtype == torch.bfloat16), _ptr(gdev),
                                         None if ga is None else _ptr(ga), None if gb is None else _ptr(gb), _stream()),
@@ -395,7 +397,20 @@ class _L1Mean(torch.autograd.Function):
 
 
 def l1_mean(a, b):
-    """nn.L1Loss()(a, b) (training/openess_trainer.py:497).  a, b: same shape, dtype (fp32 / bf16) and memory layout."""
+    """nn.L1Loss()(a, b) (training/openess_trainer.py:497).  a, b: same shape, dtype (fp32 / bf16) and memory layout.
+    Two UpsampledFeature operands of the same geometry (DeepLabV3.lazy_feats): bilinear upsampling is linear, so
+    |up(a) - up(b)| = |up(a - b)| -- the difference is formed on the low-resolution maps in fp32 and ONE full-resolution tensor
+    is written, read, and differentiated instead of two."""
+    if isinstance(a, UpsampledFeature) and isinstance(b, UpsampledFeature):
+        if a.size != b.size or a.align_corners != b.align_corners or a.x.shape != b.x.shape:
+            raise ValueError("l1_mean: upsampled operands differ in geometry")
+        d = (a.x.float() - b.x.float()).to(a.x.dtype)
+        u = bilinear_resize(d, size=a.size, align_corners=a.align_corners)
+        return _L1Mean.apply(u if (u.is_contiguous() or u.is_contiguous(memory_format=torch.channels_last)) else u.contiguous(), None)
+    if isinstance(a, UpsampledFeature):
+        a = a.materialize()
+    if isinstance(b, UpsampledFeature):
+        b = b.materialize()
     _need_gpu(a, b)
     if a.shape != b.shape or a.dtype != b.dtype or a.dtype not in (torch.float32, torch.bfloat16):
         raise ValueError("l1_mean: operands must share shape and dtype (float32 or bfloat16)")

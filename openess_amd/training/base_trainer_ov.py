@@ -258,7 +258,8 @@ class BaseTrainer(object):
         sp = rest[3] if len(rest) > 3 and torch.is_tensor(rest[3]) else None
         S = None
         if sp is not None and getattr(s, 'if_spatial_contrastive', False):
-            sps = getattr(s, 'superpixel_size', 100)          # host-side row count: no device sync in the step
+            # host-side row count: no device sync in the step (OpenESSModel pools with its own hard-coded size)
+            sps = getattr(self, 'pool_superpixel_size', None) or getattr(s, 'superpixel_size', 100)
             if torch.is_tensor(sample_batched[4]):
                 S = int((sample_batched[4] + torch.arange(sample_batched[4].shape[0])[:, None, None] * sps).max()) + 1
             else:

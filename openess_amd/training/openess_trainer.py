@@ -22,6 +22,11 @@ from .base_trainer_ov import BaseTrainer
 
 
 class OpenESSModel(BaseTrainer):
+    pool_superpixel_size = 30        # superpixel_size hard-coded in the pooling of openess_trainer.py:506 (base trainer: host-side row count)
+    # the 256-channel full-resolution features of both students are only consumed by the L1 consistency loss and the superpixel
+    # pooling: both work on the OS16 maps (hip.UpsampledFeature: one upsampled difference, one pooling matrix); False = tensors
+    lazy_features = True
+
     def init_fn(self):
         s = self.settings
         if s.config_option != 'frame2recon':
@@ -31,6 +36,7 @@ class OpenESSModel(BaseTrainer):
                                         output_stride=s.output_stride, pretrained_backbone=s.pretrained_backbone)
         self.model_recon, self.model_frame = mk(), mk()
         self.models_dict = {'model_recon': self.model_recon, 'model_frame': self.model_frame}
+        self.model_recon.lazy_feats = self.model_frame.lazy_feats = bool(self.lazy_features)
         paths = [getattr(s, k, None) for k in ('text_embeddings_path', 'visual_projs_path', 'maskclip_checkpoint')]
         if all(p and os.path.isfile(p) for p in paths):                     # openess_trainer.py:107-114
             from ..models.maskclip_model import maskClipFeatureExtractor
@@ -67,8 +73,20 @@ class OpenESSModel(BaseTrainer):
         losses['cons_pred_loss'] = l.detach()
         t_loss = t_loss + l
         if getattr(s, 'if_spatial_contrastive', False):
-            k = hip.superpixel_pool(feat_recon, superpixels, 30)          # superpixel_size hard-coded to 30 (:506)
-            q = hip.superpixel_pool(feat_frame, superpixels, 30)
+            sps = self.pool_superpixel_size                               # superpixel_size hard-coded to 30 (:506)
+            # row count from the loader (host side, last item of a prepared batch): no device sync here
+            S = batch[-1] if len(batch) > 5 and isinstance(batch[-1], int) else None
+            if isinstance(feat_recon, hip.UpsampledFeature):
+                # both maps are pooled over the same superpixels from the same geometry: one pooling matrix serves the four products
+                if S is None:
+                    off = torch.arange(0, superpixels.shape[0] * sps, sps, device=superpixels.device)[:, None, None]
+                    S = int((superpixels + off).max().item()) + 1
+                m = hip.pool_matrix(superpixels, feat_recon.x.shape[2:], sps, S, feat_recon.align_corners)
+                k = feat_recon.pool(superpixels, sps, S, matrix=m)
+                q = feat_frame.pool(superpixels, sps, S, matrix=m)
+            else:
+                k = hip.superpixel_pool(feat_recon, superpixels, sps, S=S)
+                q = hip.superpixel_pool(feat_frame, superpixels, sps, S=S)
             l = self.nce_loss(k, q)
             losses['contrastive_nce_loss'] = l.detach()
             t_loss = t_loss + l

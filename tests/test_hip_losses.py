@@ -459,3 +459,52 @@ def test_upsampled_feature_pool_through_the_pooling_matrix(B, C, h, w, Ho, Wo, d
     # the materialised path (full-resolution tensor -> K7) agrees to its own rounding
     km = hip.superpixel_pool(hip.UpsampledFeature(y, (Ho, Wo)).materialize(), sp, sps, S)
     assert float((km.detach().double() - kd.detach()).abs().max() / kd.detach().abs().max()) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.gpu
+def test_l1_mean_of_two_upsampled_features_and_dense_cosine():
+    """(a) hip.l1_mean on two hip.UpsampledFeature = nn.L1Loss on the two interpolated maps (training/openess_trainer.py:497 on
+    models/deeplabv3.py:184's outputs), computed as mean |up(a - b)|: loss 2e-3 relative to float64 of the reference ops (one
+    bf16 rounding of the difference and one of the upsampled map), gradients: cosine with the float64 gradient >= 0.995 (sign
+    flips where |up(a - b)| is within a bf16 ulp of zero).  (b) vectorised / tail / single-operand L1 against torch.
+    (c) cosine consistency on fp32 channels_last logits with K = 11, 19, 6 (dense small-C kernels): loss 1e-6, gradients 1e-5 of
+    float64 autograd of mean(1 - cosine_similarity)."""
+    from openess_amd import hip
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    B, C, h, w, Ho, Wo = 2, 64, 6, 9, 90, 140
+    a = torch.randn(B, C, h, w, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    b = torch.randn(B, C, h, w, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    l = hip.l1_mean(hip.UpsampledFeature(a, (Ho, Wo)), hip.UpsampledFeature(b, (Ho, Wo)))
+    l.backward()
+    ad, bd = a.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    up = lambda t: torch.nn.functional.interpolate(t, size=(Ho, Wo), mode="bilinear", align_corners=False)
+    ld = (up(ad) - up(bd)).abs().mean()
+    ld.backward()
+    assert abs(float(l.detach()) - float(ld.detach())) / float(ld.detach()) < 2e-3
+    cos = torch.nn.functional.cosine_similarity
+    assert float(cos(a.grad.double().flatten(), ad.grad.flatten(), dim=0)) > 0.995
+    assert float(cos(b.grad.double().flatten(), bd.grad.flatten(), dim=0)) > 0.995
+    # (b)
+    for n, dt in ((8 * 1000 + 5, torch.bfloat16), (4 * 777 + 3, torch.float32), (64, torch.bfloat16)):
+        x = torch.randn(n, generator=g).to(dev).to(dt).requires_grad_(True)
+        y = torch.randn(n, generator=g).to(dev).to(dt).requires_grad_(True)
+        l = hip.l1_mean(x.view(1, 1, 1, n), y.view(1, 1, 1, n))
+        l.backward()
+        ref = (x.detach().double() - y.detach().double()).abs().mean()
+        assert abs(float(l.detach()) - float(ref)) < 1e-6 * max(1.0, float(ref))
+        sg = torch.sign(x.detach().float() - y.detach().float()) / n
+        assert torch.allclose(x.grad.float(), sg.to(dt).float(), atol=0, rtol=0) and torch.allclose(y.grad.float(), (-sg).to(dt).float(), atol=0, rtol=0)
+    # (c)
+    for K in (11, 19, 6):
+        P = (2, 37, 53)
+        la = torch.randn(P[0], K, P[1], P[2], generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        lb = torch.randn(P[0], K, P[1], P[2], generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        l = hip.cosine_mean_loss(la, lb)
+        l.backward()
+        xd, yd = la.detach().double().requires_grad_(True), lb.detach().double().requires_grad_(True)
+        ld = (1 - torch.nn.functional.cosine_similarity(xd, yd, dim=1)).mean()
+        ld.backward()
+        assert abs(float(l.detach()) - float(ld.detach())) < 1e-6
+        for got, ref in ((la.grad, xd.grad), (lb.grad, yd.grad)):
+            assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1e-5
