@@ -179,8 +179,27 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
             }
         }
     };
+    // Residual rows of this thread's output pieces are requested all at once between the staging writes and the barrier (the
+    // accumulators are dead there, so the ITERS 16-byte pieces -- 16 on the 256 x 256 tile, 8 / 4 on the 128- / 64-row tiles --
+    // reuse their registers): one L2 / HBM latency under the barrier instead of one per store-loop iteration (the 512 -> 2048
+    // layer at M = 140 800 ran 657 us with a residual against 417 us without one: a workgroup that owns its CU has no other
+    // wave to hide the loads).  Requested before the staging they would cost the 128-row kernels their third wave per SIMD.
+    constexpr int CHUNKS_N = BN / 8;                       // 16-byte chunks per tile row
+    constexpr int ITERS = (BMX * CHUNKS_N + NTHREADS - 1) / NTHREADS;
     if (a.stats) stage(std::true_type{});
     else stage(std::false_type{});
+    uint4 rsv[ITERS];
+    if (a.residual) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int idx = tid + it * NTHREADS;
+            const int ml = idx / CHUNKS_N, cn = idx - ml * CHUNKS_N;
+            const int m = m0 + ml, n = n0 + cn * 8;
+            rsv[it] = make_uint4(0u, 0u, 0u, 0u);
+            if (idx < BMX * CHUNKS_N && m < a.M && n + 8 <= a.Cout)
+                rsv[it] = *reinterpret_cast<const uint4*>(a.residual + (long long)m * a.res_pix_stride + n);
+        }
+    }
     __syncthreads();
     if (a.stats && tid < BN) {
         float s1 = 0.f, s2 = 0.f;
@@ -198,8 +217,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
             }
         }
     }
-    constexpr int CHUNKS_N = BN / 8;                       // 16-byte chunks per tile row
-    for (int idx = tid; idx < BMX * CHUNKS_N; idx += NTHREADS) {
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + it * NTHREADS;
+        if (idx >= BMX * CHUNKS_N) break;
         const int ml = idx / CHUNKS_N, cn = idx - ml * CHUNKS_N;
         const int m = m0 + ml, n = n0 + cn * 8;
         if (m >= a.M || n >= a.Cout) continue;
@@ -210,7 +231,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a,
         rs.q4 = make_uint4(0u, 0u, 0u, 0u);
         const bool full = n + 8 <= a.Cout;
         if (a.residual) {
-            if (full) rs.q4 = *reinterpret_cast<const uint4*>(a.residual + (long long)m * a.res_pix_stride + n);
+            if (full) rs.q4 = rsv[it];
             else {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) if (n + q < a.Cout) rs.h[q] = a.residual[(long long)m * a.res_pix_stride + n + q];
