@@ -104,6 +104,36 @@ def test_conv_small_cout_f32_logits_and_residual():
     np.testing.assert_allclose(y.float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, R, pad: one geometry per kernel that ends in conv_epilogue
+    (2, 23, 29, 64, 76, 1, 0),          # 128-row tile, ragged channel tail (Cout % 8 == 4) + residual: per-element tail loads
+    (8, 55, 80, 512, 128, 1, 0),        # tile-quantisation rule -> 64-row tiles (550 of them), 4 residual pieces per thread
+    (2, 110, 160, 64, 256, 1, 0),       # K <= 256 -> BK = 32 ring kernel, 8 pieces per thread
+    (2, 110, 160, 256, 256, 3, 1),      # row-halo 3x3 kernel
+    (8, 110, 160, 256, 512, 1, 0),      # >= 400 tiles of 256 x 256: 16 pieces per thread
+])
+def test_conv_residual_epilogue_on_every_tile_shape(case):
+    """out = relu(conv + bias + residual): the residual rows are requested as one batch per thread before the barrier of the
+    epilogue (conv_epilogue); every tile shape, a ragged channel tail, rows beyond M, a strided residual view."""
+    from openess_amd import hip
+    B, H, W, Cin, Cout, R, pad = case
+    torch.manual_seed(Cin + Cout)
+    x = torch.randn(B, H, W, Cin, device="cuda").bfloat16()
+    w = torch.randn(Cout, Cin, R, R, device="cuda") / (Cin * R * R) ** 0.5
+    bias = torch.randn(Cout, device="cuda")
+    Cw = (Cout + 7) // 8 * 8 + 8
+    res = torch.randn(B, H, W, Cw, device="cuda").bfloat16()[..., :Cout]         # views: pixel stride (multiple of 8) != Cout
+    out = torch.zeros(B, H, W, Cw, device="cuda", dtype=torch.bfloat16)
+    y = hip.conv2d_nhwc(x, hip.pack_conv_weight(w), bias, Cout, R, R, 1, pad, 1, relu=True, residual=res, out=out[..., :Cout])
+    assert float(out[..., Cout:].abs().max()) == 0.0                               # nothing written past the last channel
+    ref = (ref_conv(x, w, bias, 1, pad, 1).bfloat16().float() + res.float()).clamp_min(0)
+    err = (y.float() - ref).abs()
+    assert float(err.max()) <= 2.0 ** -7 * float(ref.abs().max()) + 2e-2
+    assert float(err.mean()) <= 4e-3 * float(ref.abs().mean()) + 1e-4
+    y2 = hip.conv2d_nhwc(x, hip.pack_conv_weight(w), bias, Cout, R, R, 1, pad, 1, relu=True, residual=res)
+    assert torch.equal(y, y2)
+
+
 def test_conv_channel_slices_of_concat_buffers():
     """Input read from, and output written into, channel slices of wider NHWC buffers (ConvLSTM cat(x,h))."""
     from openess_amd import hip
