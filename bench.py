@@ -561,14 +561,22 @@ def main():
     if rank == 0 and extras and world == 1 and a.workload == "frame2voxel_pixel_distill":
         # BASELINE configs[2] (openess_trainer full path) and configs[4] (fine-tune / linear-probe): the stage-2/3 trainers and
         # OpenESSModel built through train.py's dispatch at the BASELINE size, train_step on a resident batch (tools/bench_stage2.py)
+        # Each trainer runs in its OWN process, as train.py would run it (in this process, after the headline / ingest / loader
+        # blocks, the last case read 236 event-frames/s where the same command alone reads 309: allocator and registry state of
+        # the workloads before it).
         try:
             torch.cuda.empty_cache()
-            import contextlib
             if os.path.join(ROOT, "tools") not in sys.path:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_stage2
-            with contextlib.redirect_stdout(sys.stderr):
-                out["configs"].update({"stage2:" + k: v for k, v in bench_stage2.measure(steps=max(10, a.steps // 5)).items()})
+            for case in [c[0] for c in bench_stage2.CASES]:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_stage2.py"), "--only", case, "--steps",
+                                    str(max(10, a.steps // 5))], capture_output=True, text=True, timeout=600)
+                lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
+                if r.returncode == 0 and lines:
+                    out["configs"].update({"stage2:" + k: v for k, v in json.loads(lines[-1]).items()})
+                else:
+                    out["configs"]["stage2:" + case] = {"error": (r.stderr or "")[-300:]}
         except Exception as e:      # never cost the headline
             out["configs"]["stage2_error"] = repr(e)[:300]
     if rank == 0:
