@@ -503,6 +503,17 @@ def main():
                     "avg_launch_us": round(conv_stats["ms"] * 1e3 / max(conv_stats["launches"], 1), 2),
                     "algorithmic_gflop_per_launch": round(conv_stats["flops"] / max(conv_stats["launches"], 1) / 1e9, 2),
                     "share_of_step_time": round(conv_stats["ms"] / (dt * 1e3), 3)}
+            # the ONE dominant kernel on its own: every grouped ConvLSTM launch (conv3x3_halo_group_kernel<1>) with the FLOPs of
+            # exactly the levels that launch carried (a stage's first / last launches carry two levels, not three)
+            grp = [(n, tm, fl) for k, (n, tm, fl) in conv_stats["by_shape"].items()
+                   if k and k[0] == "group" and all(isinstance(s, tuple) and s[-1] == "lstm" for s in k[1:])]
+            if grp:
+                gn, gms, gfl = (sum(g[i] for g in grp) for i in range(3))
+                roof["dominant_kernel"] = {"name": "conv3x3_halo_group_kernel<1>", "launches_per_step": round(gn / a.steps, 2),
+                                           "sum_gflop": round(gfl / a.steps / 1e9, 1), "sum_us": round(gms / a.steps * 1e3, 1),
+                                           "achieved": round(gfl / (gms * 1e-3) / 1e12, 1), "unit": "TFLOP/s",
+                                           "frac": round(gfl / (gms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                           "share_of_step_time": round(gms / (dt * 1e3), 3)}
         out = {"metric": "event-frames/sec fwd+bwd @640x480 B=8", "value": round(value, 2), "unit": "event-frames/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
@@ -526,6 +537,13 @@ def main():
                                      "HIP stream under step i (north_star 'straight from pinned host event buffers'); never `value`"}
         if world == 1:
             out["stages"] = stage_rooflines(wl, rank, device)
+            if rank == 0 and out.get("roofline") is not None:
+                # the stage fractions north_star sets targets for, inside the `roofline` object the driver's record keeps
+                short = {"voxelizer": "voxelizer", "voxelizer_f32": "voxelizer_f32_interface", "scatter_mean_bf16": "scatter_mean_bf16_blocks",
+                         "scatter_mean_fp32": "scatter_mean_fp32_blocks", "deeplabv3_fwd": "deeplabv3_forward",
+                         "vit_fwd": "maskclip_vit_b16_forward", "teacher_fwd": "dilated_r50_teacher_forward"}
+                out["roofline"]["stage_fracs"] = {k: out["stages"][v].get("frac") for k, v in short.items() if v in out["stages"]}
+                out["roofline"]["stage_ms"] = {k: out["stages"][v].get("ms") for k, v in short.items() if v in out["stages"]}
     # ---- the other single-GPU BASELINE configurations, same timing protocol
     if extras and a.workload == "frame2voxel_pixel_distill":
         del wl

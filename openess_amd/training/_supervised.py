@@ -30,9 +30,21 @@ class SupervisedTrainer(BaseTrainer):
         return False
 
     def init_fn(self):
+        """finetune_trainer.py:86-88 (and its two siblings): models, then optimisers, then the loss object."""
+        s = self.settings
+        self.buildModels()
+        self.createOptimizerDict()
+        self.task_loss = TaskLoss(losses=list(s.task_loss), gamma=2.0, num_classes=s.semseg_num_classes, ignore_index=255)
+        # One arithmetic mode (bf16 storage, fp32 accumulation) whatever use_amp says; bf16 has fp32's exponent range, so the
+        # GradScaler the reference builds under use_amp (sup_only_trainer.py:247-252) has nothing to do and is None here.
+        self.scaler = None
+        if self.amp_requested():
+            self.settings.logger.info("use_amp requested: bf16 storage / fp32 accumulation is always on; no GradScaler is built")
+
+    def buildModels(self):
+        """finetune_trainer.py:104-196: `models_dict` (front_sensor_b + back_end, or model_recon) and the reconstructor."""
         s = self.settings
         self.models_dict = {}
-        self.task_loss = TaskLoss(losses=list(s.task_loss), gamma=2.0, num_classes=s.semseg_num_classes, ignore_index=255)
         text_path = '' if not s.text_embeddings_path else s.text_embeddings_path
         try:
             open(text_path).close() if text_path else None
@@ -51,27 +63,31 @@ class SupervisedTrainer(BaseTrainer):
                                             skip_type=s.skip_connect_task_type, text_embeddings_path=text_path,
                                             materialize_ch256=False, **self.backend_kwargs())
             self.models_dict['back_end'] = self.task_backend
-            trainable = [p for p in self.task_backend.parameters() if p.requires_grad]
-            self.optimizers_dict = {'optimizer_voxel': AdamW(trainable, lr=s.lr_voxel)}
         elif s.config_option == 'frame2recon':
             self.model_recon = deeplabv3_resnet50(num_classes=s.semseg_num_classes, text_embeddings_path=text_path,
                                                   output_stride=s.output_stride, pretrained_backbone=s.pretrained_backbone,
                                                   **self.deeplab_kwargs())
             self.models_dict['model_recon'] = self.model_recon
-            trainable = [p for p in self.model_recon.parameters() if p.requires_grad]
-            self.optimizers_dict = {'optimizer_recon': AdamW(trainable, lr=s.lr_recon)}
         else:
             raise NotImplementedError(s.config_option)
         for m in self.models_dict.values():
             m.to(self.device)
-        # One arithmetic mode (bf16 storage, fp32 accumulation) whatever use_amp says; bf16 has fp32's exponent range, so the
-        # GradScaler the reference builds under use_amp (sup_only_trainer.py:247-252) has nothing to do and is None here.
-        self.scaler = None
-        if self.amp_requested():
-            self.settings.logger.info("use_amp requested: bf16 storage / fp32 accumulation is always on; no GradScaler is built")
         if 'front_sensor_b' in self.models_dict:
             self.reconstructor = ImageReconstructor(self.front_end_sensor_b, self.input_height, self.input_width,
                                                     s.nr_temporal_bins_b, self.device, s.e2vid_config)
+
+    def createOptimizerDict(self):
+        """finetune_trainer.py:198-238: one AdamW over the trainable parameters of the student (optimizer_voxel / optimizer_recon)."""
+        if not self.is_training:
+            self.optimizers_dict = {}
+            return
+        s = self.settings
+        if 'back_end' in self.models_dict:
+            trainable = [p for p in self.task_backend.parameters() if p.requires_grad]
+            self.optimizers_dict = {'optimizer_voxel': AdamW(trainable, lr=s.lr_voxel)}
+        else:
+            trainable = [p for p in self.model_recon.parameters() if p.requires_grad]
+            self.optimizers_dict = {'optimizer_recon': AdamW(trainable, lr=s.lr_recon)}
 
     def _latents(self, event):
         s = self.settings

@@ -21,8 +21,9 @@ from .ddp import GradAllReduce, broadcast_module_states, shard_indices
 class BaseTrainer(object):
     is_training = True
 
-    def __init__(self, settings):
+    def __init__(self, settings, train=True):
         self.settings = settings
+        self.is_training = bool(train)           # reference: every trainer's __init__(settings, train=True) (pretrain_trainer.py:82-83)
         if not torch.cuda.is_available():
             raise RuntimeError("openess_amd trainers need the GPU (no CPU fallback in the product path)")
         self.device = torch.device('cuda', torch.cuda.current_device())

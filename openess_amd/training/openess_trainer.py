@@ -28,10 +28,20 @@ class OpenESSModel(BaseTrainer):
     lazy_features = True
 
     def init_fn(self):
+        """openess_trainer.py:84-86: models, then optimisers, then the loss objects."""
         s = self.settings
         if s.config_option != 'frame2recon':
             raise NotImplementedError("OpenESSModel: only config_option 'frame2recon' is runnable in the reference "
                                       "(openess_trainer.py:360-535); see the module docstring")
+        self.buildModels()
+        self.createOptimizerDict()
+        self.task_loss = TaskLoss(losses=list(s.task_loss), gamma=2.0, num_classes=s.semseg_num_classes, ignore_index=255)
+        self.nce_loss = NCELoss(temperature=0.07)
+        self.l1_loss = torch.nn.L1Loss()
+
+    def buildModels(self):
+        """openess_trainer.py:104-225: the two DeepLabv3 students and, when its three files exist, the frozen MaskCLIP tower."""
+        s = self.settings
         mk = lambda: deeplabv3_resnet50(num_classes=s.semseg_num_classes, text_embeddings_path='',
                                         output_stride=s.output_stride, pretrained_backbone=s.pretrained_backbone)
         self.model_recon, self.model_frame = mk(), mk()
@@ -45,9 +55,13 @@ class OpenESSModel(BaseTrainer):
             self.models_dict['model_clip'] = self.model_clip
         for m in self.models_dict.values():
             m.to(self.device)
-        self.task_loss = TaskLoss(losses=list(s.task_loss), gamma=2.0, num_classes=s.semseg_num_classes, ignore_index=255)
-        self.nce_loss = NCELoss(temperature=0.07)
-        self.l1_loss = torch.nn.L1Loss()
+
+    def createOptimizerDict(self):
+        """openess_trainer.py:228-258: optimizer_recon / optimizer_frame."""
+        if not self.is_training:
+            self.optimizers_dict = {}
+            return
+        s = self.settings
         self.optimizers_dict = {
             'optimizer_recon': AdamW([p for p in self.model_recon.parameters() if p.requires_grad], lr=s.lr_recon),
             'optimizer_frame': AdamW([p for p in self.model_frame.parameters() if p.requires_grad], lr=s.lr_frame)}

@@ -8,6 +8,13 @@ from .pretrain_step import PretrainStep
 
 class OpenESSPretrainModel(BaseTrainer):
     def init_fn(self):
+        """pretrain_trainer.py:87-89: models, then optimisers, then the loss objects."""
+        self.buildModels()
+        self.createOptimizerDict()
+        self.task_loss, self.nce_loss = self.step.task_loss, self.step.nce_loss
+
+    def buildModels(self):
+        """pretrain_trainer.py:106-229: `models_dict` (front_sensor_b / back_end / model_frame / model_recon) and the reconstructor."""
         s = self.settings
         text = None
         if s.text_embeddings_path and torch.cuda.is_available():
@@ -27,13 +34,20 @@ class OpenESSPretrainModel(BaseTrainer):
                                  lr=s.lr_voxel, weight_task_loss=s.weight_task_loss, task_loss=tuple(s.task_loss),
                                  output_stride=s.output_stride, device=self.device, text_embeddings=text)
         self.models_dict = self.step.models_dict
+        self.reconstructor = getattr(self.step, 'reconstructor', None)
+
+    def createOptimizerDict(self):
+        """pretrain_trainer.py:231-243: one AdamW per trained module, keys optimizer_voxel / optimizer_recon / optimizer_frame,
+        learning rates from the settings."""
+        if not self.is_training:
+            self.optimizers_dict = {}
+            return
+        s = self.settings
         self.optimizers_dict = self.step.optimizers_dict
         for key, lr in (('optimizer_voxel', s.lr_voxel), ('optimizer_recon', s.lr_recon), ('optimizer_frame', s.lr_frame)):
             if key in self.optimizers_dict:
                 for g in self.optimizers_dict[key].param_groups:
                     g['lr'] = lr
-        self.reconstructor = getattr(self.step, 'reconstructor', None)
-        self.task_loss, self.nce_loss = self.step.task_loss, self.step.nce_loss
 
     def task_train_step(self, batch):
         return self.step.task_train_step(batch)
