@@ -1,5 +1,6 @@
 // HBM-bound pointwise kernels around the MFMA convolutions (gfx950): ConvLSTM gate fusion and the
 // fused EventPreprocessor-apply + NCHW->NHWC(8) bf16 layout change.  16-byte accesses per lane.
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "oess.h"
@@ -248,6 +249,10 @@ int oess_linear_probe_bwd_f32(const float* x, const float* grad_y, const float* 
     long long g = (P + LP_TP - 1) / LP_TP;
     if (g > LP_MAX_ROWS) g = LP_MAX_ROWS;
     const size_t lds = ((size_t)K * K + (size_t)2 * LP_TP * K) * sizeof(float);
+    if (lds > 64 * 1024) {          // K = 31, 32: 67-70 KB, above the 64 KB default dynamic-LDS limit
+        static std::once_flag once;
+        std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)&probe_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    }
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(probe_bwd_kernel, dim3((unsigned)g), dim3(LP_TP), lds, st, x, grad_y, w, (int64_t)P, K, grad_x, (double*)partials);
     hipLaunchKernelGGL(probe_bwd_finalize_kernel, dim3((unsigned)((K * K + K + 3) / 4)), dim3(256), 0, st, (const double*)partials, (int)g, K, grad_w, grad_bias);

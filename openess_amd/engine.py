@@ -77,10 +77,15 @@ class PackedWeight:
         return self.packed_flip
 
     @classmethod
-    def refresh_stale(cls):
-        """Repack every registered operand whose weight has a new version: one launch for the forward operands and one for
-        the data-gradient operands (tile transposes of the fresh forward operands).  Returns the number of operands packed."""
+    def refresh_stale(cls, device=None):
+        """Repack every registered operand ON `device` (default: the current device) whose weight has a new version: one launch
+        for the forward operands and one for the data-gradient operands (tile transposes of the fresh forward operands).
+        Operands of other devices are left stale for their own device's call: the pointer table is uploaded to, and the pack
+        kernel launched on, ONE device's current stream.  Returns the number of operands packed."""
         lib = hip._lib.load()
+        dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        if dev.index is None:
+            dev = torch.device('cuda', torch.cuda.current_device())
         rows = ([], [])                      # forward rows, flip rows
         nblk = [0, 0]
         members = []
@@ -92,6 +97,8 @@ class PackedWeight:
                 pw._wref = None              # no longer a plain operand (module cast / moved): get() repacks it on its own
                 cls._registry.discard(pw)
                 continue
+            if w.device != dev:
+                continue                     # another device's model: stays stale until that device refreshes
             members.append((pw, w))
             Cout, Cin, R, S = w.shape
             rows[0].append((w.data_ptr(), pw.packed.data_ptr(), Cout, Cin, R, S, 0, nblk[0]))
@@ -101,7 +108,6 @@ class PackedWeight:
                 nblk[1] += lib.oess_conv2d_pack_multi_blocks(Cout, Cin, R, S, 1)
         if not members:
             return 0
-        dev = members[0][1].device
         for which in (0, 1):
             if not rows[which]:
                 continue
@@ -112,8 +118,9 @@ class PackedWeight:
                 cls._table_cache[(dev.index, which)] = (key, table)
             else:
                 table = hit[1]
-            hip._lib.check(lib.oess_conv2d_pack_weight_multi(table.data_ptr(), len(rows[which]), nblk[which], which, hip._stream()),
-                           "oess_conv2d_pack_weight_multi")
+            with torch.cuda.device(dev):
+                hip._lib.check(lib.oess_conv2d_pack_weight_multi(table.data_ptr(), len(rows[which]), nblk[which], which,
+                                                                 torch.cuda.current_stream(dev).cuda_stream), "oess_conv2d_pack_weight_multi")
         for pw, w in members:
             b = pw._bref() if pw._bref is not None else None
             pw.key = (w._version, None if b is None else b._version, None, pw.key[3])
@@ -126,7 +133,7 @@ class PackedWeight:
                                         bn.running_var._version), cin_pad)
         if PackedWeight.group_enabled and key != self.key and self.packed is not None and self._wref is not None and self._wref() is weight and \
                 self.key is not None and self.key[2:] == key[2:]:
-            PackedWeight.refresh_stale()            # this operand and every other stale registered one, in one launch
+            PackedWeight.refresh_stale(weight.device)   # this operand and every other stale registered one of its device, in one launch
             if self.key[0] == key[0]:
                 self.key = key                      # (bias version: the fp32 bias tensor shares the parameter's storage)
         if key != self.key:
@@ -342,6 +349,9 @@ def bump_bn_counter(bn):
         bn.num_batches_tracked += 1
 
 
+_EVAL_BN_LOGGED = False
+
+
 def batch_norm_act(x, bn, relu=False, residual=None):
     """BatchNorm2d (+ residual add + ReLU) on a channels_last bf16 tensor, honouring bn.training exactly like
     nn.BatchNorm2d (batch statistics + running-stat update in train mode).  Train mode runs on the HIP norm kernels
@@ -354,10 +364,19 @@ def batch_norm_act(x, bn, relu=False, residual=None):
         if torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad or (r is not None and r.requires_grad)):
             return hip.batch_norm_train(x, bn, relu=relu, residual=r)
         return from_nhwc(hip.batch_norm_train_nhwc(nhwc(x), bn, relu=relu, residual=None if r is None else nhwc(r)))
-    y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training,
-                     0.0 if bn.momentum is None else bn.momentum, bn.eps)
     if bn.training:
-        bump_bn_counter(bn)
+        # the training path has ONE implementation (no eager fallback): a layout the HIP norm kernels do not take
+        # is a caller bug, not a reason to switch to ATen / MIOpen silently
+        raise ValueError(f"batch_norm_act: train-mode BatchNorm needs a channels_last bf16 tensor with C % 8 == 0 and C <= 2048, got "
+                         f"{tuple(x.shape)} {x.dtype} strides {tuple(x.stride())}")
+    # eval mode with un-folded running statistics (validation of a model whose BatchNorm was not folded at pack time): a plain affine
+    global _EVAL_BN_LOGGED
+    if not _EVAL_BN_LOGGED:
+        _EVAL_BN_LOGGED = True
+        import logging
+        logging.getLogger("openess_amd").info("batch_norm_act: eval-mode BatchNorm with un-folded statistics runs as an ATen affine (not on the training path)")
+    y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False,
+                     0.0 if bn.momentum is None else bn.momentum, bn.eps)
     if residual is not None:
         y = y + residual
     return F.relu(y) if relu else y

@@ -1268,6 +1268,9 @@ class _PoolMatrixMean(torch.autograd.Function):
         return gy.permute(0, 3, 1, 2), None, None
 
 
+POOL_MATRIX_MAX_BYTES = 256 << 20       # B = 8 at OS16: 18-26 MB; B = 32 at OS8 would be ~1 GB (see pool_matrix)
+
+
 def pool_matrix(superpixels, in_hw, superpixel_size, S, align_corners=False):
     """Pooling matrix of (bilinear upsample from in_hw to the size of `superpixels`) followed by the superpixel scatter-mean:
     an opaque device buffer for UpsampledFeature.pool / _PoolMatrixMean (2^-40 fixed-point weight sums + pixel counts)."""
@@ -1277,6 +1280,10 @@ def pool_matrix(superpixels, in_hw, superpixel_size, S, align_corners=False):
     h, w = int(in_hw[0]), int(in_hw[1])
     ids = superpixels.reshape(-1).contiguous().to(torch.int64)
     nbytes = lib.oess_pool_matrix_bytes(int(S), B, h, w)
+    if nbytes > POOL_MATRIX_MAX_BYTES:
+        # the matrix is dense S x (B h w) and both S and the column count grow with B: O(B^2) memset + scan per step.  Above the
+        # cap the caller pools the materialised tensor instead (UpsampledFeature.pool does that on a None matrix).
+        return None
     m = torch.empty(nbytes, dtype=torch.uint8, device=superpixels.device)
     _lib.check(lib.oess_pool_matrix_build(_ptr(ids), B, Ho, Wo, h, w, int(bool(align_corners)), int(superpixel_size), int(S), _ptr(m), nbytes,
                                           _stream()), "oess_pool_matrix_build")
@@ -1310,6 +1317,8 @@ class UpsampledFeature:
             S = int((superpixels + off).max().item()) + 1
         if matrix is None:
             matrix = pool_matrix(superpixels, self.x.shape[2:], superpixel_size, S, self.align_corners)
+        if matrix is None:              # above POOL_MATRIX_MAX_BYTES: the reference's own order, upsample then scatter-mean (K7)
+            return superpixel_pool(self.materialize(), superpixels, superpixel_size, S=S)
         return _PoolMatrixMean.apply(self.x, matrix, int(S))
 
 
@@ -1491,9 +1500,24 @@ def linear_probe(x, conv):
     """`conv(x)` for the linear-probe nn.Conv2d(K, K, 1) on fp32 channels_last logits [B, K, H, W], differentiable."""
     _need_gpu(x)
     K = x.shape[1]
-    if not _dense_cl(x) or K > 32 or tuple(conv.weight.shape) != (K, K, 1, 1) or conv.weight.dtype != torch.float32:
-        raise ValueError("linear_probe needs dense channels_last fp32 logits [B, K <= 32, H, W] and a K x K 1x1 convolution")
+    if K > 32 or tuple(conv.weight.shape) != (K, K, 1, 1) or conv.weight.dtype != torch.float32:
+        # outside the kernel's range (more than 32 classes, or not the K x K probe): the module's own convolution, said once
+        global _PROBE_WARNED
+        if not _PROBE_WARNED:
+            _PROBE_WARNED = True
+            import warnings
+            warnings.warn(f"linear_probe: K = {K} / weight {tuple(conv.weight.shape)} is outside the HIP kernel's range "
+                          "(K <= 32, K x K x 1 x 1 fp32); using nn.Conv2d for this layer")
+        return conv(x)
+    if not _dense_cl(x):        # any other layout / dtype of the logits: one re-layout, then the kernel
+        x = x.float().contiguous(memory_format=torch.channels_last)
+        if not _dense_cl(x):    # degenerate shapes (H * W == 1 ...) where channels_last strides are ambiguous
+            x = torch.empty_strided(x.shape, (x.shape[1] * x.shape[2] * x.shape[3], 1, x.shape[3] * x.shape[1], x.shape[1]),
+                                    dtype=torch.float32, device=x.device).copy_(x)
     return _LinearProbe.apply(x, conv.weight, conv.bias)
+
+
+_PROBE_WARNED = False
 
 
 def channel_sum(x_nhwc):

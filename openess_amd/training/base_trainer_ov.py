@@ -31,6 +31,7 @@ class BaseTrainer(object):
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.do_val_training_epoch = True
         self._png_pending = []                   # (slot, status tensor, file names) of device-decoded PNG maps not yet checked
+        self._png_batches = 0                    # batches that queued at least one status vector since the last check
         # Precision contract (INTEGRATION.md "Precision"): the reference's `use_amp` switches torch.autocast(fp16) + GradScaler
         # (pretrain_trainer.py:344-353).  This build has ONE numeric mode whatever the flag says: bf16 storage of activations /
         # activation gradients / MFMA weight operands, fp32 accumulation, fp32 master weights, optimiser state and losses; no
@@ -147,9 +148,10 @@ class BaseTrainer(object):
         end, and a bad file raises with its slot, path and reason."""
         pend = self._png_pending
         every = int(getattr(self.settings, 'png_check_every', 50))
-        if not pend or (not force and len(pend) < 3 * every):
+        if not pend or (not force and self._png_batches < every):      # counted in BATCHES, whatever the number of PNG slots per batch
             return
         self._png_pending = []
+        self._png_batches = 0
         allst = torch.cat([st.reshape(-1) for _, st, _ in pend])
         if not bool((allst != 0).any()):                           # the one sync
             return
@@ -218,6 +220,8 @@ class BaseTrainer(object):
         if len(sample_batched) != 7:            # datasets.synthetic_events.collate emits the 7-slot layout for every dataset
             raise ValueError(f"prepare_batch expects collate's 7-slot batch, got {len(sample_batched)} items")
         rest = [hip.h2d_async(t, self.device) if torch.is_tensor(t) else t for t in sample_batched[1:]]
+        if any(isinstance(t, dict) and 'png_bytes' in t for t in rest):
+            self._png_batches += 1
         for i, t in enumerate(rest):            # undecoded 8-bit PNG maps (device_png): one batched GPU decode per slot, flips included
             if isinstance(t, dict) and 'png_bytes' in t:
                 maps, status = hip.png_decode_gray8_batch(hip.h2d_async(t['png_bytes'], self.device), t['png_lengths'],

@@ -82,11 +82,17 @@ def test_png_status_queue_raises_with_slot_and_file_name():
     t.settings = SimpleNamespace(png_check_every=2)
     ok = torch.zeros(2, dtype=torch.int32)
     t._png_pending = [(2, ok, ['a.png', 'b.png']), (4, ok, None)]
-    t.check_png_status()                                          # 2 entries < 3 * 2: not checked yet
+    t._png_batches = 1                                            # both slots came from ONE batch
+    t.check_png_status()                                          # 1 batch < png_check_every = 2: not checked yet
     assert len(t._png_pending) == 2
+    t._png_batches = 2                                            # the interval counts batches, not PNG slots
+    t.check_png_status()
+    assert t._png_pending == [] and t._png_batches == 0
+    t._png_pending, t._png_batches = [(2, ok, None)], 1
     t.check_png_status(force=True)
     assert t._png_pending == []
     t._png_pending = [(2, ok, ['a.png', 'b.png']), (5, torch.tensor([0, 3], dtype=torch.int32), ['c.png', 'd.png'])]
+    t._png_batches = 1
     with pytest.raises(RuntimeError, match=r"batch slot 5, sample d\.png: unsupported"):
         t.check_png_status(force=True)
     assert t._png_pending == []
