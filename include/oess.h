@@ -35,7 +35,7 @@ typedef void* oess_stream_t; /* hipStream_t */
 /* Library / device identification.  OESS_ABI_VERSION is bumped whenever a signature of this header changes or an entry point
  * is removed; oess_abi_version() returns the value the library was built with and the ctypes binding (openess_amd/_lib.py,
  * ABI_VERSION) refuses a library whose value differs. */
-#define OESS_ABI_VERSION 8
+#define OESS_ABI_VERSION 9
 int oess_abi_version(void);
 const char* oess_build_info(void);           /* "liboess <ver> gfx950 hipcc <ver>" */
 const char* oess_strerror(int code);
@@ -496,6 +496,33 @@ int oess_pool_matrix_fwd(const void* matrix, const void* y, long long y_pix_stri
                          float* k, float* count, oess_stream_t stream);
 int oess_pool_matrix_bwd(const void* matrix, const float* grad_k, int B, int h, int w, int C, int S, void* grad_y, long long gy_pix_stride,
                          int is_bf16, oess_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small ops of the DeepLabv3 training path (round 5; they replace the last ATen / MIOpen / hipBLASLt launches of that path).
+ *
+ * MaxPool2d(kernel 3, stride 2, padding 1) of the ResNet stem (models/_resnet.py:124, 197 of the reference) on NHWC bf16:
+ *   out [B x Ho x Wo x C], Ho = (H - 1) / 2 + 1; idx (nullable): [B x Ho x Wo x C] bytes, winning tap 0..8 (row-major, ATen's tie
+ *   rule: first maximum, NaN wins); backward: grad_in [B x H x W x C] written once per element (gather form, deterministic).
+ * Dropout (models/deeplabv3.py:343 nn.Dropout(0.1)): y = x * keep / (1 - p), keep from Philox-4x32-10 keyed by (seed, offset,
+ *   element); the backward pass is the same call on the gradient with the same (seed, offset).  x == y allowed.
+ * ASPP image-pooling branch (models/deeplabv3.py:305-316): in_scale * pooled [B x Cin] fp32 (AdaptiveAvgPool2d(1): per-sample
+ *   channel sums and in_scale = 1 / (H W)) -> 1x1 conv w [Cout x Cin] -> BatchNorm2d in train mode over the B samples (running
+ *   stats updated, unbiased variance) -> ReLU = z [B x Cout] (+ a bf16 copy, nullable); y_pre [B x Cout] and stat [2 x Cout] = {mean, rstd} are kept for
+ *   the backward; 2 <= B <= 16.  Backward: grad_z [B x Cout] -> grad_w [Cout x Cin], grad_gamma / grad_beta [Cout], and the
+ *   gradient of the per-sample sums as bf16 [B x Cin] (nullable: frozen producer); dy_scratch [B x Cout] floats.
+ * ------------------------------------------------------------------------------------------ */
+int oess_maxpool3x3s2_fwd_nhwc_bf16(const void* in, long long in_pix_stride, int B, int H, int W, int C, void* out, long long out_pix_stride,
+                                    unsigned char* idx, oess_stream_t stream);
+int oess_maxpool3x3s2_bwd_nhwc_bf16(const void* grad_out, long long go_pix_stride, const unsigned char* idx, int B, int H, int W, int C,
+                                    void* grad_in, long long gi_pix_stride, oess_stream_t stream);
+int oess_dropout_nhwc_bf16(const void* x, long long x_pix_stride, void* y, long long y_pix_stride, long long P, int C, float p,
+                           unsigned long long seed, unsigned long long offset, oess_stream_t stream);
+int oess_aspp_pool_fwd_f32(const float* pooled, float in_scale, const float* w, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float momentum, float eps, int B, int Cin, int Cout, float* y_pre, float* stat, float* z,
+                           void* z_bf16, oess_stream_t stream);
+int oess_aspp_pool_bwd_f32(const float* grad_z, const float* pooled, float in_scale, const float* w, const float* gamma, const float* y_pre,
+                           const float* stat, const float* z, int B, int Cin, int Cout, float* dy_scratch, float* grad_w,
+                           float* grad_gamma, float* grad_beta, void* grad_pooled_bf16, oess_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OESS_LIB_PATH") or os.path.join(_HERE, "liboess.so")      # override: A/B builds of the same ABI
 
-ABI_VERSION = 8          # == OESS_ABI_VERSION of include/oess.h (tests/test_abi.py keeps the two equal)
+ABI_VERSION = 9          # == OESS_ABI_VERSION of include/oess.h (tests/test_abi.py keeps the two equal)
 
 c_i64 = ctypes.c_int64
 c_ll = ctypes.c_longlong
@@ -19,6 +19,7 @@ c_f = ctypes.c_float
 c_d = ctypes.c_double
 c_vp = ctypes.c_void_p
 c_sz = ctypes.c_size_t
+c_u64 = ctypes.c_uint64
 
 class ConvLstmDesc(ctypes.Structure):
     """oess_convlstm_desc_t (include/oess.h): one problem of oess_convlstm_fused_group_bf16."""
@@ -124,6 +125,11 @@ SIGNATURES = {
     "oess_png_decode_gray8_batch": (c_int, [c_vp, c_vp, c_ll, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_sz, c_vp, c_vp, c_vp]),
     "oess_norm_reduce_finalize_tile_stats": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_f,
                                                      c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "oess_maxpool3x3s2_fwd_nhwc_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp, c_ll, c_vp, c_vp]),
+    "oess_maxpool3x3s2_bwd_nhwc_bf16": (c_int, [c_vp, c_ll, c_vp, c_int, c_int, c_int, c_int, c_vp, c_ll, c_vp]),
+    "oess_dropout_nhwc_bf16": (c_int, [c_vp, c_ll, c_vp, c_ll, c_ll, c_int, c_f, c_u64, c_u64, c_vp]),
+    "oess_aspp_pool_fwd_f32": (c_int, [c_vp, c_f, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_f, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "oess_aspp_pool_bwd_f32": (c_int, [c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
 }
 
 _lib = None

@@ -176,8 +176,10 @@ def conv2d_infer(x, pw, Cout, k, stride=1, pad=0, dil=1, relu=False, residual=No
     return from_nhwc(y)
 
 
-def _conv_backward(x, weight, pw, k, stride, pad, dil, gy, need_gx, need_gw, need_gb):
-    """Data / weight / bias gradients of conv2d on the MFMA kernels.  gy: channels_last bf16, logical NCHW."""
+def _conv_backward(x, weight, pw, k, stride, pad, dil, gy, need_gx, need_gw, need_gb, gx_add=None):
+    """Data / weight / bias gradients of conv2d on the MFMA kernels.  gy: channels_last bf16, logical NCHW.
+    gx_add: optional NHWC bf16 tensor of x's shape that the data-gradient kernel adds in its epilogue (another consumer's
+    gradient of the same x: the skip connection of a bottleneck), so that autograd has nothing left to sum."""
     gx = gw = gb = None
     Cin_x = x.shape[1]
     gy8 = gy if gy.shape[1] % 8 == 0 else to_cl_bf16(gy)
@@ -187,7 +189,7 @@ def _conv_backward(x, weight, pw, k, stride, pad, dil, gy, need_gx, need_gw, nee
             Hz = x.shape[2] - dil * (k - 1) + 2 * pad
             Wz = x.shape[3] - dil * (k - 1) + 2 * pad
             g_in = hip.zero_insert(g_in, stride, Hz, Wz)
-        gx = from_nhwc(hip.conv2d_nhwc(g_in, pw.flip(), None, Cin_x, k, k, 1, dil * (k - 1) - pad, dil))
+        gx = from_nhwc(hip.conv2d_nhwc(g_in, pw.flip(), None, Cin_x, k, k, 1, dil * (k - 1) - pad, dil, residual=gx_add))
     if need_gw or need_gb:
         Cout, Cin = weight.shape[0], weight.shape[1]
         if need_gw:
@@ -230,7 +232,13 @@ class _ConvBNTrainFn(torch.autograd.Function):
     weight gradients."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, residual, pw, k, stride, pad, dil, relu, eps, momentum, running_mean, running_var):
+    def forward(ctx, x, weight, gamma, beta, residual, pw, k, stride, pad, dil, relu, eps, momentum, running_mean, running_var,
+                skip_in=None, skip_out=None):
+        # skip_in / skip_out: one dict shared by the FIRST and the LAST conv of a bottleneck whose identity is the block input x
+        # (models/_resnet.py Bottleneck without downsample).  x then has two consumers -- conv1 and the residual add -- and
+        # autograd would sum their gradients with an ATen add over the whole activation.  Instead the last node parks its
+        # residual gradient in the dict (and reports None for it) and the first node, which by data dependence runs later in
+        # the backward pass, lets its data-gradient kernel add it in the epilogue.
         lib = hip._lib.load()
         Cout = weight.shape[0]
         xn = nhwc(x)
@@ -265,6 +273,7 @@ class _ConvBNTrainFn(torch.autograd.Function):
                                                          Cout, hip._stream()), "oess_norm_apply_nhwc_bf16")
         ctx.save_for_backward(x, weight, gamma, y, st, out if relu else None)
         ctx.meta = (pw, k, stride, pad, dil, relu, residual is not None)
+        ctx.skip_in, ctx.skip_out = skip_in, skip_out
         return from_nhwc(out)
 
     @staticmethod
@@ -293,12 +302,20 @@ class _ConvBNTrainFn(torch.autograd.Function):
         gres = None
         if has_res:
             gres = from_nhwc(dres) if dres is not None else gy                                  # no ReLU: the residual sees dy itself
+        if gres is not None and ctx.skip_out is not None and ctx.needs_input_grad[4]:
+            ctx.skip_out['g'] = nhwc(gres)          # handed to the block's first conv; autograd sees no residual gradient here
+            gres = None
+        gx_add = None
+        if ctx.skip_in is not None:
+            gx_add = ctx.skip_in.pop('g', None)
+            if gx_add is not None and (not ctx.needs_input_grad[0] or stride != 1 or tuple(gx_add.shape) != tuple(nhwc(x).shape)):
+                raise RuntimeError("conv_bn skip-gradient hand-over: the block input needs a gradient of its own shape")
         gx, gw, _ = _conv_backward(x, weight, pw, k, stride, pad, dil, from_nhwc(dy), ctx.needs_input_grad[0],
-                                   ctx.needs_input_grad[1], False)
-        return (gx, gw, dgb[1].to(gamma.dtype), dgb[0].to(gamma.dtype), gres) + (None,) * 10
+                                   ctx.needs_input_grad[1], False, gx_add=gx_add)
+        return (gx, gw, dgb[1].to(gamma.dtype), dgb[0].to(gamma.dtype), gres) + (None,) * 12
 
 
-def conv_bn_train(x, conv, bn, pw, relu=False, residual=None):
+def conv_bn_train(x, conv, bn, pw, relu=False, residual=None, skip_in=None, skip_out=None):
     """Differentiable bias-free conv + train-mode BatchNorm2d [+ residual] [+ ReLU] (one autograd node, statistics from the conv
     epilogue).  x: logical NCHW channels_last bf16 with C % 8 == 0."""
     k, s, p, d = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0]
@@ -306,7 +323,7 @@ def conv_bn_train(x, conv, bn, pw, relu=False, residual=None):
     if residual is not None and (residual.dtype != torch.bfloat16 or residual.stride(1) != 1):
         residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     y = _ConvBNTrainFn.apply(x, conv.weight, bn.weight, bn.bias, residual, pw, k, s, p, d, bool(relu), float(bn.eps),
-                             0.0 if bn.momentum is None else float(bn.momentum), bn.running_mean, bn.running_var)
+                             0.0 if bn.momentum is None else float(bn.momentum), bn.running_mean, bn.running_var, skip_in, skip_out)
     bump_bn_counter(bn)
     return y
 

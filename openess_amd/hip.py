@@ -1567,3 +1567,156 @@ def conv_bn_train_nhwc(x, packed, Cout, R, S, stride, pad, dil, bn, relu=False, 
                                              _ptr(y), yps, _stream()), "oess_norm_apply_nhwc_bf16")
     _engine.bump_bn_counter(bn)
     return y
+
+
+# ------------------------------------------------------------------------------------------ small ops of the DeepLabv3 path (round 5)
+class _MaxPool3x3s2(torch.autograd.Function):
+    """nn.MaxPool2d(3, stride=2, padding=1) of the ResNet stem on a channels_last bf16 map (models/_resnet.py:124,197 of the
+    reference): forward keeps one byte per output element (the winning tap), backward is a gather (every input element written
+    once, fixed order)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        xn = x.permute(0, 2, 3, 1)
+        B, H, W, C, ps = _nhwc_geom(xn)
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((B, Ho, Wo, C), dtype=torch.bfloat16, device=x.device)
+        need = ctx.needs_input_grad[0]
+        idx = torch.empty((B, Ho, Wo, C), dtype=torch.uint8, device=x.device) if need else None
+        _lib.check(lib.oess_maxpool3x3s2_fwd_nhwc_bf16(_ptr(xn), ps, B, H, W, C, _ptr(y), C, _ptr(idx), _stream()),
+                   "oess_maxpool3x3s2_fwd_nhwc_bf16")
+        ctx.idx, ctx.geom = idx, (B, H, W, C)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        B, H, W, C = ctx.geom
+        gn = g.permute(0, 2, 3, 1)
+        if gn.dtype != torch.bfloat16 or gn.stride(3) != 1 or not _uniform_pix_stride(gn):
+            gn = gn.to(torch.bfloat16).contiguous()
+        _, _, _, _, gps = _nhwc_geom(gn)
+        gx = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=g.device)
+        _lib.check(lib.oess_maxpool3x3s2_bwd_nhwc_bf16(_ptr(gn), gps, _ptr(ctx.idx), B, H, W, C, _ptr(gx), C, _stream()),
+                   "oess_maxpool3x3s2_bwd_nhwc_bf16")
+        return gx.permute(0, 3, 1, 2)
+
+
+def max_pool_3x3s2(x):
+    """MaxPool2d(kernel_size=3, stride=2, padding=1) on a logical NCHW channels_last bf16 tensor with C % 8 == 0."""
+    _need_gpu(x)
+    if x.dtype != torch.bfloat16 or x.stride(1) != 1 or x.shape[1] % 8:
+        raise ValueError("max_pool_3x3s2 needs a channels_last bf16 tensor with C % 8 == 0")
+    return _MaxPool3x3s2.apply(x)
+
+
+_DROPOUT_CALLS = 0
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, offset):
+        lib = _lib.load()
+        xn = x.permute(0, 2, 3, 1)
+        B, H, W, C, ps = _nhwc_geom(xn)
+        y = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=x.device)
+        _lib.check(lib.oess_dropout_nhwc_bf16(_ptr(xn), ps, _ptr(y), C, B * H * W, C, float(p), seed, offset, _stream()),
+                   "oess_dropout_nhwc_bf16")
+        ctx.meta = (float(p), seed, offset)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        p, seed, offset = ctx.meta
+        gn = g.permute(0, 2, 3, 1)
+        if gn.dtype != torch.bfloat16 or gn.stride(3) != 1 or not _uniform_pix_stride(gn):
+            gn = gn.to(torch.bfloat16).contiguous()
+        B, H, W, C, gps = _nhwc_geom(gn)
+        gx = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=g.device)
+        _lib.check(lib.oess_dropout_nhwc_bf16(_ptr(gn), gps, _ptr(gx), C, B * H * W, C, p, seed, offset, _stream()),
+                   "oess_dropout_nhwc_bf16")
+        return gx.permute(0, 3, 1, 2), None, None, None
+
+
+def dropout(x, p, training=True):
+    """nn.Dropout(p) on a channels_last bf16 map (models/deeplabv3.py:343): Philox mask keyed by (torch.initial_seed(), a
+    per-process call counter, element), recomputed in the backward pass instead of stored.  Reproducible under torch.manual_seed."""
+    global _DROPOUT_CALLS
+    if not training or p <= 0.0:
+        return x
+    _need_gpu(x)
+    if x.dtype != torch.bfloat16 or x.stride(1) != 1 or x.shape[1] % 8:
+        raise ValueError("dropout needs a channels_last bf16 tensor with C % 8 == 0")
+    _DROPOUT_CALLS += 1
+    return _Dropout.apply(x, float(p), int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, _DROPOUT_CALLS)
+
+
+class _ASPPPoolBranch(torch.autograd.Function):
+    """ASPPPooling (models/deeplabv3.py:305-316) as one node: AdaptiveAvgPool2d(1) -> 1x1 conv -> BatchNorm2d(train) over the B
+    pooled vectors -> ReLU -> the 1x1 map broadcast back over H x W (bilinear from 1x1 == broadcast).  Forward: the per-sample
+    channel sums of the bf16 map (statistics kernel) + one B-row GEMV/BatchNorm kernel; backward: per-sample sums of the incoming
+    gradient slice, BatchNorm + GEMV adjoints, and the map's gradient as a stride-0 expanded [B, C, 1, 1] quotient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, run_mean, run_var, momentum, eps):
+        lib = _lib.load()
+        xn = x.permute(0, 2, 3, 1)
+        B, H, W, C, ps = _nhwc_geom(xn)
+        Cout = weight.shape[0]
+        st = torch.empty((2, B, C), dtype=torch.float32, device=x.device)
+        ws, wsn = _norm_partials(B, H * W, C, x.device)
+        _lib.check(lib.oess_norm_stats_nhwc_bf16(_ptr(xn), ps, B, H * W, C, _ptr(st[0]), _ptr(st[1]), _ptr(ws), wsn, _stream()),
+                   "oess_norm_stats_nhwc_bf16")
+        sums = st[0]                                  # per-sample channel sums; pooled = sums / (H W) is applied inside the kernels
+        w2 = weight.detach().reshape(Cout, C)
+        if w2.dtype != torch.float32 or not w2.is_contiguous():
+            w2 = w2.float().contiguous()
+        buf = torch.empty((2 * B + 2, Cout), dtype=torch.float32, device=x.device)      # y_pre | z | mean, rstd
+        y_pre, z, stat = buf[:B], buf[B:2 * B], buf[2 * B:]
+        zb = torch.empty((B, Cout), dtype=torch.bfloat16, device=x.device)
+        _lib.check(lib.oess_aspp_pool_fwd_f32(_ptr(sums), 1.0 / (H * W), _ptr(w2), _ptr(gamma.detach()), _ptr(beta.detach()), _ptr(run_mean),
+                                              _ptr(run_var), float(momentum), float(eps), B, C, Cout, _ptr(y_pre), _ptr(stat), _ptr(z),
+                                              _ptr(zb), _stream()), "oess_aspp_pool_fwd_f32")
+        ctx.save_for_backward(sums, w2, gamma.detach(), buf)
+        ctx.geom = (B, H, W, C, Cout)
+        return zb.view(B, Cout, 1, 1).expand(B, Cout, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        sums, w2, gamma, buf = ctx.saved_tensors
+        B, H, W, C, Cout = ctx.geom
+        y_pre, z, stat = buf[:B], buf[B:2 * B], buf[2 * B:]
+        gn = g.permute(0, 2, 3, 1)
+        if gn.dtype != torch.bfloat16 or gn.stride(3) != 1 or not _uniform_pix_stride(gn):
+            gn = gn.to(torch.bfloat16).contiguous()
+        _, _, _, _, gps = _nhwc_geom(gn)
+        gs = torch.empty((2, B, Cout), dtype=torch.float32, device=g.device)
+        ws, wsn = _norm_partials(B, H * W, Cout, g.device)
+        _lib.check(lib.oess_norm_stats_nhwc_bf16(_ptr(gn), gps, B, H * W, Cout, _ptr(gs[0]), _ptr(gs[1]), _ptr(ws), wsn, _stream()),
+                   "oess_norm_stats_nhwc_bf16")
+        out = torch.empty((B * Cout + Cout * C + 2 * Cout,), dtype=torch.float32, device=g.device)
+        dy = out[:B * Cout]
+        gw = out[B * Cout:B * Cout + Cout * C].view(Cout, C, 1, 1)
+        gg = out[B * Cout + Cout * C:B * Cout + Cout * C + Cout]
+        gb = out[B * Cout + Cout * C + Cout:]
+        gp = torch.empty((B, C), dtype=torch.bfloat16, device=g.device) if ctx.needs_input_grad[0] else None
+        _lib.check(lib.oess_aspp_pool_bwd_f32(_ptr(gs[0]), _ptr(sums), 1.0 / (H * W), _ptr(w2), _ptr(gamma), _ptr(y_pre), _ptr(stat), _ptr(z),
+                                              B, C, Cout, _ptr(dy), _ptr(gw), _ptr(gg), _ptr(gb), _ptr(gp), _stream()), "oess_aspp_pool_bwd_f32")
+        gx = gp.view(B, C, 1, 1).expand(B, C, H, W) if gp is not None else None
+        return gx, gw, gg, gb, None, None, None, None
+
+
+def aspp_pool_branch(x, conv, bn):
+    """ASPPPooling.forward for a channels_last bf16 map in TRAIN mode (batch statistics over the B pooled vectors)."""
+    _need_gpu(x)
+    B = x.shape[0]
+    if x.dtype != torch.bfloat16 or x.stride(1) != 1 or x.shape[1] % 8 or x.shape[1] > 2048 or not 2 <= B <= 16:
+        raise ValueError("aspp_pool_branch needs a channels_last bf16 map with C % 8 == 0, C <= 2048 and 2 <= B <= 16")
+    from . import engine as _engine
+    y = _ASPPPoolBranch.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                              0.0 if bn.momentum is None else float(bn.momentum), float(bn.eps))
+    _engine.bump_bn_counter(bn)
+    return y

@@ -28,7 +28,18 @@ class HipConv2d(nn.Conv2d):
         return engine.conv2d_infer(x, pw, self.out_channels, k, s, p, d)
 
 
-def conv_bn(conv, bn, x, relu=False, residual=None, out=None):
+class HipMaxPool2d(nn.MaxPool2d):
+    """nn.MaxPool2d(3, stride=2, padding=1) of the stem on the HIP kernel (forward and backward; ATen's tie rule)."""
+
+    def forward(self, x):
+        if x.is_cuda and (self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode) == (3, 2, 1, 1, False):
+            if x.dtype != torch.bfloat16 or x.stride(1) != 1 or x.shape[1] % 8:
+                x = engine.to_cl_bf16(x)
+            return hip.max_pool_3x3s2(x)
+        return super().forward(x)
+
+
+def conv_bn(conv, bn, x, relu=False, residual=None, out=None, skip_in=None, skip_out=None):
     """conv -> BatchNorm2d [-> + residual] [-> ReLU] with nn.BatchNorm2d semantics for both bn.training states.
     No autograd needed (frozen teacher, validation): train-mode BN takes its batch statistics from the conv
     epilogue (no statistics pass); eval-mode BN is folded into the packed weights and the whole tail is the
@@ -41,7 +52,7 @@ def conv_bn(conv, bn, x, relu=False, residual=None, out=None):
             x = engine.to_cl_bf16(x)
         elif x.stride(1) != 1:
             x = x.contiguous(memory_format=torch.channels_last)
-        y = engine.conv_bn_train(x, conv, bn, conv._pw, relu=relu, residual=residual)
+        y = engine.conv_bn_train(x, conv, bn, conv._pw, relu=relu, residual=residual, skip_in=skip_in, skip_out=skip_out)
         if out is not None:
             out.copy_(y)
             return out
@@ -95,13 +106,27 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
+    def _one_node_path(self, x):
+        """True when conv1 / conv3 of this block both take conv_bn's one-autograd-node path and x needs a gradient: only then
+        can the skip connection's gradient ride in conv1's data-gradient epilogue (engine._ConvBNTrainFn skip_in / skip_out)."""
+        if not (torch.is_grad_enabled() and x.requires_grad and x.is_cuda and x.dtype == torch.bfloat16 and x.stride(1) == 1 and
+                x.shape[1] % 8 == 0):
+            return False
+        for conv, bn in ((self.conv1, self.bn1), (self.conv3, self.bn3)):
+            if conv.bias is not None or not bn.training or bn.weight is None or bn.running_mean is None or conv.out_channels % 8 or \
+                    conv.out_channels > 2048 or conv.stride[0] != 1:
+                return False
+        return True
+
     def forward(self, x):
         identity = x
-        out = conv_bn(self.conv1, self.bn1, x, relu=True)
+        # no downsample: x feeds conv1 AND the residual add -> one shared hand-over slot instead of autograd's gradient sum
+        skip = {} if (self.downsample is None and self._one_node_path(x)) else None
+        out = conv_bn(self.conv1, self.bn1, x, relu=True, skip_in=skip)
         out = conv_bn(self.conv2, self.bn2, out, relu=True)
         if self.downsample is not None:
             identity = conv_bn(self.downsample[0], self.downsample[1], x)
-        return conv_bn(self.conv3, self.bn3, out, relu=True, residual=identity)
+        return conv_bn(self.conv3, self.bn3, out, relu=True, residual=identity, skip_out=skip)
 
 
 class ResNet(nn.Module):
@@ -121,7 +146,7 @@ class ResNet(nn.Module):
         self.conv1 = HipConv2d(3, self.inplanes, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = norm_layer(self.inplanes)
         self.relu = nn.ReLU(inplace=True)
-        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.maxpool = HipMaxPool2d(kernel_size=3, stride=2, padding=1)
         self.layer1 = self._make_layer(block, 64, layers[0])
         self.layer2 = self._make_layer(block, 128, layers[1], stride=2, dilate=replace_stride_with_dilation[0])
         self.layer3 = self._make_layer(block, 256, layers[2], stride=2, dilate=replace_stride_with_dilation[1])

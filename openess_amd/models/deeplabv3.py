@@ -60,6 +60,15 @@ class ASPPPooling(nn.Sequential):
 
     def forward(self, x, out=None):
         size = x.shape[-2:]
+        bn = self[2]
+        if bn.training and x.is_cuda and x.dtype == torch.bfloat16 and x.stride(1) == 1 and x.shape[1] % 8 == 0 and \
+                x.shape[1] <= 2048 and 2 <= x.shape[0] <= 16 and bn.running_mean is not None:
+            # train mode: pooling, B-row GEMV, BatchNorm over the B pooled vectors and ReLU on the HIP kernels, one autograd node
+            y = hip.aspp_pool_branch(x, self[1], bn)
+            if out is not None:
+                out.copy_(y)
+                return out
+            return y
         if x.is_cuda and x.dtype == torch.bfloat16 and x.stride(1) == 1 and x.shape[1] % 8 == 0 and x.shape[1] <= 2048:
             y = hip.global_avg_pool(x)                                     # AdaptiveAvgPool2d(1) without an fp32 copy of the map
         else:
@@ -98,7 +107,10 @@ class ASPP(nn.Module):
             for i, conv in enumerate(self.convs):
                 conv(x, out=res[:, i * oc:(i + 1) * oc])
         y = conv_bn(self.project[0], self.project[1], res, relu=True)
-        return self.project[3](y)
+        drop = self.project[3]
+        if drop.training and drop.p > 0 and y.is_cuda and y.dtype == torch.bfloat16 and y.stride(1) == 1 and y.shape[1] % 8 == 0:
+            return hip.dropout(y, drop.p, True)            # Philox mask recomputed in the backward pass (nn.Dropout(0.1), :343)
+        return drop(y)
 
 
 class DeepLabHead(nn.Module):

@@ -93,6 +93,11 @@ def test_round4_entry_points_validate_arguments_on_the_host():
     assert lib.oess_linear_probe_partials_bytes(11) == 1024 * (121 + 11) * 8 and lib.oess_linear_probe_partials_bytes(33) == 0
     assert lib.oess_linear_probe_fwd_f32(None, None, None, 100, 11, None, None) == -22
     assert lib.oess_linear_probe_bwd_f32(None, None, None, 100, 11, None, None, None, None, 0, None) == -22
+    assert lib.oess_maxpool3x3s2_fwd_nhwc_bf16(None, 64, 1, 8, 8, 64, None, 64, None, None) == -22
+    assert lib.oess_maxpool3x3s2_bwd_nhwc_bf16(None, 64, None, 1, 8, 8, 64, None, 64, None) == -22
+    assert lib.oess_dropout_nhwc_bf16(None, 8, None, 8, 10, 8, 0.1, 1, 2, None) == -22
+    assert lib.oess_aspp_pool_fwd_f32(None, 1.0, None, None, None, None, None, 0.1, 1e-5, 8, 2048, 256, None, None, None, None, None) == -22
+    assert lib.oess_aspp_pool_bwd_f32(None, None, 1.0, None, None, None, None, None, 8, 2048, 256, None, None, None, None, None, None) == -22
 
 
 def test_collate_keeps_undecoded_png_maps_as_one_byte_stream():
