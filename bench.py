@@ -456,6 +456,8 @@ def main():
                     "sub-window) instead of the default skewed schedule with grouped launches; same results (A/B)")
     ap.add_argument("--no-s2-group", action="store_true", help="skewed schedule with one launch per stride-2 encoder conv (A/B of the "
                     "grouped launch of levels 1 and 2)")
+    ap.add_argument("--no-overlap-teacher", action="store_true", help="frozen teacher forward on the step's own stream instead of a side "
+                    "stream under the recurrent encoder (A/B; same results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC child passes (roofline.traffic = null)")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only: no stages / configs / ingest blocks")
@@ -464,6 +466,9 @@ def main():
     if a.no_s2_group:
         from openess_amd.e2vid.model.unet import UNetRecurrent
         UNetRecurrent.group_s2 = False
+    if a.no_overlap_teacher:
+        from openess_amd.training.pretrain_step import PretrainStep
+        PretrainStep.overlap_teacher = False
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -45,7 +45,9 @@ _WS_CACHE = {}
 
 
 def _workspace(nbytes, device, tag="ws"):
-    key = (tag, device.index)
+    # stream-ordered reuse of one buffer is only safe on ONE stream: the current stream is always part of the key (the teacher
+    # forward / backward runs on its own stream next to the student's, training/pretrain_step.py)
+    key = (tag, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS_CACHE.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

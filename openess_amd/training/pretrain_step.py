@@ -24,6 +24,12 @@ class PretrainStep:
     # contrastive: the teacher's upsampled + normalised features are only pooled too -> hip.UpsampledNormalizedFeature (one-pass
     # backward); False = the full-resolution tensor goes through autograd as three separate adjoints
     pooled_teacher_features = True
+    # The frozen teacher's forward (image_model.py:130-143: a third of the step, BatchNorm-apply passes and short-K 1x1 layers
+    # bound by HBM) shares no data with the recurrent E2VID encoder (matrix- / LDS-bound) until the losses meet: it runs on its
+    # own HIP stream under the encoder and joins where its features are first read (the pooling of the contrastive loss) or, when
+    # nothing reads them (pixel distillation: only its BatchNorm side effects exist), at the end of the forward.  Same kernels on
+    # the same buffers, ordered by events: results are bit-identical.  False = one stream (A/B, per-launch timing without overlap).
+    overlap_teacher = True
 
     def __init__(self, config_option='frame2voxel', num_classes=11, img_size=(440, 640), nr_events_data=20,
                  nr_temporal_bins=5, if_spatial_contrastive=False, if_dense_clip_supervision=True, superpixel_size=100,
@@ -108,6 +114,38 @@ class PretrainStep:
         with torch.no_grad():
             return self.model_frame(frame)
 
+    def _teacher_begin(self, frame):
+        """Teacher forward, on the side stream when `overlap_teacher` (see the class attribute); `_teacher_join()` before its
+        result is read on the current stream."""
+        self._teacher_side = None
+        if not (self.overlap_teacher and self.device.type == 'cuda' and frame.is_cuda):
+            return self._teacher(frame)
+        from .. import engine
+        # every stale packed operand of the step (the trainable weights after the optimiser step) is refreshed HERE, on the current
+        # stream: the group repack must not be triggered from the side stream while this stream's convolutions read the operands
+        engine.PackedWeight.refresh_stale(self.device)
+        if getattr(self, '_teacher_stream', None) is None:
+            self._teacher_stream = torch.cuda.Stream(device=self.device)
+        side, main = self._teacher_stream, torch.cuda.current_stream(self.device)
+        side.wait_stream(main)                       # the frame, the weights, the previous step
+        with torch.cuda.stream(side):
+            feat = self._teacher(frame)
+        self._teacher_side = side
+        self._teacher_out = feat
+        return feat
+
+    def _teacher_join(self):
+        side = getattr(self, '_teacher_side', None)
+        if side is None:
+            return
+        main = torch.cuda.current_stream(self.device)
+        main.wait_stream(side)
+        feat = self._teacher_out
+        for t in (feat, getattr(feat, 'x', None)):      # tensors allocated on the side stream and read on this one from here on
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(main)
+        self._teacher_side = self._teacher_out = None
+
     def _pool(self, feat, superpixels, S):
         return hip.superpixel_pool(feat, superpixels, self.superpixel_size, S=S)
 
@@ -127,7 +165,7 @@ class PretrainStep:
             wf = getattr(self, 'wavefront', None)
             if wf is not None:
                 wf.begin()              # the level streams start here: the recurrent encoder also overlaps the teacher forward below
-            feat_frame = self._teacher(frame)
+            feat_frame = self._teacher_begin(frame)
             self.reconstructor.last_states_for_each_channel = {'grayscale': None}
             for i in range(self.nr_events_data):
                 _, _, latent_real = self.reconstructor.update_reconstruction(
@@ -141,18 +179,21 @@ class PretrainStep:
             losses['dense_clip_loss'] = loss_dense.detach()
             if self.if_spatial_contrastive:
                 k = self._pool(feat_voxel, batch[4], S)
+                self._teacher_join()
                 q = self._pool(feat_frame, batch[4], S)
                 loss_nce = self.nce_loss(k, q)
                 losses['contrastive_nce_loss'] = loss_nce.detach()
                 t_loss = t_loss + loss_nce
             if self.if_dense_clip_supervision:
                 t_loss = t_loss + loss_dense
+            self._teacher_join()
         else:                                                                   # frame2recon (:475-529)
             frame, recon, pl = batch[0], batch[2], batch[3]
-            feat_frame = self._teacher(frame)
+            feat_frame = self._teacher_begin(frame)
             logits_recon, feat_recon = self.model_recon(recon)
             if self.if_spatial_contrastive:
                 k = self._pool(feat_recon, batch[4], S)
+                self._teacher_join()
                 q = self._pool(feat_frame, batch[4], S)
                 loss_nce = self.nce_loss(k, q)
                 losses['contrastive_nce_loss'] = loss_nce.detach()
@@ -161,6 +202,7 @@ class PretrainStep:
                 loss_dense = self.task_loss(logits_recon, pl) * self.weight_task_loss
                 losses['dense_clip_loss'] = loss_dense.detach()
                 t_loss = t_loss + loss_dense
+            self._teacher_join()
         return t_loss, losses, {}
 
     # ------------------------------------------------------------------ pretrain_trainer.py:324-361

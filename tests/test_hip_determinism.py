@@ -101,9 +101,12 @@ def test_pretrain_step_bit_repeatable(option, contr):
     first = ev if option == "frame2voxel" else frame
     S = int((sp.cpu() + torch.arange(B)[:, None, None] * 25).max()) + 1
     runs = []
-    for rep in range(2):
+    for rep in range(3):
         st = PretrainStep(config_option=option, img_size=(H, W), nr_events_data=nwin, if_spatial_contrastive=contr,
                           superpixel_size=25, lr=1e-4)
+        # runs 0 and 2: the teacher forward on its own HIP stream under the student's encoder (the default); run 1: one stream.
+        # Same kernels on the same buffers, ordered by events -> the three runs must agree bit for bit.
+        st.overlap_teacher = rep != 1
         for name, m in st.models_dict.items():
             fill_by_name(m, 100 + len(name))
             damp_residual(m)
@@ -114,15 +117,18 @@ def test_pretrain_step_bit_repeatable(option, contr):
             losses, _, tl = st.train_step((first, None, frame, pl, sp, S))
             rec.append({k: float(v) for k, v in losses.items()})
         w = {f"{k}.{n}": p.detach().clone() for k, m in st.models_dict.items() for n, p in m.named_parameters() if p.requires_grad}
+        w.update({f"model_frame.buf.{n}": b.detach().clone() for n, b in st.model_frame.named_buffers()})     # BatchNorm running stats
         gr = {f"{k}.{n}": (None if p.grad is None else p.grad.detach().clone()) for k, m in st.models_dict.items()
               for n, p in m.named_parameters() if p.requires_grad}
         runs.append((rec, w, gr))
         torch.randn(1 << (20 + rep), device="cuda").sum()
-    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
-    for n in runs[0][1]:
-        assert torch.equal(runs[0][1][n], runs[1][1][n]), n
-        a, b = runs[0][2][n], runs[1][2][n]
-        assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), n
+    for other in (1, 2):
+        assert runs[0][0] == runs[other][0], (runs[0][0], runs[other][0])
+        for n in runs[0][1]:
+            assert torch.equal(runs[0][1][n], runs[other][1][n]), (other, n)
+        for n in runs[0][2]:
+            a, b = runs[0][2][n], runs[other][2][n]
+            assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), (other, n)
 
 
 def test_batchnorm_backward_merged_launch_equals_three_launch_path(tmp_path):

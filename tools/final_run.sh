@@ -35,11 +35,6 @@ timeout 600 bash tools/pmc_traffic.sh "python tools/bench_voxelizer.py --raw 1 -
 timeout 300 python tools/bench_png.py > $O/png.txt 2>&1
 timeout 300 python tools/bench_stage.py deeplab_fwd --breakdown > $O/deeplab_breakdown.txt 2>&1
 timeout 300 python tools/bench_segmean.py > $O/segmean.txt 2>&1 || true
-timeout 300 python tools/bench_enc_s2.py > $O/enc_s2.txt 2>&1 || true
-timeout 300 python tools/probe_1x1_epi.py > $O/probe_1x1.txt 2>&1 || true
-timeout 300 python tools/quant_probe.py > $O/quant_probe.txt 2>&1 || true
-timeout 300 python tools/gap_probe.py > $O/gap_probe.txt 2>&1 || true
-timeout 300 python tools/insitu_probe.py > $O/insitu_probe.txt 2>&1 || true
 bash tools/step_sequence.sh > $O/step_sequence.txt 2>&1 || true
 cp gpurun_out/seq_last_step.txt $O/seq_last_step.txt 2>/dev/null || true
 find $O -name "*_kernel_trace.csv" -delete
