@@ -62,15 +62,19 @@ class SyntheticEvents(Dataset):
         return first, label, frame, pl, superpixel, sam_feat, f"synthetic/{self.mode}/{index:06d}"
 
 
-def collate(samples):
+def collate(samples, arena=None):
     """Batch the reference-shaped tuples (6 items for DDD17, 7 for DSEC; the last one is the file path) into ONE layout,
     the 7-slot DSEC one with sam_feat = None for DDD17.  Raw-event dicts
-    in slot 0 are concatenated into SoA columns with per-sub-window segment offsets (pinned by DataLoader(pin_memory=True))."""
+    in slot 0 are concatenated into SoA columns with per-sub-window segment offsets (pinned by DataLoader(pin_memory=True)).
+    arena: datasets.ring_loader.Arena -- the large tensors are then written straight into a slot of the pinned loader ring
+    (`cat` / `stack` with `out=` views of the slot) instead of into fresh allocations."""
+    cat = torch.cat if arena is None else arena.cat
+    stk = torch.stack if arena is None else arena.stack
     first = [s[0] for s in samples]
     if isinstance(first[0], dict) and 'events' in first[0]:                       # DDD17: int64 [N,4] rows per sample
-        batch0 = {'events_list': [f['events'] for f in first], 'flip': [bool(f.get('flip', False)) for f in first]}
+        batch0 = {'events_list': [f['events'] if arena is None else arena.put(f['events']) for f in first], 'flip': [bool(f.get('flip', False)) for f in first]}
     elif isinstance(first[0], dict):                                              # DSEC / synthetic: x, y, t, p columns
-        ev = {k: torch.cat([f[k] for f in first]) for k in ('x', 'y', 't', 'p')}
+        ev = {k: cat([f[k] for f in first]) for k in ('x', 'y', 't', 'p')}
         ev['events_per_sample'] = torch.tensor([f['x'].numel() for f in first])
         if 'seg_offsets' in first[0]:
             offs, base = [torch.zeros(1, dtype=torch.int64)], 0
@@ -83,16 +87,16 @@ def collate(samples):
                 ev['sequence'] = [int(f['sequence']) for f in first]
         batch0 = ev
     else:
-        batch0 = torch.stack(first)
+        batch0 = stk(first)
     n = len(samples[0])
     if n not in (6, 7):
         raise ValueError(f"dataset tuples have 6 (DDD17) or 7 (DSEC) items, got {n}")
     def stack(i):
         col = [s[i] for s in samples]
         if isinstance(col[0], dict) and 'png' in col[0]:      # undecoded 8-bit maps (device_png): the files back to back
-            return {'png_bytes': torch.cat([c['png'] for c in col]), 'png_lengths': [int(c['png'].numel()) for c in col],
+            return {'png_bytes': cat([c['png'] for c in col]), 'png_lengths': [int(c['png'].numel()) for c in col],
                     'flip': [bool(c['flip']) for c in col], 'hw': tuple(col[0]['hw'])}
-        return torch.stack(col)
+        return stk(col)
     rest = [stack(i) for i in range(1, n - 1)]
     if n == 6:                     # DDD17 has no sam_feat (ddd17_events_loader.py:290): the batch ALWAYS carries the 7-slot layout
         rest = rest[:4] + [None]   # (first, label, frame | recon, pl, superpixel, sam_feat | None, file_paths); nothing downstream guesses

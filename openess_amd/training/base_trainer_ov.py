@@ -100,9 +100,15 @@ class BaseTrainer(object):
         execute under step i.  The current stream waits on one event per batch; tensors produced on the side stream are
         handed to the consumer stream with record_stream, so the caching allocator cannot recycle them early.
         `settings.ingest_prefetch: False` (or a CPU-only debug run) falls back to the in-order path."""
+        release = getattr(loader, 'consumed_after', None)       # PinnedRingLoader: the slot returns to the workers after our copies
         if not getattr(self.settings, 'ingest_prefetch', True):
             for sample_batched in loader:
-                yield self.prepare_batch(sample_batched, split)
+                batch = self.prepare_batch(sample_batched, split)
+                if release is not None:
+                    done = torch.cuda.Event()
+                    done.record(torch.cuda.current_stream(self.device))
+                    release(done)
+                yield batch
             return
         if getattr(self, '_ingest_stream', None) is None:
             self._ingest_stream = torch.cuda.Stream(device=self.device)
@@ -119,6 +125,8 @@ class BaseTrainer(object):
                 batch = self.prepare_batch(sample_batched, split)
                 ready = torch.cuda.Event()
                 ready.record(side)
+                if release is not None:
+                    release(ready)
             return batch, ready
 
         try:
@@ -207,8 +215,15 @@ class BaseTrainer(object):
         self._voxel_ds = {'train': train_ds, 'val': val_ds}            # un-wrapped datasets: Subset has no voxelize_batch
         if self.world > 1:
             train_ds = Subset(train_ds, shard_indices(len(train_ds), self.rank, self.world).tolist())
-        self.train_loader_sensor_b = DataLoader(train_ds, batch_size=s.batch_size_b, num_workers=s.num_cpu_workers,
-                                                pin_memory=True, shuffle=True, drop_last=True, collate_fn=collate)
+        # settings.ring_loader (default on with worker processes): the workers collate straight into a pinned shared ring
+        # (datasets/ring_loader.py: one host copy per byte instead of the DataLoader's three); False = torch's DataLoader
+        if getattr(s, 'ring_loader', True) and s.num_cpu_workers > 0 and len(train_ds) >= s.batch_size_b:
+            from ..datasets.ring_loader import PinnedRingLoader
+            self.train_loader_sensor_b = PinnedRingLoader(train_ds, batch_size=s.batch_size_b, shuffle=True, drop_last=True,
+                                                          num_workers=s.num_cpu_workers)
+        else:
+            self.train_loader_sensor_b = DataLoader(train_ds, batch_size=s.batch_size_b, num_workers=s.num_cpu_workers,
+                                                    pin_memory=True, shuffle=True, drop_last=True, collate_fn=collate)
         self.val_loader_sensor_b = DataLoader(val_ds, batch_size=s.batch_size_b, num_workers=s.num_cpu_workers,
                                               pin_memory=True, shuffle=False, drop_last=False, collate_fn=collate)
 

@@ -9,6 +9,7 @@ Only the `frame2recon` option with `if_spatial_contrastive: True` is runnable in
 The MaskCLIP tower the reference constructs (:107-114) is never called by any of its steps; it is built here (frozen,
 `models_dict['model_clip']`) when the three files it needs exist, and is available as an online teacher
 (`self.model_clip(frame) -> logits`), see openess_amd/models/maskclip_model.py."""
+import contextlib
 import os
 
 import torch
@@ -26,6 +27,7 @@ class OpenESSModel(BaseTrainer):
     # the 256-channel full-resolution features of both students are only consumed by the L1 consistency loss and the superpixel
     # pooling: both work on the OS16 maps (hip.UpsampledFeature: one upsampled difference, one pooling matrix); False = tensors
     lazy_features = True
+    two_streams = True               # the two students' forward (and, through autograd, backward) passes on two HIP streams; False = one
 
     def init_fn(self):
         """openess_trainer.py:84-86: models, then optimisers, then the loss objects."""
@@ -72,14 +74,32 @@ class OpenESSModel(BaseTrainer):
         for m in self.models_dict.values():
             m.train()
         frame, recon, pl, superpixels = batch[0], batch[2], batch[3], batch[4]
-        logits_frame, feat_frame = self.model_frame(frame)
-        l = self.task_loss(logits_frame, pl) * s.weight_task_loss
-        losses['semseg_frame_loss'] = l.detach()
-        t_loss = t_loss + l
+        side = None
+        if self.two_streams and frame.is_cuda:
+            # The two students share no data until the consistency losses.  Their small-map layers (OS16: 140-560 workgroups per
+            # launch on 256 CUs) leave most of the chip idle, so the frame student runs on a second HIP stream next to the
+            # reconstruction student; autograd replays each node on the stream of its forward, so the two backward passes
+            # interleave the same way.  Same kernels, same buffers, ordered by events: results are bit-identical.
+            from .. import engine
+            engine.PackedWeight.refresh_stale(self.device)        # on THIS stream, before the fork: no repack from the side stream
+            if getattr(self, '_side_stream', None) is None:
+                self._side_stream = torch.cuda.Stream(device=self.device)
+            side, main = self._side_stream, torch.cuda.current_stream(self.device)
+            side.wait_stream(main)
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            logits_frame, feat_frame = self.model_frame(frame)
+            l_frame = self.task_loss(logits_frame, pl) * s.weight_task_loss
         logits_recon, feat_recon = self.model_recon(recon)
-        l = self.task_loss(logits_recon, pl) * s.weight_task_loss
-        losses['semseg_recon_loss'] = l.detach()
-        t_loss = t_loss + l
+        l_recon = self.task_loss(logits_recon, pl) * s.weight_task_loss
+        if side is not None:
+            main.wait_stream(side)
+            for t in (logits_frame, getattr(feat_frame, 'x', feat_frame), l_frame):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(main)
+        losses['semseg_frame_loss'] = l_frame.detach()
+        t_loss = t_loss + l_frame
+        losses['semseg_recon_loss'] = l_recon.detach()
+        t_loss = t_loss + l_recon
         l = hip.l1_mean(feat_frame, feat_recon)                              # nn.L1Loss (:497)
         losses['cons_feat_loss'] = l.detach()
         t_loss = t_loss + l

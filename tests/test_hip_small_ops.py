@@ -80,7 +80,7 @@ def test_aspp_pool_branch_matches_pytorch(B, Cin, Cout, hw):
     ya = m(xa)
     yb = ref(xb).expand(-1, -1, *hw)
     assert ya.shape == yb.shape and ya.dtype == torch.bfloat16
-    np.testing.assert_allclose(ya.float().cpu().numpy(), yb.detach().cpu().numpy(), rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(ya.detach().float().cpu().numpy(), yb.detach().cpu().numpy(), rtol=1e-2, atol=1e-2)
     np.testing.assert_allclose(m[2].running_mean.cpu().numpy(), ref[2].running_mean.cpu().numpy(), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(m[2].running_var.cpu().numpy(), ref[2].running_var.cpu().numpy(), rtol=1e-4, atol=1e-5)
     assert int(m[2].num_batches_tracked) == 1

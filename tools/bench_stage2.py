@@ -77,7 +77,11 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--only", nargs="*")
+    ap.add_argument("--one-stream", action="store_true", help="OpenESSModel: both students on one stream (A/B of the two-stream default)")
     a = ap.parse_args()
+    if a.one_stream:
+        from openess_amd.training.openess_trainer import OpenESSModel
+        OpenESSModel.two_streams = False
     r = measure(a.steps, only=a.only)
     for k, v in r.items():
         print(f"{k:34s} {v['value']:8.2f} event-frames/s  {v['ms_per_step']:8.3f} ms/step  ({v['trainer']}, loss {v['loss']})", file=sys.stderr)

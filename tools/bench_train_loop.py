@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def build(batches, workers, prefetch, B=8, contrastive=False, tmp=None):
+def build(batches, workers, prefetch, B=8, contrastive=False, tmp=None, ring=True):
     import train
     from openess_amd.config.settings import Settings
     cfg = yaml.safe_load(open(os.path.join(ROOT, "tests", "configs", "pretrain_dsec_synthetic.yaml")))
@@ -40,14 +40,15 @@ def build(batches, workers, prefetch, B=8, contrastive=False, tmp=None):
     s.synthetic_length = batches * B
     s.synthetic_pool = 16
     s.ingest_prefetch = prefetch
+    s.ring_loader = bool(ring)
     trainer, loop = train.build_trainer(s)
     assert loop == 'pretraining'
     return trainer, s
 
 
-def measure(batches=24, workers=10, prefetch=True, warm=4):
+def measure(batches=24, workers=4, prefetch=True, warm=4, ring=True):
     with tempfile.TemporaryDirectory(prefix="oess_loop_", dir="/tmp") as tmp:
-        trainer, s = build(batches + warm, workers, prefetch, tmp=tmp)
+        trainer, s = build(batches + warm, workers, prefetch, tmp=tmp, ring=ring)
         for m in trainer.models_dict.values():
             m.train()
         B = s.batch_size_b
@@ -61,8 +62,13 @@ def measure(batches=24, workers=10, prefetch=True, warm=4):
                 n += 1
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        loader = trainer.train_loader_sensor_b
+        kind = "PinnedRingLoader (workers collate into a pinned shared ring: one host copy)" if hasattr(loader, "consumed_after") else \
+            "torch DataLoader (collate + shared-memory hand-over + pin thread: three host copies)"
+        if hasattr(loader, "close"):
+            loader.close()
         return {"value": round(n * B / dt, 2), "unit": "event-frames/s", "ms_per_step": round(dt / n * 1e3, 3), "steps": n,
-                "loader_workers": workers, "prefetch": bool(prefetch),
+                "loader_workers": workers, "prefetch": bool(prefetch), "loader": kind,
                 "note": "train.py's own loop: DataLoader workers -> collate (13 B/event raw columns, 208 MB/batch) -> pin thread -> "
                         "side-stream H2D + voxelizer (BaseTrainer.device_batches) -> OpenESSPretrainModel.train_step; 16-sample pool"}
 
@@ -70,8 +76,9 @@ def measure(batches=24, workers=10, prefetch=True, warm=4):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--batches", type=int, default=24)
-    ap.add_argument("--workers", type=int, default=10)
+    ap.add_argument("--workers", type=int, default=4)
+    ap.add_argument("--dataloader", action="store_true", help="torch's DataLoader instead of the pinned ring loader (A/B)")
     ap.add_argument("--no-prefetch", action="store_true")
     a = ap.parse_args()
-    r = measure(a.batches, a.workers, not a.no_prefetch)
+    r = measure(a.batches, a.workers, not a.no_prefetch, ring=not a.dataloader)
     print(json.dumps(r))

@@ -31,7 +31,7 @@ done
 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_mfma -o p -- python bench.py --child --steps 1 --warmup 1 > $O/pmc_mfma.txt 2>&1
 python tools/mfma_util.py $O/pmc_mfma $O/mfma_util.json > $O/mfma_util.txt 2>&1 || true
 timeout 600 bash tools/pmc_traffic.sh "python tools/bench_voxelizer.py --raw 1 --iters 5" "tri_sort|tri_splat" > $O/voxelizer_pmc.txt 2>&1
-{ timeout 300 python tools/bench_train_loop.py; timeout 300 python tools/bench_train_loop.py --no-prefetch; timeout 300 python tools/bench_train_loop.py --workers 6; } > $O/train_loop.txt 2>&1
+{ timeout 300 python tools/bench_train_loop.py --workers 4; timeout 300 python tools/bench_train_loop.py --workers 2; timeout 300 python tools/bench_train_loop.py --workers 4 --no-prefetch; timeout 300 python tools/bench_train_loop.py --workers 4 --dataloader; timeout 300 python tools/bench_train_loop.py --workers 10 --dataloader; } > $O/train_loop.txt 2>&1
 timeout 300 python tools/bench_png.py > $O/png.txt 2>&1
 timeout 300 python tools/bench_stage.py deeplab_fwd --breakdown > $O/deeplab_breakdown.txt 2>&1
 timeout 300 python tools/bench_segmean.py > $O/segmean.txt 2>&1 || true
