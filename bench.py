@@ -225,7 +225,7 @@ def pmc_traffic(timeout_s=420):
 
 # ------------------------------------------------------------------------------------------------ the step
 class Workload:
-    def __init__(self, name, rank, world, device, inputs, wavefront=False, force_buckets=False, skew=True):
+    def __init__(self, name, rank, world, device, inputs, wavefront=False, force_buckets=False, skew=True, pipeline=True):
         from openess_amd.training.ddp import GradAllReduce, broadcast_module_states
         from openess_amd.training.pretrain_step import PretrainStep
         self.name, self.device, self.world = name, device, world
@@ -247,28 +247,59 @@ class Workload:
         # force_buckets: launched by torch.distributed.run with ONE rank -> the whole bucket / hook / RCCL all-reduce path still runs
         self.reducer = GradAllReduce([p for m in self.step.models_dict.values() for p in m.parameters()], world, force_buckets=force_buckets)
         self.voxels = [torch.empty((B, NWIN * C, H_NET, W_SENSOR), dtype=torch.float32, device=device)]
+        self.pipeline = pipeline
 
     def voxelize(self, ev, out):
         from openess_amd import hip
         hip.voxelize_dsec_raw(ev["x"], ev["y"], ev["t"], ev["p"], self.ev["maps"], self.ev["seg_map"], self.ev["seg"], C, H_SENSOR,
                               W_SENSOR, crop_rows=CROP, out=out.view(B * NWIN * C, H_NET, W_SENSOR))
 
-    def train(self, voxels):
+    def batch_of(self, voxels):
         first = self.frame if self.option == "frame2recon" else voxels
-        labels = self.pl                          # replaced inside the step by the online teacher's argmax when one is set
+        return (first, None, self.frame, self.pl, self.sp, self.S)   # labels: replaced inside the step by the online teacher's argmax when set
+
+    def front_of(self, i):
+        """Voxelizer + the frozen half of step i (teacher encoder, recurrent E2VID encoder): enqueued, not waited for."""
+        if len(self.voxels) < 2:
+            self.voxels.append(torch.empty_like(self.voxels[0]))
+        vox = self.voxels[i & 1]             # step i + 1 is voxelized while step i's front may still read its tensor
+        self.voxelize(self.ev, vox)
+        batch = self.batch_of(vox)
+        return batch, self.step.front(batch)
+
+    def back(self, batch, front):
+        """The trainable half: student forward, losses, backward, gradient all-reduce, 2 x AdamW."""
         for opt in self.step.optimizers_dict.values():
             opt.zero_grad()
         self.reducer.prepare()
-        t_loss, losses, _ = self.step.task_train_step((first, None, self.frame, labels, self.sp, self.S))
+        t_loss, losses, _ = self.step.task_train_step(batch, front=front)
         t_loss.backward()
         self.reducer()
         for opt in self.step.optimizers_dict.values():
             opt.step()
         return t_loss
 
+    def train(self, voxels):
+        return self.back(self.batch_of(voxels), None)
+
     def one_step(self):
         self.voxelize(self.ev, self.voxels[0])
         return self.train(self.voxels[0])
+
+    def run(self, n):
+        """n complete steps.  pipeline (default): the frozen half of step i + 1 is enqueued before the trainable half of step i
+        (PretrainStep.pipeline_steps does the same for a trainer's loop); otherwise one step after the other."""
+        loss = None
+        if not self.pipeline:
+            for _ in range(n):
+                loss = self.one_step()
+            return loss
+        prev = self.front_of(0)
+        for i in range(n):
+            nxt = self.front_of(i + 1) if i + 1 < n else None
+            loss = self.back(*prev)
+            prev = nxt
+        return loss
 
     def fence(self):
         if self.world > 1:
@@ -277,14 +308,13 @@ class Workload:
 
     def timed(self, steps, warmup, conv_timing=False):
         from openess_amd import hip
-        for _ in range(warmup):
-            self.one_step()
+        if warmup:
+            self.run(warmup)
         if conv_timing:
             hip.conv_timing_begin()
         self.fence()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = self.one_step()
+        loss = self.run(steps)
         self.fence()
         dt = time.perf_counter() - t0
         stats = hip.conv_timing_end() if conv_timing else None
@@ -456,8 +486,10 @@ def main():
                     "sub-window) instead of the default skewed schedule with grouped launches; same results (A/B)")
     ap.add_argument("--no-s2-group", action="store_true", help="skewed schedule with one launch per stride-2 encoder conv (A/B of the "
                     "grouped launch of levels 1 and 2)")
-    ap.add_argument("--no-overlap-teacher", action="store_true", help="frozen teacher forward on the step's own stream instead of a side "
-                    "stream under the recurrent encoder (A/B; same results)")
+    ap.add_argument("--no-overlap-teacher", action="store_true", help="everything on ONE stream, one step after the other: no teacher / "
+                    "encoder side streams, no cross-step pipelining (A/B; same results)")
+    ap.add_argument("--no-pipeline", action="store_true", help="frozen half of step i+1 NOT enqueued ahead of the trainable half of step i "
+                    "(the teacher / encoder side streams inside a step stay; A/B; same results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC child passes (roofline.traffic = null)")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only: no stages / configs / ingest blocks")
@@ -485,7 +517,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     inputs = make_inputs(rank, device)
-    wl = Workload(a.workload, rank, world, device, inputs, wavefront=a.wavefront, force_buckets=launched and world == 1, skew=not a.no_skew)
+    wl = Workload(a.workload, rank, world, device, inputs, wavefront=a.wavefront, force_buckets=launched and world == 1, skew=not a.no_skew,
+                  pipeline=not (a.no_pipeline or a.no_overlap_teacher))
     if a.child:
         wl.timed(a.steps, a.warmup)
         return
@@ -501,9 +534,10 @@ def main():
     serial = None
     if getattr(wl.step, "overlap_teacher", False):
         n_ser = max(10, a.steps // 5)
-        wl.step.overlap_teacher = False
+        keep = wl.pipeline
+        wl.step.overlap_teacher, wl.pipeline = False, False
         dt_ser, _, serial = wl.timed(n_ser, 2, conv_timing=True)
-        wl.step.overlap_teacher = True
+        wl.step.overlap_teacher, wl.pipeline = True, keep
         if serial:
             serial["steps"], serial["dt"] = n_ser, dt_ser
 
@@ -536,14 +570,25 @@ def main():
             if dk:
                 roof["dominant_kernel"] = dk
             if serial and serial["ms"] > 0:
-                roof["concurrency"] = ("timed region: the frozen teacher's forward runs on a second HIP stream under the recurrent encoder "
-                                       "(PretrainStep.overlap_teacher), so these per-launch durations include CU time-sharing; "
-                                       "serial_reference = the same step on one stream, measured right after")
+                # The roofline of a KERNEL is read where the kernel has the chip to itself: the serial region.  The timed region's
+                # own per-launch figures (kernels of two or three streams sharing the CUs) are kept beside it.
+                timed = {k: roof[k] for k in ("achieved", "frac", "launches_per_step", "avg_launch_us", "share_of_step_time", "dominant_kernel")
+                         if k in roof}
                 ach_s = serial["flops"] / (serial["ms"] * 1e-3) / 1e12
-                roof["serial_reference"] = {"value": round(world * B * serial["steps"] / serial["dt"], 2), "unit": "event-frames/s",
-                                            "steps": serial["steps"], "achieved": round(ach_s, 1), "frac": round(ach_s / PEAK_BF16_TFLOPS, 4),
-                                            "avg_launch_us": round(serial["ms"] * 1e3 / max(serial["launches"], 1), 2),
-                                            "dominant_kernel": dominant(serial, serial["steps"], serial["dt"])}
+                roof.update({"achieved": round(ach_s, 1), "frac": round(ach_s / PEAK_BF16_TFLOPS, 4),
+                             "launches_per_step": serial["launches"] // serial["steps"],
+                             "avg_launch_us": round(serial["ms"] * 1e3 / max(serial["launches"], 1), 2),
+                             "algorithmic_gflop_per_launch": round(serial["flops"] / max(serial["launches"], 1) / 1e9, 2),
+                             "share_of_step_time": round(serial["ms"] / (serial["dt"] * 1e3), 3),
+                             "dominant_kernel": dominant(serial, serial["steps"], serial["dt"])})
+                roof["region"] = (f"serial region: {serial['steps']} steps of the same workload on ONE stream, one step after the other "
+                                  f"(--no-overlap-teacher order; {round(world * B * serial['steps'] / serial['dt'], 2)} event-frames/s), run in "
+                                  "this process right after the timed region -- a launch's duration there is the kernel's own.  In the "
+                                  "timed region the frozen half of a step (teacher encoder, recurrent E2VID encoder) runs on its own HIP "
+                                  "streams and, for step i+1, ahead of the trainable half of step i (PretrainStep.front / pipeline_steps): "
+                                  "its per-launch durations include CU time-sharing and are kept in `timed_region`")
+                roof["serial_event_frames_per_s"] = round(world * B * serial["steps"] / serial["dt"], 2)
+                roof["timed_region"] = timed
         out = {"metric": "event-frames/sec fwd+bwd @640x480 B=8", "value": round(value, 2), "unit": "event-frames/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",

@@ -41,11 +41,19 @@ class DilationFeatureExtractor(nn.Module):
         self.lazy_features = False
 
     def forward(self, x):
+        return self.head(self.encode(x))
+
+    def encode(self, x):
+        """The frozen part (preprocessing + dilated ResNet-50, train-mode BatchNorm side effects included): depends on no trainable
+        weight, so a training loop may run it for the NEXT batch while the current one is still in its backward pass."""
         if self.preprocessing:
             x = self.preprocessing(x)
         x = engine.to_cl_bf16(x)
         with torch.no_grad():                      # encoder params are frozen (image_model.py:113-114)
-            x = self.encoder(x)
+            return self.encoder(x)
+
+    def head(self, x):
+        """The trainable 1x1 decoder + x4 bilinear + L2 normalisation on the encoder's output."""
         x = self.decoder[0](x)
         if torch.is_grad_enabled() and x.requires_grad:
             # differentiable path (contrastive loss active)

@@ -97,16 +97,48 @@ class SupervisedTrainer(BaseTrainer):
                                                                     need_latents=(i == s.nr_events_data_b - 1))
         return latent
 
-    def task_train_step(self, batch):
+    def _set_modes(self):
         s = self.settings
-        losses, t_loss = {}, 0.
         for name, m in self.models_dict.items():
             m.train()
             if name == 'front_sensor_b' and not s.unfrozen_e2vid:
                 m.eval()
+
+    def front_step(self, batch):
+        """Frozen half of a step: the recurrent E2VID encoder (frozen in every fine-tune / linear-probe YAML) depends on no weight
+        the optimiser touches, so BaseTrainer.trainEpoch enqueues it for batch i+1 on its own HIP stream BEFORE the trainable half
+        of batch i (decoder forward / backward / AdamW, bound by HBM) and it runs under it.  Returns None when there is nothing
+        frozen to run ahead (frame2recon, unfrozen_e2vid): the step then runs whole in train_step."""
+        s = self.settings
+        if s.config_option not in ('recon2voxel', 'frame2voxel') or s.unfrozen_e2vid or not batch[0].is_cuda:
+            return None
+        self._set_modes()
+        if getattr(self, '_front_stream', None) is None:
+            self._front_stream = torch.cuda.Stream(device=self.device)
+        F, main = self._front_stream, torch.cuda.current_stream(self.device)
+        F.wait_stream(main)
+        with torch.cuda.stream(F):
+            latent = {k: v.detach() for k, v in self._latents(batch[0]).items()}
+            self.reconstructor.last_states_for_each_channel = {'grayscale': None}
+            done = torch.cuda.Event()
+            done.record(F)
+        return latent, done
+
+    def task_train_step(self, batch, front=None):
+        s = self.settings
+        losses, t_loss = {}, 0.
+        self._set_modes()
         gt = batch[1]
         if s.config_option in ('recon2voxel', 'frame2voxel'):
-            latent = {k: v.detach() for k, v in self._latents(batch[0]).items()}
+            if front is not None:
+                latent, done = front
+                main = torch.cuda.current_stream(self.device)
+                main.wait_event(done)
+                for v in latent.values():
+                    if torch.is_tensor(v):
+                        v.record_stream(main)
+            else:
+                latent = {k: v.detach() for k, v in self._latents(batch[0]).items()}
             pred, _ = self.task_backend(latent)
             labels = f.interpolate(gt.float().unsqueeze(1), size=(self.input_height, self.input_width), mode='nearest').squeeze(1).long()
             loss = self.task_loss(pred[1], labels) * s.weight_task_loss
@@ -117,11 +149,11 @@ class SupervisedTrainer(BaseTrainer):
             losses['semseg_recon_loss'] = loss.detach()
         return t_loss + loss, losses, {}
 
-    def train_step(self, batch):
+    def train_step(self, batch, front=None):
         for opt in self.optimizers_dict.values():
             opt.zero_grad()
         self.grad_reducer.prepare()          # N > 1: gradients accumulate straight into the all-reduce buckets
-        t_loss, losses, outputs = self.task_train_step(batch)
+        t_loss, losses, outputs = self.task_train_step(batch, front=front)
         t_loss.backward()
         self.grad_reducer()
         for opt in self.optimizers_dict.values():

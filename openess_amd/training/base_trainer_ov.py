@@ -84,8 +84,24 @@ class BaseTrainer(object):
         for m in self.models_dict.values():
             m.train()
         n = len(self.train_loader_sensor_b)
-        for i_batch, batch in enumerate(self.device_batches(self.train_loader_sensor_b)):
-            out = self.train_step(batch)
+        batches = self.device_batches(self.train_loader_sensor_b)
+        front_step = getattr(self, 'front_step', None)
+        if front_step is not None and getattr(self.settings, 'pipeline_steps', True):
+            # trainers with a frozen front half (OpenESSPretrainModel): front(batch i+1) is enqueued before the trainable half of
+            # batch i, so that it runs under it (same results; settings.pipeline_steps: False = one step after the other)
+            def results():
+                prev = None
+                for batch in batches:
+                    fr = front_step(batch)
+                    if prev is not None:
+                        yield self.train_step(prev[0], front=prev[1])
+                    prev = (batch, fr)
+                if prev is not None:
+                    yield self.train_step(prev[0], front=prev[1])
+            outs = results()
+        else:
+            outs = (self.train_step(batch) for batch in batches)
+        for i_batch, out in enumerate(outs):
             if i_batch % 20 == 0 and self.rank == 0:
                 self.log_train(i_batch, n, out[0])
             self.step_count += 1

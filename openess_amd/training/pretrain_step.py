@@ -3,6 +3,7 @@ training/pretrain_trainer.py: buildModels (:107-208), createOptimizerDict (:211-
 (:324-361) and task_train_step (:364-534).  This is the self-contained step object used by bench.py,
 smoke() and the trainer classes; it owns the models_dict / optimizers_dict with the reference's key names.
 """
+import contextlib
 import math
 
 import torch
@@ -17,6 +18,14 @@ from ..utils.loss_functions import NCELoss, TaskLoss
 from ..utils.optim import AdamW          # torch.optim.AdamW with its step on the multi-tensor HIP kernel
 
 
+class _Front:
+    """What the frozen half of a step leaves for the trainable half (PretrainStep.front)."""
+    __slots__ = ('content', 'teacher_enc', 'teacher_out', 'online_pl', 'streams', 'done')
+
+    def __init__(self):
+        self.content = self.teacher_enc = self.teacher_out = self.online_pl = self.streams = self.done = None
+
+
 class PretrainStep:
     # frame2voxel + contrastive: the student's 256-channel map is only pooled over superpixels, and the mean commutes with its 1x1
     # convolution (hip.PointwiseFeature); False = materialise the map as the reference does (A/B, tests)
@@ -24,11 +33,15 @@ class PretrainStep:
     # contrastive: the teacher's upsampled + normalised features are only pooled too -> hip.UpsampledNormalizedFeature (one-pass
     # backward); False = the full-resolution tensor goes through autograd as three separate adjoints
     pooled_teacher_features = True
-    # The frozen teacher's forward (image_model.py:130-143: a third of the step, BatchNorm-apply passes and short-K 1x1 layers
-    # bound by HBM) shares no data with the recurrent E2VID encoder (matrix- / LDS-bound) until the losses meet: it runs on its
-    # own HIP stream under the encoder and joins where its features are first read (the pooling of the contrastive loss) or, when
-    # nothing reads them (pixel distillation: only its BatchNorm side effects exist), at the end of the forward.  Same kernels on
-    # the same buffers, ordered by events: results are bit-identical.  False = one stream (A/B, per-launch timing without overlap).
+    # FROZEN FRONT / TRAINABLE BACK.  The teacher's encoder (image_model.py:130-143) and the recurrent E2VID encoder are frozen:
+    # nothing in them depends on a weight the optimiser touches.  `front(batch)` runs them on their own HIP streams (teacher on
+    # one, E2VID on another: the teacher's BatchNorm-apply passes and short-K 1x1 layers are bound by HBM, the ConvLSTM by the
+    # matrix / LDS side) and returns a handle; `task_train_step(batch, front=handle)` is the trainable rest (student decoder /
+    # DeepLabv3, teacher head when the contrastive loss trains it, losses).  A loop may therefore enqueue front(batch i+1) BEFORE
+    # the back half of batch i (`pipeline_steps`): the frozen front of the next batch then runs under the HBM-bound decoder
+    # forward / backward / AdamW of the current one.  Same kernels on the same values in a dependency-respecting order: losses,
+    # gradients, weights and the teacher's running statistics are bit-identical to the one-stream order (tests/test_hip_determinism).
+    # overlap_teacher = False puts everything on the caller's stream (A/B, per-launch timing without CU sharing).
     overlap_teacher = True
 
     def __init__(self, config_option='frame2voxel', num_classes=11, img_size=(440, 640), nr_events_data=20,
@@ -105,95 +118,116 @@ class PretrainStep:
             if name == 'front_sensor_b':
                 m.eval()                       # unfrozen_e2vid: False in every pre-training YAML
 
-    def _teacher(self, frame):
-        """The reference always runs the teacher forward (pretrain_trainer.py:434,484), including its train-mode
-        BatchNorm side effects, even when the contrastive loss is off and its output is unused.  In that case no
-        gradient can reach the teacher's decoder, so the forward runs without autograd bookkeeping."""
-        if self.if_spatial_contrastive:
-            return self.model_frame(frame)
-        with torch.no_grad():
-            return self.model_frame(frame)
+    def front(self, batch):
+        """Frozen half of the step for `batch` (see the class comment): teacher encoder (+ its head when nothing trains it) and,
+        for frame2voxel, the 20 recurrent E2VID encoder steps.  Everything is enqueued, nothing is waited for; the handle goes to
+        task_train_step(batch, front=handle)."""
+        self._set_modes()
+        h = _Front()
+        frame = batch[2] if self.config_option == 'frame2voxel' else batch[0]
+        cuda = self.overlap_teacher and self.device.type == 'cuda' and frame.is_cuda
+        main = torch.cuda.current_stream(self.device) if cuda else None
+        if cuda:
+            if getattr(self, '_front_stream', None) is None:
+                self._front_stream = torch.cuda.Stream(device=self.device)
+                self._teacher_stream = torch.cuda.Stream(device=self.device)
+            F, T = self._front_stream, self._teacher_stream
+            F.wait_stream(main)                  # the batch's tensors and everything queued so far (NOT what the caller enqueues later)
+            T.wait_stream(main)
+        ctx = (lambda st: torch.cuda.stream(st)) if cuda else (lambda st: contextlib.nullcontext())
+        if self.online_teacher is not None:
+            with ctx(T if cuda else None), torch.no_grad():
+                h.online_pl = self.online_teacher(frame).argmax(dim=1)
+        with ctx(T if cuda else None):
+            # the teacher head is trained by the contrastive loss: then it belongs to the back half; otherwise nothing can reach it
+            # and the whole forward runs here without autograd bookkeeping (the reference runs it too, pretrain_trainer.py:434,484)
+            if self.if_spatial_contrastive:
+                h.teacher_enc = self.model_frame.encode(frame)
+            else:
+                with torch.no_grad():
+                    h.teacher_out = self.model_frame(frame)
+        if self.config_option == 'frame2voxel':
+            event = batch[0]
+            with ctx(F if cuda else None):
+                wf = getattr(self, 'wavefront', None)
+                if wf is not None:
+                    wf.begin()
+                self.reconstructor.last_states_for_each_channel = {'grayscale': None}
+                for i in range(self.nr_events_data):
+                    _, _, latent_real = self.reconstructor.update_reconstruction(
+                        event, channel_slice=(i * self.bins, self.bins), wavefront=wf,
+                        need_latents=(i == self.nr_events_data - 1))      # only the last sub-window's latents are used (:437-441)
+                if wf is not None:
+                    wf.end(*latent_real.values())
+                self.reconstructor.last_states_for_each_channel = {'grayscale': None}    # the sequence ends with the step
+                h.content = {k: v.detach() for k, v in latent_real.items()}              # trainTaskStepPretrain (:550-562)
+        if cuda:
+            h.streams = (F, T)
+            h.done = (torch.cuda.Event(), torch.cuda.Event())
+            h.done[0].record(F)
+            h.done[1].record(T)
+        return h
 
-    def _teacher_begin(self, frame):
-        """Teacher forward, on the side stream when `overlap_teacher` (see the class attribute); `_teacher_join()` before its
-        result is read on the current stream."""
-        self._teacher_side = None
-        if not (self.overlap_teacher and self.device.type == 'cuda' and frame.is_cuda):
-            return self._teacher(frame)
-        from .. import engine
-        # every stale packed operand of the step (the trainable weights after the optimiser step) is refreshed HERE, on the current
-        # stream: the group repack must not be triggered from the side stream while this stream's convolutions read the operands
-        engine.PackedWeight.refresh_stale(self.device)
-        if getattr(self, '_teacher_stream', None) is None:
-            self._teacher_stream = torch.cuda.Stream(device=self.device)
-        side, main = self._teacher_stream, torch.cuda.current_stream(self.device)
-        side.wait_stream(main)                       # the frame, the weights, the previous step
-        with torch.cuda.stream(side):
-            feat = self._teacher(frame)
-        self._teacher_side = side
-        self._teacher_out = feat
-        return feat
-
-    def _teacher_join(self):
-        side = getattr(self, '_teacher_side', None)
-        if side is None:
+    def _join_front(self, h):
+        """The current stream continues after the front half; tensors allocated on the front streams are handed to it."""
+        if h.streams is None:
             return
         main = torch.cuda.current_stream(self.device)
-        main.wait_stream(side)
-        feat = self._teacher_out
-        for t in (feat, getattr(feat, 'x', None)):      # tensors allocated on the side stream and read on this one from here on
+        for e in h.done:
+            main.wait_event(e)
+        live = [h.teacher_enc, h.teacher_out, getattr(h.teacher_out, 'x', None), h.online_pl] + list((h.content or {}).values())
+        for t in live:
             if torch.is_tensor(t) and t.is_cuda:
                 t.record_stream(main)
-        self._teacher_side = self._teacher_out = None
+        h.streams = None
+
+    def pipeline_steps(self, batches, back):
+        """Software pipeline over an iterable of device batches: front(batch i+1) is enqueued before `back(batch i, front i)` runs,
+        so the frozen half of the next batch executes under the trainable half of the current one.  `back` is the caller's step
+        body (zero_grad, task_train_step(batch, front=...), backward, optimiser); yields its results in batch order."""
+        prev = None
+        for batch in batches:
+            fr = self.front(batch)
+            if prev is not None:
+                yield back(*prev)
+            prev = (batch, fr)
+        if prev is not None:
+            yield back(*prev)
 
     def _pool(self, feat, superpixels, S):
         return hip.superpixel_pool(feat, superpixels, self.superpixel_size, S=S)
 
-    def task_train_step(self, batch):
+    def task_train_step(self, batch, front=None):
         """batch: (event | frame, label, frame | recon, pl, superpixels) already on the device.
-        `superpixel_rows` (optional 6th item) = max offset id + 1 computed by the loader on the host."""
+        `superpixel_rows` (optional 6th item) = max offset id + 1 computed by the loader on the host.
+        front: the handle of front(batch) when the caller pipelines the steps; None = the frozen half is enqueued here."""
         losses = {}
         t_loss = 0.
         self._set_modes()
         S = batch[5] if len(batch) > 5 else None
-        if self.online_teacher is not None:
-            with torch.no_grad():
-                online_pl = self.online_teacher(batch[2] if self.config_option == 'frame2voxel' else batch[0]).argmax(dim=1)
-            batch = (*batch[:3], online_pl, *batch[4:])
+        h = front if front is not None else self.front(batch)
+        self._join_front(h)
+        if h.online_pl is not None:
+            batch = (*batch[:3], h.online_pl, *batch[4:])
+        feat_frame = self.model_frame.head(h.teacher_enc) if self.if_spatial_contrastive else h.teacher_out
         if self.config_option == 'frame2voxel':
-            event, frame, pl = batch[0], batch[2], batch[3]
-            wf = getattr(self, 'wavefront', None)
-            if wf is not None:
-                wf.begin()              # the level streams start here: the recurrent encoder also overlaps the teacher forward below
-            feat_frame = self._teacher_begin(frame)
-            self.reconstructor.last_states_for_each_channel = {'grayscale': None}
-            for i in range(self.nr_events_data):
-                _, _, latent_real = self.reconstructor.update_reconstruction(
-                    event, channel_slice=(i * self.bins, self.bins), wavefront=wf,
-                    need_latents=(i == self.nr_events_data - 1))      # only the last sub-window's latents are used (:437-441)
-            if wf is not None:
-                wf.end(*latent_real.values())
-            content = {k: v.detach() for k, v in latent_real.items()}          # trainTaskStepPretrain (:550-562)
-            pred, feat_voxel = self.task_backend(content)
+            pl = batch[3]
+            pred, feat_voxel = self.task_backend(h.content)
             loss_dense = self.task_loss(pred[1], pl) * self.weight_task_loss
             losses['dense_clip_loss'] = loss_dense.detach()
             if self.if_spatial_contrastive:
                 k = self._pool(feat_voxel, batch[4], S)
-                self._teacher_join()
                 q = self._pool(feat_frame, batch[4], S)
                 loss_nce = self.nce_loss(k, q)
                 losses['contrastive_nce_loss'] = loss_nce.detach()
                 t_loss = t_loss + loss_nce
             if self.if_dense_clip_supervision:
                 t_loss = t_loss + loss_dense
-            self._teacher_join()
         else:                                                                   # frame2recon (:475-529)
-            frame, recon, pl = batch[0], batch[2], batch[3]
-            feat_frame = self._teacher_begin(frame)
+            recon, pl = batch[2], batch[3]
             logits_recon, feat_recon = self.model_recon(recon)
             if self.if_spatial_contrastive:
                 k = self._pool(feat_recon, batch[4], S)
-                self._teacher_join()
                 q = self._pool(feat_frame, batch[4], S)
                 loss_nce = self.nce_loss(k, q)
                 losses['contrastive_nce_loss'] = loss_nce.detach()
@@ -202,7 +236,6 @@ class PretrainStep:
                 loss_dense = self.task_loss(logits_recon, pl) * self.weight_task_loss
                 losses['dense_clip_loss'] = loss_dense.detach()
                 t_loss = t_loss + loss_dense
-            self._teacher_join()
         return t_loss, losses, {}
 
     # ------------------------------------------------------------------ pretrain_trainer.py:324-361

@@ -49,14 +49,19 @@ class OpenESSPretrainModel(BaseTrainer):
                 for g in self.optimizers_dict[key].param_groups:
                     g['lr'] = lr
 
-    def task_train_step(self, batch):
-        return self.step.task_train_step(batch)
+    def task_train_step(self, batch, front=None):
+        return self.step.task_train_step(batch, front=front)
 
-    def train_step(self, batch):
+    def front_step(self, batch):
+        """Frozen half of the step (teacher encoder, recurrent E2VID encoder) for `batch`, enqueued on its own HIP streams: trainEpoch
+        calls it for batch i+1 before train_step(batch i, front=...) (PretrainStep.front / pipeline_steps)."""
+        return self.step.front(batch)
+
+    def train_step(self, batch, front=None):
         for opt in self.optimizers_dict.values():
             opt.zero_grad()
         self.grad_reducer.prepare()          # N > 1: gradients accumulate straight into the all-reduce buckets
-        t_loss, losses, outputs = self.task_train_step((batch[0], batch[1], batch[2], batch[3], batch[4], batch[-1]))
+        t_loss, losses, outputs = self.task_train_step((batch[0], batch[1], batch[2], batch[3], batch[4], batch[-1]), front=front)
         t_loss.backward()
         self.grad_reducer()
         for opt in self.optimizers_dict.values():

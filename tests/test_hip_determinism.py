@@ -104,8 +104,9 @@ def test_pretrain_step_bit_repeatable(option, contr):
     for rep in range(3):
         st = PretrainStep(config_option=option, img_size=(H, W), nr_events_data=nwin, if_spatial_contrastive=contr,
                           superpixel_size=25, lr=1e-4)
-        # runs 0 and 2: the teacher forward on its own HIP stream under the student's encoder (the default); run 1: one stream.
-        # Same kernels on the same buffers, ordered by events -> the three runs must agree bit for bit.
+        # run 0: the frozen half (teacher encoder, E2VID encoder) on its own HIP streams inside each step (the default); run 1: one
+        # stream; run 2: streams AND the software pipeline -- front(step 1) enqueued before the trainable half of step 0
+        # (PretrainStep.pipeline_steps).  Same kernels on the same values, ordered by events -> bit-identical.
         st.overlap_teacher = rep != 1
         for name, m in st.models_dict.items():
             fill_by_name(m, 100 + len(name))
@@ -113,9 +114,22 @@ def test_pretrain_step_bit_repeatable(option, contr):
         if option == "frame2recon":
             st.model_recon.classifier.ASPP.project[3].p = 0.0        # dropout off: the Philox stream differs between the two runs
         rec = []
-        for it in range(2):
-            losses, _, tl = st.train_step((first, None, frame, pl, sp, S))
-            rec.append({k: float(v) for k, v in losses.items()})
+        batch = (first, None, frame, pl, sp, S)
+        if rep == 2:
+            def back(b, fr):
+                for opt in st.optimizers_dict.values():
+                    opt.zero_grad()
+                t_loss, losses, _ = st.task_train_step(b, front=fr)
+                t_loss.backward()
+                for opt in st.optimizers_dict.values():
+                    opt.step()
+                return losses
+            for losses in st.pipeline_steps([batch, batch], back):
+                rec.append({k: float(v) for k, v in losses.items()})
+        else:
+            for it in range(2):
+                losses, _, tl = st.train_step(batch)
+                rec.append({k: float(v) for k, v in losses.items()})
         w = {f"{k}.{n}": p.detach().clone() for k, m in st.models_dict.items() for n, p in m.named_parameters() if p.requires_grad}
         w.update({f"model_frame.buf.{n}": b.detach().clone() for n, b in st.model_frame.named_buffers()})     # BatchNorm running stats
         gr = {f"{k}.{n}": (None if p.grad is None else p.grad.detach().clone()) for k, m in st.models_dict.items()

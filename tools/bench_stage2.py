@@ -17,6 +17,8 @@ import yaml
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+PIPELINE = True
+
 CASES = [  # name, yaml, config_option, flags
     ("finetune_frame2voxel", "finetune_dsec_synthetic.yaml", "frame2voxel", dict(if_finetuning=True)),
     ("finetune_frame2recon", "finetune_dsec_synthetic.yaml", "frame2recon", dict(if_finetuning=True)),
@@ -58,12 +60,22 @@ def measure(steps=20, warm=3, only=None):
             for m in trainer.models_dict.values():
                 m.train()
             batch = next(iter(trainer.device_batches(trainer.train_loader_sensor_b)))
-            for _ in range(warm):
-                trainer.train_step(batch)
+            front_step = getattr(trainer, 'front_step', None) if PIPELINE else None
+
+            def run(n):
+                # BaseTrainer.trainEpoch's order: the frozen half of step i + 1 (trainers that have one) is enqueued before the
+                # trainable half of step i
+                prev = front_step(batch) if front_step is not None else None
+                out = None
+                for i in range(n):
+                    nxt = front_step(batch) if (front_step is not None and i + 1 < n) else None
+                    out = trainer.train_step(batch, front=prev) if prev is not None else trainer.train_step(batch)
+                    prev = nxt
+                return out
+            run(warm)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(steps):
-                losses, _, total = trainer.train_step(batch)
+            losses, _, total = run(steps)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             out[name] = {"value": round(steps * s.batch_size_b / dt, 2), "unit": "event-frames/s", "ms_per_step": round(dt / steps * 1e3, 3),
@@ -77,11 +89,12 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--only", nargs="*")
-    ap.add_argument("--one-stream", action="store_true", help="OpenESSModel: both students on one stream (A/B of the two-stream default)")
+    ap.add_argument("--one-stream", action="store_true", help="A/B: OpenESSModel's students on one stream; no frozen-front pipelining in the fine-tune / linear-probe steps")
     a = ap.parse_args()
     if a.one_stream:
         from openess_amd.training.openess_trainer import OpenESSModel
         OpenESSModel.two_streams = False
+        PIPELINE = False
     r = measure(a.steps, only=a.only)
     for k, v in r.items():
         print(f"{k:34s} {v['value']:8.2f} event-frames/s  {v['ms_per_step']:8.3f} ms/step  ({v['trainer']}, loss {v['loss']})", file=sys.stderr)

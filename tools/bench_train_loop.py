@@ -46,20 +46,33 @@ def build(batches, workers, prefetch, B=8, contrastive=False, tmp=None, ring=Tru
     return trainer, s
 
 
-def measure(batches=24, workers=4, prefetch=True, warm=4, ring=True):
+def measure(batches=24, workers=4, prefetch=True, warm=4, ring=True, pipeline=True):
     with tempfile.TemporaryDirectory(prefix="oess_loop_", dir="/tmp") as tmp:
         trainer, s = build(batches + warm, workers, prefetch, tmp=tmp, ring=ring)
         for m in trainer.models_dict.values():
             m.train()
         B = s.batch_size_b
-        t0, n = None, 0
-        for i, batch in enumerate(trainer.device_batches(trainer.train_loader_sensor_b)):
-            if i == warm:
+        t0, done = None, 0
+
+        def step(batch, fr):                       # one finished step; the clock starts after `warm` of them
+            nonlocal t0, done
+            trainer.train_step(batch, front=fr) if fr is not None else trainer.train_step(batch)
+            done += 1
+            if done == warm:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-            trainer.train_step(batch)
-            if i >= warm:
-                n += 1
+        prev = None
+        for batch in trainer.device_batches(trainer.train_loader_sensor_b):
+            if pipeline:                           # BaseTrainer.trainEpoch's order: front(i + 1) enqueued before the back half of i
+                fr = trainer.front_step(batch)
+                if prev is not None:
+                    step(*prev)
+                prev = (batch, fr)
+            else:
+                step(batch, None)
+        if prev is not None:
+            step(*prev)
+        n = done - warm
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         loader = trainer.train_loader_sensor_b
@@ -68,7 +81,7 @@ def measure(batches=24, workers=4, prefetch=True, warm=4, ring=True):
         if hasattr(loader, "close"):
             loader.close()
         return {"value": round(n * B / dt, 2), "unit": "event-frames/s", "ms_per_step": round(dt / n * 1e3, 3), "steps": n,
-                "loader_workers": workers, "prefetch": bool(prefetch), "loader": kind,
+                "loader_workers": workers, "prefetch": bool(prefetch), "loader": kind, "pipelined_steps": bool(pipeline),
                 "note": "train.py's own loop: DataLoader workers -> collate (13 B/event raw columns, 208 MB/batch) -> pin thread -> "
                         "side-stream H2D + voxelizer (BaseTrainer.device_batches) -> OpenESSPretrainModel.train_step; 16-sample pool"}
 
@@ -78,7 +91,8 @@ if __name__ == "__main__":
     ap.add_argument("--batches", type=int, default=24)
     ap.add_argument("--workers", type=int, default=4)
     ap.add_argument("--dataloader", action="store_true", help="torch's DataLoader instead of the pinned ring loader (A/B)")
+    ap.add_argument("--no-pipeline", action="store_true", help="one step after the other (no front(i+1) ahead of the back half of step i)")
     ap.add_argument("--no-prefetch", action="store_true")
     a = ap.parse_args()
-    r = measure(a.batches, a.workers, not a.no_prefetch, ring=not a.dataloader)
+    r = measure(a.batches, a.workers, not a.no_prefetch, ring=not a.dataloader, pipeline=not a.no_pipeline)
     print(json.dumps(r))
