@@ -27,7 +27,10 @@ class OpenESSModel(BaseTrainer):
     # the 256-channel full-resolution features of both students are only consumed by the L1 consistency loss and the superpixel
     # pooling: both work on the OS16 maps (hip.UpsampledFeature: one upsampled difference, one pooling matrix); False = tensors
     lazy_features = True
-    two_streams = True               # the two students' forward (and, through autograd, backward) passes on two HIP streams; False = one
+    # True: the two students' forward (and, through autograd, backward) passes on two HIP streams.  Measured at the BASELINE size over
+    # five alternating pairs of runs (round 5): 300 vs 294 event-frames/s with a +-30 run-to-run spread -- no gain to show, so
+    # the default stays one stream; the switch and its bit-equality test remain.
+    two_streams = False
 
     def init_fn(self):
         """openess_trainer.py:84-86: models, then optimisers, then the loss objects."""

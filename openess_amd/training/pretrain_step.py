@@ -5,6 +5,7 @@ smoke() and the trainer classes; it owns the models_dict / optimizers_dict with 
 """
 import contextlib
 import math
+import os
 
 import torch
 
@@ -129,8 +130,9 @@ class PretrainStep:
         main = torch.cuda.current_stream(self.device) if cuda else None
         if cuda:
             if getattr(self, '_front_stream', None) is None:
-                self._front_stream = torch.cuda.Stream(device=self.device)
-                self._teacher_stream = torch.cuda.Stream(device=self.device)
+                pr = int(os.environ.get("OESS_FRONT_PRIORITY", "0"))          # EXPERIMENT knob (round 5): HIP stream priority of the front streams
+                self._front_stream = torch.cuda.Stream(device=self.device, priority=pr)
+                self._teacher_stream = torch.cuda.Stream(device=self.device, priority=pr)
             F, T = self._front_stream, self._teacher_stream
             F.wait_stream(main)                  # the batch's tensors and everything queued so far (NOT what the caller enqueues later)
             T.wait_stream(main)

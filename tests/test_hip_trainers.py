@@ -203,7 +203,7 @@ def test_openess_model_two_streams_equal_one_stream(tmp_path):
     from openess_amd.config.settings import Settings
     from openess_amd.training.openess_trainer import OpenESSModel
     runs = []
-    for two in (True, False, True):
+    for two in (True, False, True):          # (the default is one stream; the switch must stay exact)
         train.seed_everything()
         s = Settings(os.path.join(CFG, "openess_dsec_synthetic.yaml"), generate_log=False)
         s.ckpt_dir = str(tmp_path)
