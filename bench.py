@@ -191,7 +191,7 @@ def _pmc_pass(counter, timeout_s):
     out = tempfile.mkdtemp(prefix=f"oess_pmc_{counter}_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--",
-           sys.executable, os.path.abspath(__file__), "--child", "--steps", "1", "--warmup", "1"]
+           sys.executable, os.path.abspath(__file__), "--child", "--steps", "1", "--warmup", "1", "--no-overlap-teacher"]
     try:
         subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         import csv

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copy the judged summaries of tools/final_run.sh from gpurun_out/fin/ into profiles/ (tracked), named per round."""
 import json, os, shutil, subprocess, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r04"
+R = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src, dst = "gpurun_out/fin", "profiles"
 pairs = {f"prof_frame2voxel_pixel_distill/step_kernel_stats.csv": f"{R}_step_pixel_distill_kernel_stats.csv",
          f"prof_frame2voxel_full/step_kernel_stats.csv": f"{R}_step_frame2voxel_full_kernel_stats.csv",
@@ -10,7 +10,8 @@ pairs = {f"prof_frame2voxel_pixel_distill/step_kernel_stats.csv": f"{R}_step_pix
          f"stage_maskclip_fwd/p_kernel_stats.csv": f"{R}_stage_maskclip_fwd_kernel_stats.csv",
          f"stage_teacher_fwd/p_kernel_stats.csv": f"{R}_stage_teacher_fwd_kernel_stats.csv",
          f"vox_raw1/p_kernel_stats.csv": f"{R}_voxelizer_raw_kernel_stats.csv",
-         f"vox_raw0/p_kernel_stats.csv": f"{R}_voxelizer_f32_kernel_stats.csv"}
+         f"vox_raw0/p_kernel_stats.csv": f"{R}_voxelizer_f32_kernel_stats.csv",
+         f"prof_pipelined/step_kernel_stats.csv": f"{R}_step_pixel_distill_pipelined_kernel_stats.csv"}
 for a, b in pairs.items():
     shutil.copyfile(os.path.join(src, a), os.path.join(dst, b))
 line = [l for l in open(os.path.join(src, "bench.txt")).read().split("\n") if l.startswith("{")][-1]
@@ -19,7 +20,7 @@ subprocess.run([sys.executable, "tools/mfma_util.py", os.path.join(src, "pmc_mfm
                check=True, stdout=subprocess.DEVNULL)
 # plain-text outputs quoted in DESIGN / EXPERIMENTS (present from round 3 on)
 with open(os.path.join(dst, f"{R}_misc_outputs.txt"), "w") as f:
-    for name in ("pytest_gpu.txt", "pytest_gpu_run2.txt", "smoke.txt", "bench_no_skew.txt", "bench_torchrun_world1.txt", "train_loop.txt", "png.txt", "deeplab_breakdown.txt",
+    for name in ("pytest_gpu.txt", "pytest_gpu_run2.txt", "smoke.txt", "bench_schedule_ab.txt", "bench_no_skew.txt", "aten_probe_frame2recon_full.txt", "bench_torchrun_world1.txt", "train_loop.txt", "png.txt", "deeplab_breakdown.txt",
                  "segmean.txt", "voxelizer_pmc.txt", "stage_deeplab_fwd.txt", "stage_maskclip_fwd.txt", "stage_teacher_fwd.txt",
                  "vox_raw1.txt", "vox_raw0.txt", "enc_s2.txt", "probe_1x1.txt", "gap_probe.txt", "insitu_probe.txt", "step_sequence.txt"):
         p = os.path.join(src, name)

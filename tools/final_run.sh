@@ -19,19 +19,28 @@ for i in 1 2; do
 done
 # RCCL call path with ONE rank (the box has one GPU): torch.distributed.run -> nccl process group -> bucketed all-reduce per step
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --no-pmc --no-extras > $O/bench_torchrun_world1.txt 2>&1
+# same box: the product schedule (frozen front of step i+1 under the trainable back of step i) / front streams without the
+# cross-step pipeline / everything on one stream -- alternating short runs
+for i in 1 2; do for f in "" "--no-pipeline" "--no-overlap-teacher"; do
+  echo "frame2voxel_pixel_distill $f" >> $O/bench_schedule_ab.txt
+  timeout 600 python bench.py --steps 30 --warmup 5 $f --no-cpu-baseline --no-pmc --no-extras 2>&1 | tail -1 | cut -c1-160 >> $O/bench_schedule_ab.txt
+done; done
+# kernel traces: ONE stream (a launch's duration is the kernel's own: what `roofline` quotes) and the product schedule
 for wl in frame2voxel_pixel_distill frame2voxel_full frame2recon_full; do
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -o step -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-extras --workload $wl > $O/prof_$wl.txt 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -o step -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-extras --no-overlap-teacher --workload $wl > $O/prof_$wl.txt 2>&1
 done
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_pipelined -o step -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-extras > $O/prof_pipelined.txt 2>&1
 for st in deeplab_fwd maskclip_fwd teacher_fwd; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stage_$st -o p -- python tools/bench_stage.py $st --iters 10 > $O/stage_$st.txt 2>&1
 done
 for r in 1 0; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/vox_raw$r -o p -- python tools/bench_voxelizer.py --raw $r --iters 20 > $O/vox_raw$r.txt 2>&1
 done
-timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_mfma -o p -- python bench.py --child --steps 1 --warmup 1 > $O/pmc_mfma.txt 2>&1
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_mfma -o p -- python bench.py --child --steps 1 --warmup 1 --no-overlap-teacher > $O/pmc_mfma.txt 2>&1
 python tools/mfma_util.py $O/pmc_mfma $O/mfma_util.json > $O/mfma_util.txt 2>&1 || true
 timeout 600 bash tools/pmc_traffic.sh "python tools/bench_voxelizer.py --raw 1 --iters 5" "tri_sort|tri_splat" > $O/voxelizer_pmc.txt 2>&1
-{ timeout 300 python tools/bench_train_loop.py --workers 4; timeout 300 python tools/bench_train_loop.py --workers 2; timeout 300 python tools/bench_train_loop.py --workers 4 --no-prefetch; timeout 300 python tools/bench_train_loop.py --workers 4 --dataloader; timeout 300 python tools/bench_train_loop.py --workers 10 --dataloader; } > $O/train_loop.txt 2>&1
+{ timeout 300 python tools/bench_train_loop.py --workers 4; timeout 300 python tools/bench_train_loop.py --workers 2; timeout 300 python tools/bench_train_loop.py --workers 4 --no-pipeline; timeout 300 python tools/bench_train_loop.py --workers 4 --no-prefetch; timeout 300 python tools/bench_train_loop.py --workers 4 --dataloader; timeout 300 python tools/bench_train_loop.py --workers 10 --dataloader; } > $O/train_loop.txt 2>&1
+timeout 300 python tools/aten_probe.py frame2recon_full > $O/aten_probe_frame2recon_full.txt 2>&1 || true
 timeout 300 python tools/bench_png.py > $O/png.txt 2>&1
 timeout 300 python tools/bench_stage.py deeplab_fwd --breakdown > $O/deeplab_breakdown.txt 2>&1
 timeout 300 python tools/bench_segmean.py > $O/segmean.txt 2>&1 || true
