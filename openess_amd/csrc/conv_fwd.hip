@@ -860,7 +860,13 @@ __device__ __forceinline__ void conv3x3_halo_tile(const ConvArgs& a, const int b
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int nch = a.Cin >> 6;                          // 64-channel chunks
+    // Loop-invariant scalars of the K loop, pinned in SGPRs.  In the grouped kernel `a` is g.a[p] with a run-time p, i.e. kernel-
+    // argument MEMORY: hipcc treats such loads as free to rematerialise and re-issued s_load_dword a.Cin / a.H / a.in_pix_stride
+    // + s_waitcnt lgkmcnt(0) in front of every slab's barrier (round-5 disassembly: three scalar-cache round trips per macro step
+    // on the kernel that owns 41 % of the step).  The empty asm makes the values opaque, so they stay in registers.
+    int Cin_s = a.Cin, H_s = a.H, ips_s = (int)a.in_pix_stride;
+    asm volatile("" : "+s"(Cin_s), "+s"(H_s), "+s"(ips_s));
+    const int nch = Cin_s >> 6;                          // 64-channel chunks
     const int NJ = 3 * nch;                              // macro steps (dy, chunk); 3 K-slabs each
     const int W = a.W, dil = a.dil, wd = W + dil;
 
@@ -903,24 +909,22 @@ __device__ __forceinline__ void conv3x3_halo_tile(const ConvArgs& a, const int b
         boff[i] = ((n0 + r) * a.Kpad + (slot ^ ((r >> 1) & 7)) * 8) * 2;
     }
     // halo part `part` (instructions [i0, i1)) of macro step j -> halo buffer j & 1
-    auto issue_halo = [&](int j, int i0, int i1) {
-        const int dy = j / nch, cc = j - dy * nch;
+    auto issue_halo = [&](int j, int dy, int cc, int i0, int i1) {        // (dy, cc) = (j / nch, j % nch), kept by the caller
         const int ddy = (dy - 1) * dil;
-        const int tapoff = (ddy * W * (int)a.in_pix_stride + cc * 64) * 2;
+        const int tapoff = (ddy * W * ips_s + cc * 64) * 2;
         unsigned char* st = smem + (j & 1) * HALO_BYTES;
 #pragma unroll
         for (int i = 0; i < H_INSTR; ++i) {
             if (i < i0 || i >= i1) continue;
-            const bool ok = (unsigned)(hy[i] + ddy) < (unsigned)a.H;
+            const bool ok = (unsigned)(hy[i] + ddy) < (unsigned)H_s;
             const unsigned voff = ok ? (unsigned)(hoff[i] + tapoff) : 0x80000000u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave * H_INSTR + i) * 1024),
                                                      16, voff, 0, 0, 0);
         }
     };
     // weight slab of (macro step j, dx) -> weight stage kt & 1, kt = 3*j + dx
-    auto issue_w = [&](int j, int dx) {
-        const int dy = j / nch, cc = j - dy * nch;
-        const int koff = ((dy * 3 + dx) * a.Cin + cc * 64) * 2;
+    auto issue_w = [&](int j, int dy, int cc, int dx) {
+        const int koff = ((dy * 3 + dx) * Cin_s + cc * 64) * 2;
         unsigned char* st = smem + 2 * HALO_BYTES + ((3 * j + dx) & 1) * BST_BYTES;
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i)
@@ -964,8 +968,8 @@ __device__ __forceinline__ void conv3x3_halo_tile(const ConvArgs& a, const int b
     const uint32_t half = (uint32_t)(lane >> 5);
     const uint32_t rswb = (uint32_t)(((lane & 31) >> 1) & 7);
 
-    issue_halo(0, 0, H_INSTR);
-    issue_w(0, 0);
+    issue_halo(0, 0, 0, 0, H_INSTR);
+    issue_w(0, 0, 0, 0);
     constexpr bool LSTM_PREF = (EPI == 1);
     LstmPrefetch pref;
     if constexpr (LSTM_PREF) lstm_prefetch(a, pref, m0, n0, tid);
@@ -988,19 +992,22 @@ __device__ __forceinline__ void conv3x3_halo_tile(const ConvArgs& a, const int b
 #define OESS_HWAIT(N_, FA_, FB_)                                                                                 \
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(FA_[0]), "+v"(FA_[1]), "+v"(FB_[0]), "+v"(FB_[1]) : "n"(N_) : "memory");
 
+    int dy_c = 0, cc_c = 0;                              // (dy, chunk) of macro step j, carried instead of divided out
     for (int j = 0; j < NJ; ++j) {
         const uint32_t hbase_ = lds0 + (uint32_t)((j & 1) * HALO_BYTES);
+        int dy_n = dy_c, cc_n = cc_c + 1;                // macro step j + 1
+        if (cc_n == nch) { cc_n = 0; ++dy_n; }
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();               // slab (j, dx) complete for every wave; the other buffers are free
             // next weight slab, and a third of the next macro step's halo, travel under this slab's MFMAs
-            if (dx < 2) issue_w(j, dx + 1);
-            else if (j + 1 < NJ) issue_w(j + 1, 0);
+            if (dx < 2) issue_w(j, dy_c, cc_c, dx + 1);
+            else if (j + 1 < NJ) issue_w(j + 1, dy_n, cc_n, 0);
             if (j + 1 < NJ) {
-                if (dx == 0) issue_halo(j + 1, 0, 2);
-                else if (dx == 1) issue_halo(j + 1, 2, 4);
-                else issue_halo(j + 1, 4, H_INSTR);
+                if (dx == 0) issue_halo(j + 1, dy_n, cc_n, 0, 2);
+                else if (dx == 1) issue_halo(j + 1, dy_n, cc_n, 2, 4);
+                else issue_halo(j + 1, dy_n, cc_n, 4, H_INSTR);
             }
             const uint32_t wbase_ = lds0 + (uint32_t)(((3 * j + dx) & 1) * BST_BYTES);
             bf16x8_t fa0[MT], fb0[NT], fa1[MT], fb1[NT];
@@ -1019,6 +1026,7 @@ __device__ __forceinline__ void conv3x3_halo_tile(const ConvArgs& a, const int b
             OESS_HFRAG_MMA(fa1, fb1)
             __builtin_amdgcn_s_setprio(0);
         }
+        dy_c = dy_n; cc_c = cc_n;
     }
 #undef OESS_HFRAG_READ
 #undef OESS_HFRAG_MMA
