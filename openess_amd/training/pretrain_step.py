@@ -43,6 +43,9 @@ class PretrainStep:
     # gradients, weights and the teacher's running statistics are bit-identical to the one-stream order (tests/test_hip_determinism).
     # overlap_teacher = False puts everything on the caller's stream (A/B, per-launch timing without CU sharing).
     overlap_teacher = True
+    # if_spatial_contrastive: False -> nothing reads the teacher's output.  True (default) runs the whole forward anyway, as the
+    # reference does (pretrain_trainer.py:434); False stops after the encoder, whose BatchNorm updates are the call's only effect.
+    run_unused_teacher_head = True
 
     def __init__(self, config_option='frame2voxel', num_classes=11, img_size=(440, 640), nr_events_data=20,
                  nr_temporal_bins=5, if_spatial_contrastive=False, if_dense_clip_supervision=True, superpixel_size=100,
@@ -144,9 +147,14 @@ class PretrainStep:
             # and the whole forward runs here without autograd bookkeeping (the reference runs it too, pretrain_trainer.py:434,484)
             if self.if_spatial_contrastive:
                 h.teacher_enc = self.model_frame.encode(frame)
-            else:
+            elif self.run_unused_teacher_head:
                 with torch.no_grad():
                     h.teacher_out = self.model_frame(frame)
+            else:
+                # Pixel distillation: nothing reads the teacher's features (pretrain_trainer.py:434 computes them and drops them).
+                # What the call leaves behind are the train-mode BatchNorm updates of the ENCODER; the head (1x1 conv, x4 bilinear,
+                # L2 normalise: no state) is dead code here exactly like the E2VID decoder whose outputs every caller discards.
+                h.teacher_enc = self.model_frame.encode(frame)
         if self.config_option == 'frame2voxel':
             event = batch[0]
             with ctx(F if cuda else None):
