@@ -1,10 +1,11 @@
 # usage (on the GPU box, from the repo root): bash tools/step_sequence.sh [bench.py workload]
 # Kernel trace of bench.py, then the LAST step in launch order: duration (us), idle time in front of the launch (us), kernel name
 # -> gpurun_out/seq_last_step.txt; prints the sums.  Shows where the queue runs empty (host) and the gaps between large kernels.
+# (one stream, --no-overlap-teacher: in the product schedule three streams interleave and "the step in launch order" is not a sequence)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 WL=${1:-frame2voxel_pixel_distill}
-timeout 900 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/seq -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-extras --workload $WL > gpurun_out/seq.txt 2>&1
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/seq -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --no-extras --no-overlap-teacher --workload $WL > gpurun_out/seq.txt 2>&1
 python - <<'PY'
 import csv, glob, re
 fn = glob.glob('gpurun_out/seq/**/p_kernel_trace.csv', recursive=True)[0]
