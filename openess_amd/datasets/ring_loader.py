@@ -107,13 +107,13 @@ def _worker(wid, dataset, ring, slot_bytes, tasks, done, base_seed):
         job = tasks.get()
         if job is None:
             return
-        seq, slot, indices = job
+        epoch, seq, slot, indices = job
         try:
             arena = Arena(ring[slot * slot_bytes:(slot + 1) * slot_bytes])
             batch = collate([dataset[i] for i in indices], arena=arena)
-            done.put((seq, slot, _encode(batch), None))
+            done.put((epoch, seq, slot, _encode(batch), None))
         except Exception:                                        # reported to the consumer, which raises
-            done.put((seq, slot, None, traceback.format_exc()))
+            done.put((epoch, seq, slot, None, traceback.format_exc()))
 
 
 class PinnedRingLoader:
@@ -147,6 +147,8 @@ class PinnedRingLoader:
         self._busy = []                         # (slot, event | None): handed to the consumer, copies possibly still in flight
         self._last_slot = None
         self._closed = False
+        self._epoch = 0                         # an iteration abandoned half-way leaves tasks in flight: their results are dropped
+        self._outstanding = 0                   # tasks sent - results received, over all epochs
 
     def _estimate_slot_bytes(self):
         """One batch through the plain collate on this process: its tensor bytes + 25 % (ragged event counts) + alignment slack."""
@@ -203,29 +205,35 @@ class PinnedRingLoader:
         batches = [order[i:i + self.batch_size] for i in range(0, n, self.batch_size)]
         if self.drop_last and batches and len(batches[-1]) < self.batch_size:
             batches.pop()
-        nxt, want, ready, inflight = 0, 0, {}, 0
+        self._epoch += 1
+        epoch = self._epoch
+        nxt, want, ready = 0, 0, {}
         while want < len(batches):
             self._reclaim(block=False)
             while nxt < len(batches) and self._free:
-                self._tasks.put((nxt, self._free.pop(), batches[nxt]))
+                self._tasks.put((epoch, nxt, self._free.pop(), batches[nxt]))
                 nxt += 1
-                inflight += 1
+                self._outstanding += 1
             if want in ready:
                 slot, spec = ready.pop(want)
                 want += 1
                 self._last_slot = slot
                 yield _decode(spec, self.ring[slot * self.slot_bytes:(slot + 1) * self.slot_bytes])
                 continue
-            if inflight == 0:
+            if self._outstanding == 0:
                 self._reclaim(block=True)                        # every slot is with the consumer: wait for its oldest copies
                 continue
             try:
-                seq, slot, spec, err = self._done.get(timeout=120)
+                ep, seq, slot, spec, err = self._done.get(timeout=120)
             except queue.Empty:
                 dead = [p.pid for p in self._procs if not p.is_alive()]
                 raise RuntimeError(f"PinnedRingLoader: no batch for 120 s (dead workers: {dead})")
-            inflight -= 1
+            self._outstanding -= 1
+            if ep != epoch:                                      # left over from an iteration the consumer abandoned
+                self._free.append(slot)
+                continue
             if err is not None:
+                self._free.append(slot)
                 raise RuntimeError("PinnedRingLoader worker failed:\n" + err)
             ready[seq] = (slot, spec)
         self._reclaim(block=False)

@@ -93,3 +93,21 @@ def test_arena_views_are_aligned_and_disjoint():
     assert x.start % 256 == 0 and y.start % 256 == 0 and z.start % 256 == 0 and x.start < y.start < z.start
     assert x.t.tolist() == [0, 1, 2, 3, 4, 0, 1, 2] and y.t.shape == (2, 2, 3) and z.t.tolist() == [1, 2, 3]
     assert x.t.data_ptr() == buf.data_ptr() + x.start
+
+
+def test_ring_loader_abandoned_iteration_does_not_leak_into_the_next():
+    ds = _ds(16)
+    ld = PinnedRingLoader(ds, batch_size=4, shuffle=False, num_workers=2, slots=3, pin=False)
+    try:
+        it = iter(ld)
+        first = next(it)                      # the workers are already filling the other slots for batches 1, 2
+        assert _same(first, collate([ds[j] for j in range(4)]))
+        del it                                # consumer walks away mid-epoch
+        for rep in range(2):
+            n = 0
+            for i, b in enumerate(ld):        # (a batch is only valid until the next one is requested: 3 slots, 4 batches)
+                assert _same(b, collate([ds[j] for j in range(i * 4, i * 4 + 4)])), (rep, i)
+                n += 1
+            assert n == 4
+    finally:
+        ld.close()
