@@ -847,12 +847,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a) {
 constexpr int HALO_ROWS = 160;
 
 // one 128 x 128 tile (`bid` = tile index after the XCD remap); smem = [halo 0][halo 1][weights 0][weights 1]
-template <int EPI>
+// BMX = 256 (EPI = 1 only; EXPERIMENT of round 5): an 8-wave workgroup owns 256 pixels x 128 gate columns -- the weight slab is
+// fetched once per 256 pixels (150 instead of 92 FLOP per L2 -> LDS byte, 3.7 instead of 5.7 DMA instructions per wave and slab),
+// one workgroup per CU (2 x 40 KB halo + 2 x 16 KB weights), the wave tile stays 64 x 64.
+constexpr int HALO_ROWS_256 = 320;
+constexpr int LSTM_EPI_HALF = 26624;                     // LDS of one 128-row half of the ConvLSTM epilogue (25 600 B used)
+template <int EPI, int BMX = 128>
 __device__ __forceinline__ void conv3x3_halo_tile(const ConvArgs& a, const int bid, unsigned char* smem) {
-    constexpr int BMX = 128, BN = 128, NWAVES = 4, WAVES_N = 2, WM = 64, WN = 64, MT = 2, NT = 2;
-    constexpr int H_INSTR = HALO_ROWS / 8 / NWAVES;      // 5 DMA instructions per thread per halo
-    constexpr int B_INSTR = BN * 8 / 64 / NWAVES;        // 4
-    constexpr int HALO_BYTES = HALO_ROWS * 128, BST_BYTES = BN * 128;
+    constexpr int BN = 128, NWAVES = BMX / 32, WAVES_N = 2, WM = 64, WN = 64, MT = 2, NT = 2;
+    constexpr int HROWS = (BMX == 128) ? HALO_ROWS : HALO_ROWS_256;
+    constexpr int H_INSTR = HROWS / 8 / NWAVES;          // 5 DMA instructions per thread per halo
+    constexpr int B_INSTR = BN * 8 / 64 / NWAVES;        // 4 (2 with eight waves)
+    constexpr int HALO_BYTES = HROWS * 128, BST_BYTES = BN * 128;
+    static_assert(BMX == 128 || EPI == 1, "the 256-row tile exists for the fused ConvLSTM only");
     constexpr int NFRAG = MT + NT;
 
     const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
@@ -995,7 +1002,8 @@ __device__ __forceinline__ void conv3x3_halo_tile(const ConvArgs& a, const int b
     issue_w(0, 0, 0, 0);
     constexpr bool LSTM_PREF = (EPI == 1);
     LstmPrefetch pref;
-    if constexpr (LSTM_PREF) lstm_prefetch(a, pref, m0, n0, tid);
+    const int ehalf = (BMX == 256) ? (wm >> 1) : 0;      // 256-row tile: the epilogue runs as two independent 128-row halves
+    if constexpr (LSTM_PREF) lstm_prefetch(a, pref, m0 + ehalf * 128, n0, tid & 255);
 
 #define OESS_HFRAG_READ(DST_A, DST_B, KS, DX)                                                                    \
     {                                                                                                            \
@@ -1063,7 +1071,8 @@ __device__ __forceinline__ void conv3x3_halo_tile(const ConvArgs& a, const int b
 #undef OESS_HWAIT
     __syncthreads();
 
-    if constexpr (EPI == 1) lstm_epilogue<MT, NT, true, false>(a, acc, smem, m0, n0, wm, wn, lane, tid, &pref);
+    if constexpr (EPI == 1) lstm_epilogue<MT, NT, true, false>(a, acc, smem + ehalf * LSTM_EPI_HALF, m0 + ehalf * 128, n0, wm & 1, wn, lane,
+                                                                 tid & 255, &pref);
     else conv_epilogue<BMX, BN, BN + 8, 256, WAVES_N>(a, acc, smem, m0, n0, wm, wn, lane, tid);
 }
 
@@ -1103,6 +1112,19 @@ __global__ __launch_bounds__(256) void conv3x3_halo_group_kernel(ConvGroup g) {
     const int q = nwg >> 3, r = nwg & 7;
     if (li >= q + (xcd < r ? 1 : 0)) return;             // padding of a problem whose tile count is not a multiple of 8
     conv3x3_halo_tile<EPI>(a, (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + li, smem);
+}
+
+// the same grouped launch on 256 x 128 tiles (8 waves, one workgroup per CU): tiles_m of every problem counts 256-row tiles
+__global__ __launch_bounds__(512) void conv3x3_halo256_group_kernel(ConvGroup g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int p = (idx >= g.start8[1] ? 1 : 0) + (idx >= g.start8[2] ? 1 : 0);
+    const int li = idx - g.start8[p];
+    const ConvArgs& a = g.a[p];
+    const int nwg = a.tiles_m * a.tiles_n;
+    const int q = nwg >> 3, r = nwg & 7;
+    if (li >= q + (xcd < r ? 1 : 0)) return;
+    conv3x3_halo_tile<1, 256>(a, (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + li, smem);
 }
 
 // =================================================================================================
@@ -2018,6 +2040,7 @@ void conv_set_attrs() {
                              (const void*)&conv_fwd_dma_kernel<64, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<64, 128, 2, true>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 2, false, 1>, (const void*)&conv_fwd_dma_kernel<128, 128, 2, true, 1>,
                              (const void*)&conv3x3_halo_kernel<0>, (const void*)&conv3x3_halo_kernel<1>, (const void*)&conv3x3_halo_group_kernel<1>,
+                             (const void*)&conv3x3_halo256_group_kernel,
                              (const void*)&conv_fwd_dma_kernel<256, 256, 2, true>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 4, true>,
                              (const void*)&conv_fwd_dma32_kernel<128, true, 0, 3>, (const void*)&conv5x5s2_halo_kernel<false>,
@@ -2349,6 +2372,27 @@ int oess_convlstm_fused_group_bf16(const oess_convlstm_desc_t* d, int n, oess_st
         }
     }
     g.start8[3] = at;
+    static const int use256 = [] { const char* e = getenv("OESS_LSTM256"); return e ? atoi(e) : 0; }();      // EXPERIMENT knob (round 5)
+    bool ok256 = use256 != 0;
+    for (int i = 0; i < n && ok256; ++i) {
+        const ConvArgs& a = g.a[i];
+        ok256 = a.R == 3 && a.dil == 1 && (a.dil + 255 + a.dil * ((256 + a.W - 2) / a.W) + a.dil + 1) <= HALO_ROWS_256 && a.tiles_n * 128 == a.Cout;
+    }
+    if (ok256) {
+        at = 0;
+        for (int i = 0; i < 3; ++i) {
+            g.start8[i] = at;
+            if (i < n) {
+                g.a[i].tiles_m = (g.a[i].M + 255) / 256;
+                at += (g.a[i].tiles_m * g.a[i].tiles_n + 7) / 8;
+            }
+        }
+        g.start8[3] = at;
+        const size_t lds256 = (size_t)2 * HALO_ROWS_256 * 128 + (size_t)2 * 128 * 128;
+        hipLaunchKernelGGL(conv3x3_halo256_group_kernel, dim3(8 * at), dim3(512), lds256, (hipStream_t)stream, g);
+        OESS_HIP(hipGetLastError());
+        return OESS_OK;
+    }
     const size_t lds = (size_t)2 * HALO_ROWS * 128 + (size_t)2 * 128 * 128;
     hipLaunchKernelGGL((conv3x3_halo_group_kernel<1>), dim3(8 * at), dim3(CONV_THREADS), lds, (hipStream_t)stream, g);
     OESS_HIP(hipGetLastError());

@@ -22,12 +22,12 @@ subprocess.run([sys.executable, "tools/mfma_util.py", os.path.join(src, "pmc_mfm
 with open(os.path.join(dst, f"{R}_misc_outputs.txt"), "w") as f:
     for name in ("pytest_gpu.txt", "pytest_gpu_run2.txt", "smoke.txt", "bench_schedule_ab.txt", "bench_no_skew.txt", "aten_probe_frame2recon_full.txt", "bench_torchrun_world1.txt", "train_loop.txt", "png.txt", "deeplab_breakdown.txt",
                  "segmean.txt", "voxelizer_pmc.txt", "stage_deeplab_fwd.txt", "stage_maskclip_fwd.txt", "stage_teacher_fwd.txt",
-                 "vox_raw1.txt", "vox_raw0.txt", "enc_s2.txt", "probe_1x1.txt", "gap_probe.txt", "insitu_probe.txt", "step_sequence.txt"):
+                 "vox_raw1.txt", "vox_raw0.txt", "step_sequence.txt"):
         p = os.path.join(src, name)
         if os.path.exists(p):
             body = [l for l in open(p, errors="replace").read().split("\n") if l.strip() and "amdgpu.ids" not in l and not l.startswith("+")]
             f.write(f"==== {name}\n" + "\n".join(body[-40:]) + "\n")
-for name, out in (("quant_probe.txt", f"{R}_quant_probe.txt"), ("seq_last_step.txt", f"{R}_step_sequence_last_step.txt")):
+for name, out in (("seq_last_step.txt", f"{R}_step_sequence_last_step.txt"),):
     p = os.path.join(src, name)
     if os.path.exists(p):
         body = [l for l in open(p, errors="replace").read().split("\n") if l.strip() and "amdgpu.ids" not in l]
