@@ -2372,24 +2372,41 @@ int oess_convlstm_fused_group_bf16(const oess_convlstm_desc_t* d, int n, oess_st
         }
     }
     g.start8[3] = at;
-    static const int use256 = [] { const char* e = getenv("OESS_LSTM256"); return e ? atoi(e) : 0; }();      // EXPERIMENT knob (round 5)
-    bool ok256 = use256 != 0;
-    for (int i = 0; i < n && ok256; ++i) {
-        const ConvArgs& a = g.a[i];
-        ok256 = a.R == 3 && a.dil == 1 && (a.dil + 255 + a.dil * ((256 + a.W - 2) / a.W) + a.dil + 1) <= HALO_ROWS_256 && a.tiles_n * 128 == a.Cout;
-    }
-    if (ok256) {
-        at = 0;
-        for (int i = 0; i < 3; ++i) {
-            g.start8[i] = at;
-            if (i < n) {
-                g.a[i].tiles_m = (g.a[i].M + 255) / 256;
-                at += (g.a[i].tiles_m * g.a[i].tiles_n + 7) / 8;
-            }
+    // EXPERIMENT knob (round 5): OESS_LSTM256 = 1: every problem on 256 x 128 tiles; 2: only the long-K problems (>= 30 slabs: the
+    // epilogue is a small share of their tiles), the others stay on the 128 x 128 tiles in a second launch
+    static const int use256 = [] { const char* e = getenv("OESS_LSTM256"); return e ? atoi(e) : 0; }();
+    if (use256) {
+        ConvGroup big, small;
+        memset(&big, 0, sizeof(big)); memset(&small, 0, sizeof(small));
+        int nb = 0, ns = 0;
+        for (int i = 0; i < n; ++i) {
+            const ConvArgs& a = g.a[i];
+            const bool fits = a.R == 3 && a.dil == 1 && (a.dil + 255 + a.dil * ((256 + a.W - 2) / a.W) + a.dil + 1) <= HALO_ROWS_256 &&
+                              a.tiles_n * 128 == a.Cout;
+            if (fits && (use256 == 1 || a.Kpad / BK >= 30)) big.a[nb++] = a; else small.a[ns++] = a;
         }
-        g.start8[3] = at;
-        const size_t lds256 = (size_t)2 * HALO_ROWS_256 * 128 + (size_t)2 * 128 * 128;
-        hipLaunchKernelGGL(conv3x3_halo256_group_kernel, dim3(8 * at), dim3(512), lds256, (hipStream_t)stream, g);
+        auto layout = [](ConvGroup& q, int cnt, int rows) {
+            int at_ = 0;
+            for (int i = 0; i < 3; ++i) {
+                q.start8[i] = at_;
+                if (i < cnt) {
+                    q.a[i].tiles_m = (q.a[i].M + rows - 1) / rows;
+                    at_ += (q.a[i].tiles_m * q.a[i].tiles_n + 7) / 8;
+                }
+            }
+            q.start8[3] = at_;
+            return at_;
+        };
+        if (nb) {
+            const int atb = layout(big, nb, 256);
+            const size_t lds256 = (size_t)2 * HALO_ROWS_256 * 128 + (size_t)2 * 128 * 128;
+            hipLaunchKernelGGL(conv3x3_halo256_group_kernel, dim3(8 * atb), dim3(512), lds256, (hipStream_t)stream, big);
+        }
+        if (ns) {
+            const int ats = layout(small, ns, 128);
+            const size_t lds128 = (size_t)2 * HALO_ROWS * 128 + (size_t)2 * 128 * 128;
+            hipLaunchKernelGGL((conv3x3_halo_group_kernel<1>), dim3(8 * ats), dim3(CONV_THREADS), lds128, (hipStream_t)stream, small);
+        }
         OESS_HIP(hipGetLastError());
         return OESS_OK;
     }
