@@ -224,8 +224,20 @@ class BaseTrainer(object):
             n_train = getattr(s, 'synthetic_length', 2 * s.batch_size_b * self.world)
             train_ds = builder(length=n_train, mode='train', pool=getattr(s, 'synthetic_pool', 0), **common)
             val_ds = builder(length=max(s.batch_size_b, 2), mode='val', **common)
+        elif s.dataset_name_b == 'DSEC_events':
+            train_ds, val_ds = self.createDSECDataset(
+                s.dataset_name_b, s.dataset_path_b, s.batch_size_b, s.nr_events_data_b, s.delta_t_per_data_b, s.nr_events_window_b,
+                s.data_augmentation_train, s.event_representation_b, s.nr_temporal_bins_b, s.require_paired_data_train_b,
+                s.require_paired_data_val_b, s.separate_pol_b, s.normalize_event_b, s.semseg_num_classes, s.fixed_duration_b,
+                s.config_option, getattr(s, 'pl_sources', ''), getattr(s, 'superpixel_sources', ''), s.skip_ratio,
+                getattr(s, 'if_sam_distillation', False))
         else:
-            train_ds, val_ds = builder.build_from_settings(s)
+            train_ds, val_ds = self.createDDD17EventsDataset(
+                s.dataset_name_b, s.dataset_path_b, s.split_train_b, s.batch_size_b, s.nr_events_data_b, s.delta_t_per_data_b,
+                s.nr_events_window_b, s.data_augmentation_train, s.event_representation_b, s.nr_temporal_bins_b,
+                s.require_paired_data_train_b, s.require_paired_data_val_b, s.separate_pol_b, s.normalize_event_b, s.fixed_duration_b,
+                s.config_option, getattr(s, 'pl_sources', ''), getattr(s, 'superpixel_sources', ''), s.skip_ratio,
+                getattr(s, 'if_sam_distillation', False))
         self.sensor_geometry = (train_ds.sensor_hw, train_ds.crop_rows) if hasattr(train_ds, 'sensor_hw') else None
         self.rectify_maps = torch.from_numpy(train_ds.rectify_map[None]).to(self.device) if hasattr(train_ds, 'rectify_map') else None
         self._voxel_ds = {'train': train_ds, 'val': val_ds}            # un-wrapped datasets: Subset has no voxelize_batch
@@ -242,6 +254,38 @@ class BaseTrainer(object):
                                                     pin_memory=True, shuffle=True, drop_last=True, collate_fn=collate)
         self.val_loader_sensor_b = DataLoader(val_ds, batch_size=s.batch_size_b, num_workers=s.num_cpu_workers,
                                               pin_memory=True, shuffle=False, drop_last=False, collate_fn=collate)
+
+    # The reference's two dataset factories (base_trainer_ov.py:93-183, 187-276) with their positional signatures.  They return the
+    # (train, validation) DATASETS; createDataLoaders wraps them (ring loader / DataLoader, sharding), where the reference builds its
+    # two torch DataLoaders inside the factory.
+    def createDSECDataset(self, dataset_name, dsec_dir, batch_size, nr_events_data, delta_t_per_data, nr_events_window, augmentation,
+                          event_representation, nr_bins_per_data, require_paired_data_train, require_paired_data_val, separate_pol,
+                          normalize_event, semseg_num_classes, fixed_duration, config_option, pl_sources, superpixel_sources,
+                          skip_ratio, if_sam_distillation):
+        builder = self.getDataloader(dataset_name)
+        kw = dict(dsec_dir=dsec_dir, nr_events_data=nr_events_data, delta_t_per_data=delta_t_per_data, nr_events_window=nr_events_window,
+                  event_representation=event_representation, nr_bins_per_data=nr_bins_per_data, separate_pol=separate_pol,
+                  normalize_event=normalize_event, semseg_num_classes=semseg_num_classes, fixed_duration=fixed_duration,
+                  config_option=config_option, pl_sources=pl_sources, device_png=getattr(self.settings, 'device_png_decode', False))
+        train = builder(augmentation=augmentation, mode='train', require_paired_data=require_paired_data_train,
+                        superpixel_sources=superpixel_sources, skip_ratio=skip_ratio, if_sam_distillation=if_sam_distillation, **kw)
+        val = builder(augmentation=False, mode='val', require_paired_data=require_paired_data_val, superpixel_sources='', skip_ratio=2,
+                      if_sam_distillation=False, **kw)                                              # :137-157: never augmented, every 2nd sample
+        return train, val
+
+    def createDDD17EventsDataset(self, dataset_name, root, split_train, batch_size, nr_events_data, delta_t_per_data, nr_events_per_data,
+                                 augmentation, event_representation, nr_bins_per_data, require_paired_data_train,
+                                 require_paired_data_val, separate_pol, normalize_event, fixed_duration, config_option, pl_sources,
+                                 superpixel_sources, skip_ratio, if_sam_distillation):
+        builder = self.getDataloader(dataset_name)
+        kw = dict(event_representation=event_representation, nr_events_data=nr_events_data, delta_t_per_data=delta_t_per_data,
+                  nr_bins_per_data=nr_bins_per_data, separate_pol=separate_pol, normalize_event=normalize_event,
+                  fixed_duration=fixed_duration, nr_events_per_data=nr_events_per_data, config_option=config_option,
+                  pl_sources=pl_sources, superpixel_sources=superpixel_sources, skip_ratio=skip_ratio,
+                  if_sam_distillation=if_sam_distillation)
+        train = builder(root, split=split_train, augmentation=augmentation, require_paired_data=require_paired_data_train, **kw)
+        val = builder(root, split='valid', augmentation=False, require_paired_data=require_paired_data_val, **kw)    # :232-250
+        return train, val
 
     def prepare_batch(self, sample_batched, split='train'):
         """Host batch -> device batch.  A raw-event dict becomes the B x (nr_events_data*C) x H x W voxel tensor

@@ -210,3 +210,47 @@ def test_ingest_prefetch_equals_in_order_loop(tmp_path):
         finals.append({k + "." + n: p.detach().clone() for k, m in trainer.models_dict.items() for n, p in m.named_parameters()
                        if p.requires_grad})
     assert any(not torch.equal(v, finals[1][k]) for k, v in finals[0].items()) is False
+
+
+def test_trainer_dataset_factories_equal_the_loaders_own_mapping(tmp_path):
+    """BaseTrainer.createDSECDataset / createDDD17EventsDataset (base_trainer_ov.py:93-183, 187-276 of the reference, positional
+    signatures) must build the same (train, validation) datasets as the loaders' settings mapping: same samples, same flags."""
+    from types import SimpleNamespace
+    from openess_amd.datasets.DSEC_events_loader import DSECEvents
+    from openess_amd.datasets.ddd17_events_loader import DDD17Events
+    from openess_amd.training.base_trainer_ov import BaseTrainer
+    from tests import synth_datasets as sd
+    t = BaseTrainer.__new__(BaseTrainer)
+    dsec = sd.make_dsec_tree(str(tmp_path / "dsec"))
+    s = SimpleNamespace(dataset_name_b='DSEC_events', dataset_path_b=dsec, batch_size_b=2, nr_events_data_b=3, delta_t_per_data_b=50,
+                        nr_events_window_b=200, data_augmentation_train=True, event_representation_b='voxel_grid', nr_temporal_bins_b=5,
+                        require_paired_data_train_b=False, require_paired_data_val_b=True, separate_pol_b=False, normalize_event_b=False,
+                        semseg_num_classes=11, fixed_duration_b=False, config_option='frame2voxel', pl_sources='pl_fcclip_rgb',
+                        superpixel_sources='sp_sam_rgb', skip_ratio=1, if_sam_distillation=False, device_png_decode=False)
+    t.settings = s
+    tr, va = t.createDSECDataset(s.dataset_name_b, s.dataset_path_b, s.batch_size_b, s.nr_events_data_b, s.delta_t_per_data_b,
+                                 s.nr_events_window_b, s.data_augmentation_train, s.event_representation_b, s.nr_temporal_bins_b,
+                                 s.require_paired_data_train_b, s.require_paired_data_val_b, s.separate_pol_b, s.normalize_event_b,
+                                 s.semseg_num_classes, s.fixed_duration_b, s.config_option, s.pl_sources, s.superpixel_sources,
+                                 s.skip_ratio, s.if_sam_distillation)
+    tr2, va2 = DSECEvents.build_from_settings(s)
+    assert len(tr) == len(tr2) > 0 and len(va) == len(va2) > 0
+    assert getattr(va, 'require_paired_data', None) == getattr(va2, 'require_paired_data', None)
+    a, b = va[0], va2[0]
+    assert len(a) == len(b) and a[-1] == b[-1] and torch.equal(a[1], b[1])
+    ddd = sd.make_ddd17_tree(str(tmp_path / "ddd17"))
+    s2 = SimpleNamespace(dataset_name_b='DDD17_events', dataset_path_b=ddd, split_train_b='train', batch_size_b=2, nr_events_data_b=4,
+                         delta_t_per_data_b=50, nr_events_window_b=500, data_augmentation_train=False, event_representation_b='voxel_grid',
+                         nr_temporal_bins_b=5, require_paired_data_train_b=False, require_paired_data_val_b=True, separate_pol_b=False,
+                         normalize_event_b=False, fixed_duration_b=False, config_option='frame2voxel', pl_sources='pl_fcclip_rgb',
+                         superpixel_sources='sp_sam_rgb', skip_ratio=1, if_sam_distillation=False)
+    t.settings = s2
+    tr, va = t.createDDD17EventsDataset(s2.dataset_name_b, s2.dataset_path_b, s2.split_train_b, s2.batch_size_b, s2.nr_events_data_b,
+                                        s2.delta_t_per_data_b, s2.nr_events_window_b, s2.data_augmentation_train,
+                                        s2.event_representation_b, s2.nr_temporal_bins_b, s2.require_paired_data_train_b,
+                                        s2.require_paired_data_val_b, s2.separate_pol_b, s2.normalize_event_b, s2.fixed_duration_b,
+                                        s2.config_option, s2.pl_sources, s2.superpixel_sources, s2.skip_ratio, s2.if_sam_distillation)
+    tr2, va2 = DDD17Events.build_from_settings(s2)
+    assert len(tr) == len(tr2) > 0 and len(va) == len(va2) > 0
+    a, b = tr[1], tr2[1]
+    assert len(a) == len(b) and torch.equal(a[1], b[1]) and torch.equal(a[0]['events'], b[0]['events'])
