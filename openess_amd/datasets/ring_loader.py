@@ -133,9 +133,14 @@ class PinnedRingLoader:
         if pin:
             # page-lock the ring so that the trainer's copies from it are asynchronous DMA (hipHostRegister)
             rc = torch.cuda.cudart().cudaHostRegister(self.ring.data_ptr(), self.ring.numel(), 0)
-            if int(rc) != 0:
-                raise RuntimeError(f"hipHostRegister of the {self.ring.numel() >> 20} MB loader ring failed ({rc})")
-            self.pinned = True
+            if int(rc) == 0:
+                self.pinned = True
+            else:
+                # e.g. a memlock limit below the ring size: the loader still saves two of the three host copies, but the trainer's
+                # host->device copies are then staged by the runtime (synchronous for large tensors) -- say so, do not die
+                import warnings
+                warnings.warn(f"PinnedRingLoader: hipHostRegister of the {self.ring.numel() >> 20} MB ring failed ({rc}); continuing with "
+                              "a pageable ring (raise `ulimit -l` for asynchronous copies)")
         ctx = mp.get_context('fork')
         self._tasks, self._done = ctx.Queue(), ctx.Queue()
         base_seed = int(torch.empty((), dtype=torch.int64).random_().item())
