@@ -847,7 +847,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a) {
 constexpr int HALO_ROWS = 160;
 
 // one 128 x 128 tile (`bid` = tile index after the XCD remap); smem = [halo 0][halo 1][weights 0][weights 1]
-// BMX = 256 (EPI = 1 only; EXPERIMENT of round 5): an 8-wave workgroup owns 256 pixels x 128 gate columns -- the weight slab is
+// BMX = 256 (EPI = 1 only; round 5): an 8-wave workgroup owns 256 pixels x 128 gate columns -- the weight slab is
 // fetched once per 256 pixels (150 instead of 92 FLOP per L2 -> LDS byte, 3.7 instead of 5.7 DMA instructions per wave and slab),
 // one workgroup per CU (2 x 40 KB halo + 2 x 16 KB weights), the wave tile stays 64 x 64.
 constexpr int HALO_ROWS_256 = 320;
@@ -2234,6 +2234,9 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
     //      Same template as rule (6).  Measured against the 128 x 128 tiling on the teacher's layers at M = 140 800:
     //      512->2048 556 -> 451 us, 1024->2048 831 -> 680, 2048->512 396 -> 362, 256->1024 179 -> 169; ViT fc1 (M = 8 968,
     //      432 tiles) 65.8 -> 62.5.  Below ~1.5 rounds of 256 tiles the coarser quantisation loses (324 tiles: 51.7 -> 59.5 us).
+    //      (Round 5: under the concurrent step schedule these 128 KB / 512-thread workgroups wait for a CU free of ConvLSTM
+    //      workgroups and run 2.2 x longer than alone; the 128 x 128 tiling, which co-resides, was measured there as well:
+    //      193.0 vs 194.8 event-frames/s, 318 vs 324 on frame2recon_full -- the big tile stays.)
     if (!lstm && bn == 128 && fastk && (Cout % 256) == 0 && a.Kpad >= 256 && R == 1 && S == 1 && stride == 1) {
         const long long t256 = (long long)((a.M + 255) / 256) * (Cout / 256);
         if (t256 >= 400) {
@@ -2372,9 +2375,12 @@ int oess_convlstm_fused_group_bf16(const oess_convlstm_desc_t* d, int n, oess_st
         }
     }
     g.start8[3] = at;
-    // EXPERIMENT knob (round 5): OESS_LSTM256 = 1: every problem on 256 x 128 tiles; 2: only the long-K problems (>= 30 slabs: the
-    // epilogue is a small share of their tiles), the others stay on the 128 x 128 tiles in a second launch
-    static const int use256 = [] { const char* e = getenv("OESS_LSTM256"); return e ? atoi(e) : 0; }();
+    // 256 x 128 tiles on ONE 8-wave workgroup per CU (default since round 5).  Alone the grouped launch is 2-3 % slower on them
+    // than on two 128 x 128 workgroups per CU (one workgroup per CU exposes the cell-update epilogue; fewer operand bytes per FLOP
+    // buy nothing), but the product schedule runs it next to the teacher's and the decoder's kernels, and one 112 KB workgroup
+    // leaves them 48 KB of LDS and 24 wave slots per CU where two 72 KB workgroups leave 16 KB: +1.4-1.6 % on the step on three
+    // boxes (EXPERIMENTS R5-3b).  OESS_LSTM256 = 0 restores the 128 x 128 tiles (A/B), 2 = only the problems with >= 30 K-slabs.
+    static const int use256 = [] { const char* e = getenv("OESS_LSTM256"); return e ? atoi(e) : 1; }();
     if (use256) {
         ConvGroup big, small;
         memset(&big, 0, sizeof(big)); memset(&small, 0, sizeof(small));
