@@ -52,7 +52,9 @@ PEAK_HBM_GBS = 8000.0           # MI355X HBM3E (MI355X_MICROARCH.md)
 # algorithmic work per batch of 8 (SURVEY 8d / BASELINE.md section 4)
 VOX_BYTES = 16 * B * NWIN * N_PER + 4 * B * NWIN * C * H_SENSOR * W_SENSOR           # 1.239 GB
 GFLOP_FWD = {"deeplabv3_resnet50": 106.8 * B, "dilated_r50_teacher": 845.1 * B}
-DOMINANT = re.compile(r"conv3x3_halo_kernel<[01]>|conv_fwd_dma_kernel<(128|64), 128, 2, (true|false), [01](, 256)?>|conv_fwd_dma_kernel<256, 256, 2, true, 0(, 512)?>|conv_fwd_dma32_kernel<128, true, 0, 3")
+DOMINANT = re.compile(r"conv3x3_halo_kernel<[01]>|conv3x3_halo_group_kernel<1>|conv3x3_halo256_group_kernel|conv5x5s2_halo(_group)?_kernel|"
+                      r"conv_fwd_dma_kernel<(128|64), 128, [24], (true|false), [01](, 256)?>|conv_fwd_dma_kernel<256, 256, 2, true, 0(, 512)?>|"
+                      r"conv_fwd_dma32_kernel<128, true, 0, 3")
 
 
 def make_events(rank, structured=False):
@@ -547,7 +549,8 @@ def main():
         if not grp:
             return None
         gn, gms, gfl = (sum(g[i] for g in grp) for i in range(3))
-        return {"name": "conv3x3_halo_group_kernel<1>", "launches_per_step": round(gn / steps, 2),
+        return {"name": "conv3x3_halo256_group_kernel (grouped fused-ConvLSTM launch, 256 x 128 tiles; OESS_LSTM256=0: conv3x3_halo_group_kernel<1>)",
+                "launches_per_step": round(gn / steps, 2),
                 "sum_gflop": round(gfl / steps / 1e9, 1), "sum_us": round(gms / steps * 1e3, 1),
                 "achieved": round(gfl / (gms * 1e-3) / 1e12, 1), "unit": "TFLOP/s",
                 "frac": round(gfl / (gms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "share_of_step_time": round(gms / (dt_ * 1e3), 3)}
@@ -557,7 +560,7 @@ def main():
         roof = None
         if conv_stats and conv_stats["ms"] > 0:
             ach = conv_stats["flops"] / (conv_stats["ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "conv3x3_halo_group_kernel<1> (the three fused-ConvLSTM levels of a stage of the recurrent encoder in one launch) + conv3x3_halo_kernel<{0|1}> (3x3 stride-1, row-halo reuse) + conv_fwd_dma_kernel<{128|64},128,2> + conv_fwd_dma_kernel<256,256,2> (large 1x1 layers) + short-K conv_fwd_dma32_kernel<128,..,3> + conv5x5s2_halo{,_group}_kernel (5x5 stride-2 encoders, 2-D input halo; levels 1 + 2 in one launch): implicit-GEMM bf16 MFMA with LDS-DMA operands, every forward / data-gradient launch with Cout > 64; conv FLOPs only",
+            roof = {"bound": "mfma", "kernel": "conv3x3_halo256_group_kernel (the three fused-ConvLSTM levels of a stage of the recurrent encoder in one launch) + conv3x3_halo_kernel<{0|1}> (3x3 stride-1, row-halo reuse) + conv_fwd_dma_kernel<{128|64},128,2> + conv_fwd_dma_kernel<256,256,2> (large 1x1 layers) + short-K conv_fwd_dma32_kernel<128,..,3> + conv5x5s2_halo{,_group}_kernel (5x5 stride-2 encoders, 2-D input halo; levels 1 + 2 in one launch): implicit-GEMM bf16 MFMA with LDS-DMA operands, every forward / data-gradient launch with Cout > 64; conv FLOPs only",
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                     "launches_per_step": conv_stats["launches"] // a.steps,
