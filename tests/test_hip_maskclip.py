@@ -97,17 +97,3 @@ def test_online_teacher_labels_in_the_step():
         losses.append(float(ls['dense_clip_loss']))
     assert losses[0] == pytest.approx(losses[1], rel=2e-5)
 
-
-def test_maskclip_tower_two_half_batches_on_two_streams_equal_one_stream():
-    """The tower couples no samples of a batch, so the forward of two half batches on two HIP streams (the default from the second
-    call on) must equal the one-stream forward bit for bit."""
-    o, m = _pair((32, 32))
-    torch.manual_seed(9)
-    img = torch.rand(4, 3, 48, 80).cuda()
-    with torch.no_grad():
-        first = m(img)                         # first call: one stream (builds the packed operands)
-        assert m._packed_once
-        two = m(img)
-        m.two_streams = False
-        one = m(img)
-    assert torch.equal(first, one) and torch.equal(two, one)
