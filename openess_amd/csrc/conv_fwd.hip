@@ -2042,7 +2042,7 @@ void conv_set_attrs() {
                              (const void*)&conv3x3_halo_kernel<0>, (const void*)&conv3x3_halo_kernel<1>, (const void*)&conv3x3_halo_group_kernel<1>,
                              (const void*)&conv3x3_halo256_group_kernel,
                              (const void*)&conv_fwd_dma_kernel<256, 256, 2, true>,
-                             (const void*)&conv_fwd_dma_kernel<128, 128, 4, true>,
+                             (const void*)&conv_fwd_dma_kernel<128, 128, 4, true, 0, 512>,
                              (const void*)&conv_fwd_dma32_kernel<128, true, 0, 3>, (const void*)&conv5x5s2_halo_kernel<false>,
                              (const void*)&conv5x5s2_halo_kernel<true>, (const void*)&conv5x5s2_halo_group_kernel};
         for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2163,14 +2163,16 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
     //      flight).  Measured on the DeepLabv3 forward (round 5, same box, ring 2 / 3 / 4): 1024->256 36.1 / 31.6 / 31.4 us,
     //      2048->256 42.1 / 36.2 / 35.4, 1280->256 30.6-43.8 / 26.3 / 26.7, 256->1024 25.1 / 21.1 / 23.8; the 3x3 layers of the
     //      same maps do not move (45 / 64 / 73 us either way: they stay on the row-halo kernel) -- the small-map K loop is not
-    //      waiting for the operand round trip alone (profiles/r05_deep_ring_ab.txt).
+    //      waiting for the operand round trip alone (profiles/r05_deep_ring_ab.txt).  EIGHT waves (32 x 64 wave tiles, two waves
+    //      per SIMD: one wave's DMA issue runs under the other's MFMAs, which a lone 4-wave workgroup cannot do): 1024->256
+    //      32.3 -> 29.4 us, 2048->256 36.0 -> 30.1, 1280->256 28.7 -> 23.1, 256->1024 22.5 -> 20.4 (same box, alternating).
     {
         const bool is3x3halo = R == 3 && S == 3 && stride == 1 && pad == dil;
         if (!capture && !lstm && bn == 128 && fastk && t128 <= 256 && a.Kpad / BK >= 16 && a.Kpad / BK < 200 && !is3x3halo) {
             if (want_workspace) return OESS_OK;
             size_t lds = (size_t)4 * (BM + 128) * 8 * 16;
             if (lds < epi) lds = epi;
-            hipLaunchKernelGGL((conv_fwd_dma_kernel<128, 128, 4, true>), grid, block, lds, st, a);
+            hipLaunchKernelGGL((conv_fwd_dma_kernel<128, 128, 4, true, 0, 512>), grid, dim3(512), lds, st, a);
             OESS_HIP(hipGetLastError());
             return OESS_OK;
         }
