@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--raw", type=int, default=1)
     ap.add_argument("--B", type=int, default=8)
+    ap.add_argument("--chunks", type=int, default=1, help="split the batch into this many calls over sample groups (record workspace reused)")
     ap.add_argument("--h2d", type=int, default=0, help="1: time the pinned-host -> device copy of the raw columns with every batch")
     a = ap.parse_args()
     C, H, W, crop, nwin, n_per, B = 5, 480, 640, 40, 20, 100000, a.B
@@ -49,6 +50,12 @@ def main():
         if a.raw and a.h2d:
             dx, dy, dt, dp = (v.to("cuda", non_blocking=True) for v in (hx, hy, ht, hp))
             hip.voxelize_dsec_raw(dx, dy, dt, dp, maps, seg_map, so, C, H, W, crop_rows=crop, out=out)
+        elif a.raw and a.chunks > 1:
+            per = B * nwin // a.chunks
+            for c in range(a.chunks):
+                e0_, e1_ = int(so[c * per]), int(so[(c + 1) * per])
+                hip.voxelize_dsec_raw(x[e0_:e1_], y[e0_:e1_], t[e0_:e1_], p[e0_:e1_], maps, seg_map[c * per:(c + 1) * per],
+                                      so[c * per:(c + 1) * per + 1] - so[c * per], C, H, W, crop_rows=crop, out=out[c * per * C:(c + 1) * per * C])
         elif a.raw:
             hip.voxelize_dsec_raw(x, y, t, p, maps, seg_map, so, C, H, W, crop_rows=crop, out=out)
         else:
@@ -65,7 +72,7 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
     alg = B * (16 * nwin * n_per + 4 * nwin * C * H * W)
-    print(f"voxelize B={B} raw={a.raw} h2d={a.h2d}: {ms:.3f} ms/batch  algorithmic {alg / 1e9:.3f} GB -> {alg / ms / 1e6:.1f} GB/s "
+    print(f"voxelize B={B} raw={a.raw} h2d={a.h2d} chunks={a.chunks}: {ms:.3f} ms/batch  algorithmic {alg / 1e9:.3f} GB -> {alg / ms / 1e6:.1f} GB/s "
           f"({alg / ms / 1e6 / 8000 * 100:.1f}% of 8 TB/s)  {B / ms * 1000:.0f} event-frames/s")
 
 
