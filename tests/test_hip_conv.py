@@ -365,6 +365,7 @@ def test_convlstm_fused_step_matches_torch(B, H, W, Cx, C):
     [(2, 24, 40, 128), (2, 12, 20, 256)],                        # two problems (the drain stage of the skewed schedule)
     [(1, 13, 11, 64), (1, 7, 9, 64), (3, 5, 6, 128)],            # ragged last tiles, 3 + 1 + 2 tiles
     [(1, 9, 11, 64), (1, 13, 10, 32)],                           # the zero-state problem has Cin = 32: not the row-halo kernel's -> launched one by one
+    [(8, 220, 320, 64), (8, 110, 160, 128), (8, 55, 80, 256)],   # the BASELINE size (B = 8, 440 x 640 crop): 256-row grouped tiles == 128-row launches, bit for bit
 ])
 def test_convlstm_fused_group_equals_separate_launches(geoms):
     """oess_convlstm_fused_group_bf16: n independent ConvLSTM steps in one launch give bit-identical hidden and cell states to n

@@ -107,6 +107,35 @@ def test_e2vid_recurrent_latents(g, keys):
     assert lat[True][2] == lat[False][2]
 
 
+@pytest.mark.gpu
+def test_e2vid_recurrent_baseline_size_skew_equals_plain():
+    """BASELINE size (B = 8, 440 x 640, 5 bins per sub-window): the skewed schedule -- grouped 256 x 128-tile ConvLSTM launches,
+    grouped stride-2 encoder convs, head + encoder 0 as one kernel -- ends in the same bits as the plain order, which launches
+    every level's 128 x 128-tile kernels one by one.  A size-independent property: the CPU oracle cannot run this size."""
+    from openess_amd.e2vid.image_reconstructor import ImageReconstructor
+    from openess_amd.e2vid.model.model import E2VIDRecurrent
+    m = E2VIDRecurrent(E2VID_LIGHTWEIGHT_CONFIG).eval()
+    fill_by_name(m, 11)
+    m.cuda()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    nwin = 5
+    ev = torch.randn((8, 5 * nwin, 440, 640), device="cuda", generator=gen) * (torch.rand((8, 5 * nwin, 440, 640), device="cuda", generator=gen) < 0.3)
+    out = {}
+    for skew in (False, True):
+        r = ImageReconstructor(m, 440, 640, 5, torch.device("cuda"))
+        r.skew = skew
+        for i in range(nwin):
+            _, states, lat = r.update_reconstruction(ev, channel_slice=(5 * i, 5), need_latents=(i == nwin - 1))
+        out[skew] = ({k: v.clone() for k, v in lat.items() if v is not None}, [s_['cell'].clone() for s_ in states])
+        del r
+    assert set(out[True][0]) == set(out[False][0])
+    for k in out[True][0]:
+        assert torch.equal(out[True][0][k], out[False][0][k]), k
+        assert bool(torch.isfinite(out[True][0][k].float()).all())
+    for a_, b_ in zip(out[True][1], out[False][1]):
+        assert torch.equal(a_, b_)
+
+
 @pytest.fixture(scope="module")
 def gpre():
     return dict(np.load(os.path.join(GOLDEN, "e2vid_pre.npz")))
