@@ -2235,7 +2235,7 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
     //      CU, wave tile 64 x 128 (24 fragment reads per 32 MFMAs instead of 16 per 16, half the L2 -> LDS bytes per FLOP).
     //      Same template as rule (6).  Measured against the 128 x 128 tiling on the teacher's layers at M = 140 800:
     //      512->2048 556 -> 451 us, 1024->2048 831 -> 680, 2048->512 396 -> 362, 256->1024 179 -> 169; ViT fc1 (M = 8 968,
-    //      432 tiles) 65.8 -> 62.5.  Below ~1.5 rounds of 256 tiles the coarser quantisation loses (324 tiles: 51.7 -> 59.5 us).
+    //      432 tiles) 65.8 -> 62.5 without its GELU epilogue (with it, round 5: 88 us on either tiling).  Below ~1.5 rounds of 256 tiles the coarser quantisation loses (324 tiles: 51.7 -> 59.5 us).
     //      (Round 5: under the concurrent step schedule these 128 KB / 512-thread workgroups wait for a CU free of ConvLSTM
     //      workgroups and run 2.2 x longer than alone; the 128 x 128 tiling, which co-resides, was measured there as well:
     //      193.0 vs 194.8 event-frames/s, 318 vs 324 on frame2recon_full -- the big tile stays.)
