@@ -1127,6 +1127,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo256_group_kernel(ConvGroup g)
     conv3x3_halo_tile<1, 256>(a, (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + li, smem);
 }
 
+#include "conv_lstm_w128.h"
+
 // =================================================================================================
 // 5x5 / stride-2 / pad-2 convolutions with a 2-D INPUT HALO in LDS (conv5x5s2_halo_kernel): E2VID's three encoder
 // ConvLayers (e2vid/model/unet.py: 32->64 @440x640, 64->128 @220x320, 128->256 @110x160, 20 launches each per step).
@@ -2040,7 +2042,7 @@ void conv_set_attrs() {
                              (const void*)&conv_fwd_dma_kernel<64, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<64, 128, 2, true>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 2, false, 1>, (const void*)&conv_fwd_dma_kernel<128, 128, 2, true, 1>,
                              (const void*)&conv3x3_halo_kernel<0>, (const void*)&conv3x3_halo_kernel<1>, (const void*)&conv3x3_halo_group_kernel<1>,
-                             (const void*)&conv3x3_halo256_group_kernel,
+                             (const void*)&conv3x3_halo256_group_kernel, (const void*)&conv3x3_lstm_w128_group_kernel,
                              (const void*)&conv_fwd_dma_kernel<256, 256, 2, true>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 4, true, 0, 512>,
                              (const void*)&conv_fwd_dma32_kernel<128, true, 0, 3>, (const void*)&conv5x5s2_halo_kernel<false>,
@@ -2382,16 +2384,18 @@ int oess_convlstm_fused_group_bf16(const oess_convlstm_desc_t* d, int n, oess_st
     // buy nothing), but the product schedule runs it next to the teacher's and the decoder's kernels, and one 112 KB workgroup
     // leaves them 48 KB of LDS and 24 wave slots per CU where two 72 KB workgroups leave 16 KB: +1.4-1.6 % on the step on three
     // boxes (EXPERIMENTS R5-3b).  OESS_LSTM256 = 0 restores the 128 x 128 tiles (A/B), 2 = only the problems with >= 30 K-slabs.
-    static const int use256 = [] { const char* e = getenv("OESS_LSTM256"); return e ? atoi(e) : 1; }();
+    const int use256 = [] { const char* e = getenv("OESS_LSTM256"); return e ? atoi(e) : 1; }();
     if (use256) {
-        ConvGroup big, small;
-        memset(&big, 0, sizeof(big)); memset(&small, 0, sizeof(small));
-        int nb = 0, ns = 0;
+        ConvGroup big, small, w128;
+        memset(&big, 0, sizeof(big)); memset(&small, 0, sizeof(small)); memset(&w128, 0, sizeof(w128));
+        int nb = 0, ns = 0, nw = 0;
         for (int i = 0; i < n; ++i) {
             const ConvArgs& a = g.a[i];
             const bool fits = a.R == 3 && a.dil == 1 && (a.dil + 255 + a.dil * ((256 + a.W - 2) / a.W) + a.dil + 1) <= HALO_ROWS_256 &&
                               a.tiles_n * 128 == a.Cout;
-            if (fits && (use256 == 1 || a.Kpad / BK >= 30)) big.a[nb++] = a; else small.a[ns++] = a;
+            // 128 x 128 wave tiles (conv_lstm_w128.h): 256-column tiles, an even number of (dy, 64-channel) macro steps
+            if (use256 == 3 && fits && a.Cout % 256 == 0 && a.Cin % 128 == 0) { w128.a[nw] = a; w128.a[nw].tiles_n = a.Cout / 256; ++nw; }
+            else if (fits && (use256 == 1 || use256 == 3 || a.Kpad / BK >= 30)) big.a[nb++] = a; else small.a[ns++] = a;
         }
         auto layout = [](ConvGroup& q, int cnt, int rows) {
             int at_ = 0;
@@ -2405,6 +2409,10 @@ int oess_convlstm_fused_group_bf16(const oess_convlstm_desc_t* d, int n, oess_st
             q.start8[3] = at_;
             return at_;
         };
+        if (nw) {
+            const int atw = layout(w128, nw, 256);
+            hipLaunchKernelGGL(conv3x3_lstm_w128_group_kernel, dim3(8 * atw), dim3(256), (size_t)W128_LDS, (hipStream_t)stream, w128);
+        }
         if (nb) {
             const int atb = layout(big, nb, 256);
             const size_t lds256 = (size_t)2 * HALO_ROWS_256 * 128 + (size_t)2 * 128 * 128;
