@@ -19,16 +19,117 @@
 // slab (j, dx = 0).  vmcnt is counted: 10 halo pieces stay in flight across the barrier of (j, 0).
 // LDS: [halo 0][halo 1] 2 x 40 KB, [weights 0][weights 1] 2 x 32 KB = 144 KB, one workgroup per CU.
 // Requires: 3 x 3, dil 1, stride 1, Cin % 128 == 0 (an even number of macro steps), Cout % 256 == 0, lds base 128-byte aligned.
+#ifndef W128_ABL
+#define W128_ABL 0     // debug ablations (tools/bench_lstm_group.py): 1 no epilogue, 2 no LDS-DMA in the K loop, 4 no barrier, 8 no fragment reads,
+                       // 16 no vmcnt waits, 32 no halo DMA, 64 no weight DMA, 128 no previous-cell loads, 256 no gate math, 512 no stores
+#endif
 constexpr int W128_HROWS = 320;
 constexpr int W128_HALO_BYTES = W128_HROWS * 128;         // 40 960
 constexpr int W128_WST_BYTES = 256 * 128;                 // 32 768
 constexpr int W128_LDS = 2 * W128_HALO_BYTES + 2 * W128_WST_BYTES;   // 147 456
 
+// halo piece issued in gap m of group G (0..2) of slab dx, or -1.  Default: all ten pieces in slab dx = 0 (4 / 3 / 3 over G0..G2, every
+// other gap from m = 8).  W128_ABL & 4096: spread over the three slabs (4 / 3 / 3 pieces; G0 gaps 8, 12 and G1 gap 8 (+ gap 12 on dx = 0)).
+constexpr bool W128_SPREAD = (W128_ABL & 4096) != 0;
+constexpr int w128_halo_piece_at(int dx, int G, int m) {
+    if (W128_SPREAD) {
+        const int base = dx == 0 ? 0 : (dx == 1 ? 4 : 7);
+        if (G == 0 && m == 8) return base;
+        if (G == 0 && m == 12) return base + 1;
+        if (G == 1 && m == 8) return base + 2;
+        if (G == 1 && m == 12 && dx == 0) return 3;
+        return -1;
+    }
+    if (dx != 0 || m < 8 || (m & 1)) return -1;
+    const int k = (m - 8) / 2;
+    if (G == 0) return k;
+    if (k >= 3) return -1;
+    return G == 1 ? 4 + k : 7 + k;
+}
+constexpr int w128_halo_vmcnt(int dx) { return W128_SPREAD ? (dx == 0 ? 4 : (dx == 1 ? 3 : 0)) : (dx == 0 ? 10 : 0); }
+
 template <typename F, int... Is>
 __device__ __forceinline__ void w128_for(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 #define W128_FOR(N, VAR, ...) w128_for([&](auto VAR) __attribute__((always_inline)) __VA_ARGS__, std::make_integer_sequence<int, N>{})
 
+// Cell update of a 256-pixel x 64-hidden-channel tile straight from the accumulators (layout: lstm_epilogue of conv_fwd.hip, four
+// waves as 2 x 2, 64 cells per lane).  smem: fp32 cell image [256][65] + bf16 hidden image [256][66].
+__device__ __forceinline__ void w128_lstm_epilogue(const ConvArgs& a, f32x16_t (&acc)[4][4], unsigned char* smem, int m0, int n0,
+                                                   int wm, int wn, int lane, int tid) {
+    constexpr int MT = 4, NT = 4, ROWS = 256, HC = 64, CP = HC + 1, HP = HC + 2;
+    float* lc = reinterpret_cast<float*>(smem);
+    uint16_t* lh = reinterpret_cast<uint16_t*>(smem + ROWS * CP * 4);
+    const int C = a.lstm_C;
+    const int hc0 = n0 >> 2;
+    const int p = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int ml = wm * 128 + i * 32 + p;
+        const int m = m0 + ml;
+        const bool valid = m < a.M;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int hcl = wn * 32 + j * 8 + 2 * q + hi;
+                const int hc = hc0 + hcl;
+                const float gi = acc[i][j][q * 4 + 0], gr = acc[i][j][q * 4 + 1], go = acc[i][j][q * 4 + 2], gc = acc[i][j][q * 4 + 3];
+                float pc = 0.0f;
+                if constexpr ((W128_ABL & 128) == 0) pc = (a.lstm_prev && valid) ? a.lstm_prev[(long long)m * C + hc] : 0.0f;
+                float nc, hv;
+                if constexpr ((W128_ABL & 256) != 0) { nc = gr * pc + gi * gc; hv = go * nc; }
+                else {
+                    nc = fast_sigmoid(gr) * pc + fast_sigmoid(gi) * fast_tanh(gc);     // submodules.py:211
+                    hv = fast_sigmoid(go) * fast_tanh(nc);                              // submodules.py:212
+                }
+                lc[ml * CP + hcl] = nc;
+                lh[ml * HP + hcl] = (uint16_t)pack_bf16x2(hv, 0.0f);
+            }
+    }
+    __syncthreads();
+    if constexpr ((W128_ABL & 512) != 0) { if (lc[tid] == 12345.678f) a.lstm_cell[tid] = 1.f; return; }
+    const bool vec_ok = (C & 3) == 0 && (a.lstm_h_stride & 7) == 0 && (((uintptr_t)a.lstm_h | (uintptr_t)a.lstm_cell) & 15) == 0;
+    if (vec_ok) {
+#pragma unroll
+        for (int idx = tid; idx < ROWS * (HC / 4); idx += 256) {
+            const int row = idx / (HC / 4), c4 = idx - row * (HC / 4);
+            const int m = m0 + row;
+            const float* sp = lc + row * CP + c4 * 4;
+            if (m < a.M) out_store16(a.lstm_cell + (long long)m * C + hc0 + c4 * 4, make_uint4(__float_as_uint(sp[0]), __float_as_uint(sp[1]), __float_as_uint(sp[2]), __float_as_uint(sp[3])));
+        }
+        const uint32_t* lhv = reinterpret_cast<const uint32_t*>(lh);
+#pragma unroll
+        for (int idx = tid; idx < ROWS * (HC / 8); idx += 256) {
+            const int row = idx / (HC / 8), c8 = idx - row * (HC / 8);
+            const int m = m0 + row;
+            const uint32_t* sp = lhv + row * (HP / 2) + c8 * 4;
+            if (m < a.M) out_store16(a.lstm_h + (long long)m * a.lstm_h_stride + hc0 + c8 * 8, make_uint4(sp[0], sp[1], sp[2], sp[3]));
+        }
+        return;
+    }
+    for (int idx = tid; idx < ROWS * HC; idx += 256) {
+        const int row = idx / HC, col = idx - row * HC;
+        const int m = m0 + row;
+        if (m < a.M) a.lstm_cell[(long long)m * C + hc0 + col] = lc[row * CP + col];
+    }
+    const uint32_t* lh32 = reinterpret_cast<const uint32_t*>(lh);
+    for (int idx = tid; idx < ROWS * (HC / 2); idx += 256) {
+        const int row = idx / (HC / 2), col = idx - row * (HC / 2);
+        const int m = m0 + row;
+        if (m < a.M) *reinterpret_cast<uint32_t*>(a.lstm_h + (long long)m * a.lstm_h_stride + hc0 + col * 2) = lh32[row * (HP / 2) + col];
+    }
+}
+
+// W128_ABL & 8192: s_memtime stamps (debug).  Each wave sums the cycles of group G of slab dx into tacc[dx * 4 + G] (a stamp is taken
+// just before the s_waitcnt that closes a group, so a group's figure = the wait in front of it + its 16 MFMAs), plus the phases
+// prologue / fill / K loop / epilogue in tacc[12..15]; wave w of every problem's first tile overwrites lstm_cell[w * 16 + k].
+constexpr bool W128_STAMP = (W128_ABL & 8192) != 0;
+#define W128_STAMP_TAKE() do { if constexpr (W128_STAMP) asm volatile("s_memtime %0" : "=s"(tnow)); } while (0)
+#define W128_STAMP_ADD(K) do { if constexpr (W128_STAMP) { tacc[K] += (unsigned)tnow - tlast; tlast = (unsigned)tnow; } } while (0)
+
 __device__ __forceinline__ void conv3x3_lstm_w128_tile(const ConvArgs& a, const int bid, unsigned char* smem) {
+    unsigned long long tnow = 0; unsigned tlast = 0; unsigned tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    W128_STAMP_TAKE(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tlast = (unsigned)tnow;
     constexpr int BMX = 256, BN = 256, NWAVES = 4, MT = 4, NT = 4;
     constexpr int H_INSTR = W128_HROWS / 8 / NWAVES;     // 10 halo pieces per wave and macro step
     constexpr int B_INSTR = BN * 8 / 64 / NWAVES;        // 8 weight pieces per wave and slab
@@ -127,8 +228,14 @@ __device__ __forceinline__ void conv3x3_lstm_w128_tile(const ConvArgs& a, const 
     // (the four VALU instructions of a piece are volatile asm as well: left to hipcc they are hoisted in front of the slab's first
     //  MFMA, ~40 instructions during which the matrix pipe idles)
     const unsigned oob = 0x80000000u;
-    auto halo_piece = [&](auto par_c, auto i_c, int ddy, int tapoff) __attribute__((always_inline)) {
+    auto halo_piece0 = [&](auto par_c, auto i_c, int ddy, int tapoff) __attribute__((always_inline)) {
         constexpr int par = decltype(par_c)::value, i = decltype(i_c)::value;
+        if constexpr ((W128_ABL & 2048) != 0) {                     // no in-loop VALU: unchecked rows (timing only)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(smem + par * HALO_BYTES + (wave * H_INSTR + i) * 1024),
+                                                     16, (unsigned)hoff[i], (W128_ABL & 1024) ? 0 : tapoff + 2 * dil * W * ips_s, 0, 0);
+            return;
+        }
+        if constexpr ((W128_ABL & 1024) != 0) { ddy = 0; tapoff = 0; }     // always the tile's own rows (cache-hot; timing only)
         unsigned voff;
         asm volatile("v_add_u32 %0, %1, %2\n\tv_cmp_gt_u32 vcc, %3, %0\n\tv_add_u32 %0, %4, %5\n\tv_cndmask_b32 %0, %6, %0, vcc"
                      : "=&v"(voff) : "v"(hy[i]), "s"(ddy), "s"(H_s), "v"(hoff[i]), "s"(tapoff), "v"(oob) : "vcc");
@@ -136,10 +243,16 @@ __device__ __forceinline__ void conv3x3_lstm_w128_tile(const ConvArgs& a, const 
                                                  16, voff, 0, 0, 0);
     };
     // weight piece i of the slab at byte offset koff along K (scalar offset of the instruction) into weight stage `st`
-    auto w_piece = [&](auto st_c, auto i_c, int koff) __attribute__((always_inline)) {
+    auto w_piece0 = [&](auto st_c, auto i_c, int koff) __attribute__((always_inline)) {
         constexpr int st = decltype(st_c)::value, i = decltype(i_c)::value;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(smem + 2 * HALO_BYTES + st * WST + (wave * B_INSTR + i) * 1024),
                                                  16, (unsigned)boff[i], koff, 0, 0);
+    };
+    auto halo_piece = [&](auto par_c, auto i_c, int ddy, int tapoff) __attribute__((always_inline)) {
+        if constexpr ((W128_ABL & (2 | 32)) == 0) halo_piece0(par_c, i_c, ddy, tapoff);
+    };
+    auto w_piece = [&](auto st_c, auto i_c, int koff) __attribute__((always_inline)) {
+        if constexpr ((W128_ABL & (2 | 64)) == 0) w_piece0(st_c, i_c, koff);
     };
     // byte offset along K of slab (dy, cc, dx); slabs past the end re-fetch the last one (never read)
     const int koff_last = ((8 * Cin_s) + (nch - 1) * 64) * 2;
@@ -156,6 +269,7 @@ __device__ __forceinline__ void conv3x3_lstm_w128_tile(const ConvArgs& a, const 
     auto frag_read = [&fp, &fw, &pa, &wa](auto buf_c, auto q_c, auto dx_c, auto ks_c, auto hoff_c, auto woff_c) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_c)::value, q = decltype(q_c)::value, DX = decltype(dx_c)::value, KS = decltype(ks_c)::value;
         constexpr int HOFF = decltype(hoff_c)::value, WOFF = decltype(woff_c)::value;
+        if constexpr ((W128_ABL & 8) != 0) return;
         if constexpr (q == 0) W128_RD_W(BUF, 0, KS, WOFF);
         else if constexpr (q <= 4) W128_RD_P(BUF, q - 1, DX, KS, HOFF);
         else W128_RD_W(BUF, q - 4, KS, WOFF);
@@ -168,14 +282,17 @@ __device__ __forceinline__ void conv3x3_lstm_w128_tile(const ConvArgs& a, const 
 
     // ---- pipeline fill: halo 0, weight slabs 0 and 1, fragments of k-step 0
     int dy_c = 0, cc_c = 0, dy_n = 0, cc_n = 0;          // (dy, chunk) of macro steps j and j + 1
-    W128_FOR(H_INSTR, i, { halo_piece(std::integral_constant<int, 0>{}, i, -dil, (-dil * W * ips_s) * 2); });
-    W128_FOR(B_INSTR, i, { w_piece(std::integral_constant<int, 0>{}, i, slab_koff(0, 0, 0)); });
+    W128_STAMP_TAKE(); if constexpr (W128_STAMP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); W128_STAMP_ADD(12);
+    W128_FOR(H_INSTR, i, { halo_piece0(std::integral_constant<int, 0>{}, i, -dil, (-dil * W * ips_s) * 2); });
+    W128_FOR(B_INSTR, i, { w_piece0(std::integral_constant<int, 0>{}, i, slab_koff(0, 0, 0)); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     W128_FOR(8, q, { frag_read(std::integral_constant<int, 0>{}, q, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{},
                                std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); });
-    W128_FOR(B_INSTR, i, { w_piece(std::integral_constant<int, 1>{}, i, slab_koff(0, 0, 1)); });
+    W128_FOR(B_INSTR, i, { w_piece0(std::integral_constant<int, 1>{}, i, slab_koff(0, 0, 1)); });
+    W128_STAMP_TAKE();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    W128_STAMP_ADD(13);
 
     // one K-slab: macro step j of parity PAR, tap DX
     auto slab = [&](auto par_c, auto dx_c) __attribute__((always_inline)) {
@@ -195,26 +312,32 @@ __device__ __forceinline__ void conv3x3_lstm_w128_tile(const ConvArgs& a, const 
         W128_FOR(16, m, {
             mma(std::integral_constant<int, 0>{}, m);
             if constexpr (m < 8) frag_read(std::integral_constant<int, 1>{}, m, cDX{}, std::integral_constant<int, 1>{}, cH{}, cW{});
-            else if constexpr (DX == 0 && (m & 1) == 0) halo_piece(std::integral_constant<int, PAR ^ 1>{}, std::integral_constant<int, (m - 8) / 2>{}, ddy_n, tap_n);
+            else if constexpr (w128_halo_piece_at(DX, 0, m) >= 0) halo_piece(std::integral_constant<int, PAR ^ 1>{}, std::integral_constant<int, w128_halo_piece_at(DX, 0, m)>{}, ddy_n, tap_n);
         });
+        W128_STAMP_TAKE();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        W128_STAMP_ADD(DX * 4 + 0);
         // G1: buffer 1, reads of k-step 2 into buffer 0
         W128_FOR(16, m, {
             mma(std::integral_constant<int, 1>{}, m);
             if constexpr (m < 8) frag_read(std::integral_constant<int, 0>{}, m, cDX{}, std::integral_constant<int, 2>{}, cH{}, cW{});
-            else if constexpr (DX == 0 && (m & 1) == 0 && m < 14) halo_piece(std::integral_constant<int, PAR ^ 1>{}, std::integral_constant<int, 4 + (m - 8) / 2>{}, ddy_n, tap_n);
+            else if constexpr (w128_halo_piece_at(DX, 1, m) >= 0) halo_piece(std::integral_constant<int, PAR ^ 1>{}, std::integral_constant<int, w128_halo_piece_at(DX, 1, m)>{}, ddy_n, tap_n);
         });
+        W128_STAMP_TAKE();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        W128_STAMP_ADD(DX * 4 + 1);
         // G2: buffer 0, reads of k-step 3 into buffer 1
         W128_FOR(16, m, {
             mma(std::integral_constant<int, 0>{}, m);
             if constexpr (m < 8) frag_read(std::integral_constant<int, 1>{}, m, cDX{}, std::integral_constant<int, 3>{}, cH{}, cW{});
-            else if constexpr (DX == 0 && (m & 1) == 0 && m < 14) halo_piece(std::integral_constant<int, PAR ^ 1>{}, std::integral_constant<int, 7 + (m - 8) / 2>{}, ddy_n, tap_n);
+            else if constexpr (w128_halo_piece_at(DX, 2, m) >= 0) halo_piece(std::integral_constant<int, PAR ^ 1>{}, std::integral_constant<int, w128_halo_piece_at(DX, 2, m)>{}, ddy_n, tap_n);
         });
         // slab s + 1 landed (this wave's pieces), every wave is done reading slab s
-        if constexpr (DX == 0) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");
+        W128_STAMP_TAKE();
+        if constexpr ((W128_ABL & 16) != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(w128_halo_vmcnt(DX)) : "memory");
+        if constexpr ((W128_ABL & 4) == 0) asm volatile("s_barrier" ::: "memory");
+        W128_STAMP_ADD(DX * 4 + 2);
         // G3: buffer 1, reads of k-step 0 of slab s + 1 into buffer 0, weight slab s + 2
         W128_FOR(16, m, {
             mma(std::integral_constant<int, 1>{}, m);
@@ -222,7 +345,9 @@ __device__ __forceinline__ void conv3x3_lstm_w128_tile(const ConvArgs& a, const 
                                            std::integral_constant<int, nHOFF>{}, std::integral_constant<int, nWOFF>{});
             else w_piece(std::integral_constant<int, WSTAGE>{}, std::integral_constant<int, m - 8>{}, koff2);
         });
+        W128_STAMP_TAKE();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        W128_STAMP_ADD(DX * 4 + 3);
     };
     auto macro_step = [&](auto par_c) __attribute__((always_inline)) {
         dy_n = dy_c; cc_n = cc_c + 1;
@@ -241,7 +366,22 @@ __device__ __forceinline__ void conv3x3_lstm_w128_tile(const ConvArgs& a, const 
     // the MFMAs are opaque to hipcc's hazard recognizer: let the last ones retire before the accumulators are read
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     __syncthreads();
-    lstm_epilogue<MT, NT, false, false>(a, acc, smem, m0, n0, wm, wn, lane, tid);
+    if constexpr ((W128_ABL & 1) != 0) {
+        float sum = 0.f;
+        for (int i = 0; i < MT; ++i) for (int j = 0; j < NT; ++j) for (int e = 0; e < 16; ++e) sum += acc[i][j][e];
+        if (sum == 12345.678f) a.lstm_cell[tid] = sum;
+        return;
+    }
+    w128_lstm_epilogue(a, acc, smem, m0, n0, wm, wn, lane, tid);
+    if constexpr (W128_STAMP) {
+        W128_STAMP_TAKE(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); W128_STAMP_ADD(14);
+        __syncthreads();
+        if (bid == 0 && lane == 0) {
+            tacc[15] = (unsigned)NJ;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a.lstm_cell[wave * 16 + k] = (float)tacc[k];
+        }
+    }
 }
 
 // up to three problems in one launch (ConvGroup as conv3x3_halo_group_kernel); tiles_m counts 256-pixel tiles, tiles_n 256-column tiles

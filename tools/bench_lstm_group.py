@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--zero", action="store_true")
+    ap.add_argument("--stamps", action="store_true", help="print the s_memtime stamps of a W128_ABL & 8192 build (first tile of each level)")
     a = ap.parse_args()
     modes = [int(m) for m in a.modes.split(",")]
     ps = problems(a.batch, a.zero)
@@ -59,6 +60,19 @@ def main():
         dh = max(float((x.float() - y.float()).abs().max()) for x, y in zip(h, ref_h))
         bad = sum(int((~torch.isfinite(x)).sum()) for x in c)
         print(f"mode {m}: max|cell - mode1| = {dc:.3e}  max|hidden - mode1| = {dh:.3e}  non-finite cells {bad}", flush=True)
+    if a.stamps:
+        for m in modes:
+            c, h = run(ps, m)
+            torch.cuda.synchronize()
+            for p, cc in zip(ps, c):
+                v = cc.reshape(-1)[:64].cpu().reshape(4, 16)
+                nj = float(v[0, 15])
+                print(f"level C={p['C']}: NJ={nj:.0f}  cycles per slab and group (rows: wave; dx0 G0..G3 | dx1 | dx2), then prologue fill epilogue totals")
+                for w in range(4):
+                    g = [float(x) / nj for x in v[w, :12]]
+                    print("   w%d " % w + " | ".join(" ".join(f"{x:6.0f}" for x in g[d * 4:d * 4 + 4]) for d in range(3)) +
+                          f"   slab avg {sum(g) / 3:6.0f}   pro {float(v[w, 12]):7.0f} fill {float(v[w, 13]):7.0f} epi {float(v[w, 14]):7.0f}  loop {sum(g) * nj:8.0f}")
+        return
     times = {m: [] for m in modes}
     for _ in range(a.rounds):
         for m in modes:
