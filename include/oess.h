@@ -35,7 +35,7 @@ typedef void* oess_stream_t; /* hipStream_t */
 /* Library / device identification.  OESS_ABI_VERSION is bumped whenever a signature of this header changes or an entry point
  * is removed; oess_abi_version() returns the value the library was built with and the ctypes binding (openess_amd/_lib.py,
  * ABI_VERSION) refuses a library whose value differs. */
-#define OESS_ABI_VERSION 9
+#define OESS_ABI_VERSION 10
 int oess_abi_version(void);
 const char* oess_build_info(void);           /* "liboess <ver> gfx950 hipcc <ver>" */
 const char* oess_strerror(int code);
@@ -312,6 +312,23 @@ typedef struct {
     const float* prev_cell; float* cell; void* hidden; long long hidden_pix_stride;
 } oess_convlstm_desc_t;
 int oess_convlstm_fused_group_bf16(const oess_convlstm_desc_t* problems, int n, oess_stream_t stream);
+
+/* The same n <= 3 ConvLSTM steps on the round-6 kernel (csrc/conv_lstm_w128.h: persistent workgroups, one wave per SIMD on a
+ * 128-pixel x 128-gate-column accumulator block, hand-laid MFMA / LDS / LDS-DMA stream).  Replaces ConvLSTM.forward
+ * (e2vid/model/submodules.py:199-214) exactly as oess_convlstm_fused_bf16 does; what differs is the STORAGE of the cell state:
+ * prev_cell / cell are in the kernel's own "w128-tiled" layout ([tile of 256 pixels x 64 channels][wave][16][lane][4] fp32 = the
+ * accumulator layout, oess_convlstm_w128_cell_bytes(B*H*W, C) bytes: the pixel count is padded to a multiple of 256), so the
+ * previous cell arrives and the new cell leaves with coalesced 16-byte accesses and no transposition.  The cell state never
+ * leaves the recurrent encoder (submodules.py:205-212 only feeds it back); oess_convlstm_w128_cell_relayout converts to and from
+ * the reference's [B,H,W,C] order for state import / export and tests.  cell may equal prev_cell (a tile updates its own block)
+ * or be disjoint from it; hidden (NHWC bf16, own pixel stride) must not overlap `in`; no output of one problem may overlap
+ * another problem's buffers (checked).  Takes 3 x 3 / pad 1 Gates with Cin % 64 == 0, C_hidden % 64 == 0, H >= 8 and 32-bit
+ * extents; anything else returns OESS_EINVAL before any launch (callers fall back to oess_convlstm_fused_group_bf16 on a cell
+ * state in [B,H,W,C] order).  Gate arithmetic: bias added inside the exponent's FMA, sigmoid / tanh via exp2 + rcp (the fused
+ * kernels' fast forms); results agree with oess_convlstm_fused_bf16 to fp32 rounding of that reassociation. */
+size_t oess_convlstm_w128_cell_bytes(long long pixels, int C_hidden);      /* 0 when C_hidden % 64 != 0 */
+int oess_convlstm_w128_cell_relayout(const float* src, float* dst, long long pixels, int C_hidden, int to_tiled, oess_stream_t stream);
+int oess_convlstm_w128_group_bf16(const oess_convlstm_desc_t* problems, int n, oess_stream_t stream);
 
 /* n <= 2 INDEPENDENT 5x5 / stride-2 / pad-2 convolutions (out = act(conv(in, w) + bias), arguments as oess_conv2d_fwd_bf16 with
  * R = S = 5, stride 2, pad 2, relu in {0, 1}) in ONE launch: the encoder ConvLayers of levels 1 and 2 of E2VID's recurrent encoder

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OESS_LIB_PATH") or os.path.join(_HERE, "liboess.so")      # override: A/B builds of the same ABI
 
-ABI_VERSION = 9          # == OESS_ABI_VERSION of include/oess.h (tests/test_abi.py keeps the two equal)
+ABI_VERSION = 10         # == OESS_ABI_VERSION of include/oess.h (tests/test_abi.py keeps the two equal)
 
 c_i64 = ctypes.c_int64
 c_ll = ctypes.c_longlong
@@ -65,6 +65,9 @@ SIGNATURES = {
     "oess_convlstm_fused_bf16": (c_int, [c_vp, c_ll, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp,
                                          c_vp, c_vp, c_ll, c_vp]),
     "oess_convlstm_fused_group_bf16": (c_int, [c_vp, c_int, c_vp]),
+    "oess_convlstm_w128_cell_bytes": (c_sz, [c_ll, c_int]),
+    "oess_convlstm_w128_cell_relayout": (c_int, [c_vp, c_vp, c_ll, c_int, c_int, c_vp]),
+    "oess_convlstm_w128_group_bf16": (c_int, [c_vp, c_int, c_vp]),
     "oess_conv5x5s2_group_bf16": (c_int, [c_vp, c_int, c_vp]),
     "oess_loss_partials_bytes": (c_sz, []),
     "oess_l1_mean_fwd": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),

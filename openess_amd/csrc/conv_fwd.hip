@@ -23,6 +23,10 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
+#include <map>
+#include <mutex>
+#include <vector>
 #include "oess.h"
 #include "oess_common.h"
 
@@ -2042,7 +2046,7 @@ void conv_set_attrs() {
                              (const void*)&conv_fwd_dma_kernel<64, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<64, 128, 2, true>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 2, false, 1>, (const void*)&conv_fwd_dma_kernel<128, 128, 2, true, 1>,
                              (const void*)&conv3x3_halo_kernel<0>, (const void*)&conv3x3_halo_kernel<1>, (const void*)&conv3x3_halo_group_kernel<1>,
-                             (const void*)&conv3x3_halo256_group_kernel, (const void*)&conv3x3_lstm_w128_group_kernel,
+                             (const void*)&conv3x3_halo256_group_kernel, (const void*)&conv3x3_lstm_w128_kernel,
                              (const void*)&conv_fwd_dma_kernel<256, 256, 2, true>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 4, true, 0, 512>,
                              (const void*)&conv_fwd_dma32_kernel<128, true, 0, 3>, (const void*)&conv5x5s2_halo_kernel<false>,
@@ -2384,18 +2388,16 @@ int oess_convlstm_fused_group_bf16(const oess_convlstm_desc_t* d, int n, oess_st
     // buy nothing), but the product schedule runs it next to the teacher's and the decoder's kernels, and one 112 KB workgroup
     // leaves them 48 KB of LDS and 24 wave slots per CU where two 72 KB workgroups leave 16 KB: +1.4-1.6 % on the step on three
     // boxes (EXPERIMENTS R5-3b).  OESS_LSTM256 = 0 restores the 128 x 128 tiles (A/B), 2 = only the problems with >= 30 K-slabs.
-    const int use256 = [] { const char* e = getenv("OESS_LSTM256"); return e ? atoi(e) : 1; }();
+    static const int use256 = [] { const char* e = getenv("OESS_LSTM256"); return e ? atoi(e) : 1; }();
     if (use256) {
-        ConvGroup big, small, w128;
-        memset(&big, 0, sizeof(big)); memset(&small, 0, sizeof(small)); memset(&w128, 0, sizeof(w128));
-        int nb = 0, ns = 0, nw = 0;
+        ConvGroup big, small;
+        memset(&big, 0, sizeof(big)); memset(&small, 0, sizeof(small));
+        int nb = 0, ns = 0;
         for (int i = 0; i < n; ++i) {
             const ConvArgs& a = g.a[i];
             const bool fits = a.R == 3 && a.dil == 1 && (a.dil + 255 + a.dil * ((256 + a.W - 2) / a.W) + a.dil + 1) <= HALO_ROWS_256 &&
                               a.tiles_n * 128 == a.Cout;
-            // 128 x 128 wave tiles (conv_lstm_w128.h): 256-column tiles, an even number of (dy, 64-channel) macro steps
-            if (use256 == 3 && fits && a.Cout % 256 == 0 && a.Cin % 128 == 0) { w128.a[nw] = a; w128.a[nw].tiles_n = a.Cout / 256; ++nw; }
-            else if (fits && (use256 == 1 || use256 == 3 || a.Kpad / BK >= 30)) big.a[nb++] = a; else small.a[ns++] = a;
+            if (fits && (use256 == 1 || a.Kpad / BK >= 30)) big.a[nb++] = a; else small.a[ns++] = a;
         }
         auto layout = [](ConvGroup& q, int cnt, int rows) {
             int at_ = 0;
@@ -2409,10 +2411,6 @@ int oess_convlstm_fused_group_bf16(const oess_convlstm_desc_t* d, int n, oess_st
             q.start8[3] = at_;
             return at_;
         };
-        if (nw) {
-            const int atw = layout(w128, nw, 256);
-            hipLaunchKernelGGL(conv3x3_lstm_w128_group_kernel, dim3(8 * atw), dim3(256), (size_t)W128_LDS, (hipStream_t)stream, w128);
-        }
         if (nb) {
             const int atb = layout(big, nb, 256);
             const size_t lds256 = (size_t)2 * HALO_ROWS_256 * 128 + (size_t)2 * 128 * 128;
@@ -2432,6 +2430,148 @@ int oess_convlstm_fused_group_bf16(const oess_convlstm_desc_t* d, int n, oess_st
     return OESS_OK;
 }
 
+}  // extern "C"
+
+// ---- ConvLSTM on 128 x 128 wave tiles with the cell state in the kernel's own layout (conv_lstm_w128.h)
+namespace {
+struct W128Sched { int* dev; int stride; int grid; };
+// Static tile lists: workgroup b (one per CU; XCD b % 8 by the dispatch order, used for locality only) takes tiles of "its" XCD's
+// contiguous chunk of every problem -- neighbouring tiles share halo rows and weight slabs in that XCD's L2, as in the one-tile
+// kernels -- dealt longest-K first onto the least loaded of the XCD's workgroups (cost = slabs x measured cycles per slab + a
+// per-tile constant), i.e. what a dynamic queue would do, without an atomic and a reset per launch.
+static int w128_schedule(const ConvArgs* a, int n, W128Sched* out) {
+    static std::mutex mu;
+    static std::map<std::vector<int>, W128Sched> cache;
+    std::vector<int> key;
+    const int grid = num_cus();
+    key.push_back(grid);
+    for (int i = 0; i < n; ++i) { key.push_back(a[i].tiles_m); key.push_back(a[i].tiles_n); key.push_back(a[i].Cin); }
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) { *out = it->second; return OESS_OK; }
+    if (grid < 8 || grid % 8) return OESS_EINVAL;
+    const int per = grid / 8;
+    std::vector<std::vector<int>> lists(grid);
+    std::vector<long long> load(grid, 0);
+    for (int x = 0; x < 8; ++x)
+        for (int p = 0; p < n; ++p) {
+            const int nwg = a[p].tiles_m * a[p].tiles_n, q = nwg >> 3, r = nwg & 7;
+            const int cnt = q + (x < r ? 1 : 0), base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+            const long long cost = (long long)(a[p].Cin / 64) * 9 * 2420 + 7000;
+            for (int li = 0; li < cnt; ++li) {
+                int best = 0;
+                for (int c = 1; c < per; ++c) if (load[c * 8 + x] < load[best * 8 + x]) best = c;
+                lists[best * 8 + x].push_back((p << 24) | (base + li));
+                load[best * 8 + x] += cost;
+            }
+        }
+    size_t longest = 0;
+    for (auto& l : lists) longest = l.size() > longest ? l.size() : longest;
+    if (longest > (size_t)W128_MAX_LIST) return OESS_EINVAL;
+    const int stride = (int)longest + 1;
+    std::vector<int> flat((size_t)grid * stride, -1);
+    for (int b = 0; b < grid; ++b) for (size_t k = 0; k < lists[b].size(); ++k) flat[(size_t)b * stride + k] = lists[b][k];
+    W128Sched sc{nullptr, stride, grid};
+    if (hipMalloc((void**)&sc.dev, flat.size() * sizeof(int) + (size_t)grid * 4 * 16 * sizeof(float)) != hipSuccess) return OESS_ELAUNCH;
+    if (hipMemcpy(sc.dev, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return OESS_ELAUNCH;
+    cache[key] = sc;
+    *out = sc;
+    return OESS_OK;
+}
+}  // namespace
+
+extern "C" {
+size_t oess_convlstm_w128_cell_bytes(long long pixels, int C_hidden) {
+    if (pixels <= 0 || C_hidden <= 0 || (C_hidden & 63)) return 0;
+    return (size_t)((pixels + 255) / 256 * 256) * (size_t)C_hidden * 4;
+}
+
+int oess_convlstm_w128_cell_relayout(const float* src, float* dst, long long pixels, int C_hidden, int to_tiled, oess_stream_t stream) {
+    if (!src || !dst || src == dst || pixels <= 0 || C_hidden <= 0 || (C_hidden & 63)) return OESS_EINVAL;
+    const long long total = (pixels + 255) / 256 * 256 * C_hidden;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(w128_cell_relayout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, pixels, C_hidden, to_tiled);
+    OESS_HIP(hipGetLastError());
+    return OESS_OK;
+}
+
+int oess_convlstm_w128_group_bf16(const oess_convlstm_desc_t* d, int n, oess_stream_t stream) {
+    if (!d || n <= 0 || n > 3) return OESS_EINVAL;
+    auto span = [](const void* p, long long pixels, long long stride, int c, const char** lo, const char** hi) {
+        *lo = (const char*)p; *hi = *lo + (pixels - 1) * stride * 2 + (long long)c * 2;
+    };
+    int ctot = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!d[i].in || !d[i].hidden || !d[i].cell || d[i].B <= 0 || d[i].H < 8 || d[i].W <= 0 || d[i].R != 3 || d[i].S != 3 || d[i].pad != 1 ||
+            d[i].C_hidden <= 0 || (d[i].C_hidden & 63) || d[i].Cin <= 0 || (d[i].Cin & 63))
+            return OESS_EINVAL;
+        ctot += 4 * d[i].C_hidden;
+        const long long px = (long long)d[i].B * d[i].H * d[i].W;
+        const size_t cb = oess_convlstm_w128_cell_bytes(px, d[i].C_hidden);
+        if (cb >= 0x7fffffffull || px * d[i].W >= 0x100000000ll) return OESS_EINVAL;
+        if (d[i].prev_cell && d[i].prev_cell != d[i].cell) {
+            const char *p0 = (const char*)d[i].prev_cell, *c0 = (const char*)d[i].cell;
+            if (p0 < c0 + cb && c0 < p0 + cb) return OESS_EINVAL;         // a tile updates its own block in place or elsewhere, not a shifted copy
+        }
+        const char *h0, *h1, *c0 = (const char*)d[i].cell, *c1 = c0 + cb;
+        span(d[i].hidden, px, d[i].hidden_pix_stride, d[i].C_hidden, &h0, &h1);
+        if ((h1 - h0) >= 0x7fffffffll) return OESS_EINVAL;
+        for (int j = 0; j < n; ++j) {
+            const long long pj = (long long)d[j].B * d[j].H * d[j].W;
+            const char *i0, *i1, *g0, *g1, *e0 = (const char*)d[j].cell, *e1 = e0 + oess_convlstm_w128_cell_bytes(pj, d[j].C_hidden);
+            span(d[j].in, pj, d[j].in_pix_stride, d[j].Cin, &i0, &i1);
+            span(d[j].hidden, pj, d[j].hidden_pix_stride, d[j].C_hidden, &g0, &g1);
+            if (h0 < i1 && i0 < h1) return OESS_EINVAL;
+            if (c0 < i1 && i0 < c1) return OESS_EINVAL;
+            if (j != i && ((h0 < g1 && g0 < h1) || (c0 < e1 && e0 < c1))) return OESS_EINVAL;
+        }
+    }
+    if (ctot > W128_BIAS_FLOATS) return OESS_EINVAL;
+    ConvArgs args[3];
+    for (int i = 0; i < n; ++i) {
+        LstmOut l{d[i].prev_cell, d[i].cell, d[i].hidden, d[i].hidden_pix_stride, d[i].C_hidden};
+        if (conv_fwd_impl(d[i].in, d[i].in_pix_stride, d[i].B, d[i].H, d[i].W, d[i].Cin, d[i].w_packed_gates, d[i].bias, 4 * d[i].C_hidden,
+                          3, 3, 1, 1, 1, 0, nullptr, 0, nullptr, nullptr, 0, nullptr, &l, stream, nullptr, 0, nullptr, &args[i]) != OESS_OK)
+            return OESS_EINVAL;
+        ConvArgs& a = args[i];
+        // halo rows of a 256-pixel tile; a tile may wrap into the next image at most once (rows per tile <= H)
+        if (a.Kpad != 9 * a.Cin || (1 + 255 + ((256 + a.W - 2) / a.W) + 1 + 1) > W128_HROWS || ((256 + a.W - 2) / a.W + 1) > a.H || !a.mg_w || !a.mg_wd)
+            return OESS_EINVAL;
+        a.tiles_m = (a.M + 255) / 256;
+        a.tiles_n = a.Cout / 256;
+    }
+    int order[3] = {0, 1, 2};                  // longest K first
+    for (int i = 1; i < n; ++i)
+        for (int j = i; j > 0 && args[order[j]].Kpad > args[order[j - 1]].Kpad; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    W128Group g;
+    memset(&g, 0, sizeof(g));
+    for (int i = 0; i < n; ++i) g.a[i] = args[order[i]];
+    g.n = n;
+    W128Sched sc;
+    const int rc = w128_schedule(g.a, n, &sc);
+    if (rc != OESS_OK) return rc;
+    g.sched = sc.dev; g.sched_stride = sc.stride;
+    hipLaunchKernelGGL(conv3x3_lstm_w128_kernel, dim3(sc.grid), dim3(256), (size_t)W128_LDS, (hipStream_t)stream, g);
+    OESS_HIP(hipGetLastError());
+#if (W128_ABL & 8192)
+    {
+        std::vector<float> st((size_t)sc.grid * 64);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(st.data(), sc.dev + (size_t)sc.grid * sc.stride, st.size() * 4, hipMemcpyDeviceToHost);
+        double sum[16] = {0};
+        for (int b = 0; b < sc.grid; ++b) for (int k = 0; k < 16; ++k) sum[k] += st[((size_t)b * 4) * 16 + k];
+        fprintf(stderr, "w128 stamps (wave 0, cycles per workgroup, mean of %d): dx0 G0..G3 | dx1 | dx2 | once fill epi tiles\n  ", sc.grid);
+        double loop = 0;
+        for (int k = 0; k < 12; ++k) { fprintf(stderr, "%9.0f%s", sum[k] / sc.grid, (k & 3) == 3 ? " |" : ""); loop += sum[k] / sc.grid; }
+        fprintf(stderr, " %9.0f %9.0f %9.0f %5.1f   loop %9.0f\n", sum[12] / sc.grid, sum[13] / sc.grid, sum[14] / sc.grid, sum[15] / sc.grid, loop);
+    }
+#endif
+    return OESS_OK;
+}
+}  // extern "C"
+
+extern "C" {
 int oess_conv5x5s2_group_bf16(const oess_conv_s2_desc_t* d, int n, oess_stream_t stream) {
     if (!d || n <= 0 || n > 2) return OESS_EINVAL;
     for (int i = 0; i < n; ++i)

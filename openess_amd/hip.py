@@ -688,6 +688,64 @@ def convlstm_fused(xh, packed_gates, bias, cell, hidden_out, k, pad, prev_cell_i
     return hidden_out
 
 
+def convlstm_w128_cell_elems(pixels, C):
+    """Number of fp32 elements of a w128-tiled cell state for `pixels` = B*H*W pixels and C hidden channels (0: C % 64 != 0)."""
+    return int(_lib.load().oess_convlstm_w128_cell_bytes(int(pixels), int(C))) // 4
+
+
+def convlstm_w128_cell_relayout(src, pixels, C, to_tiled):
+    """Cell state between the reference's [pixels, C] fp32 order and the w128-tiled order of oess_convlstm_w128_group_bf16."""
+    lib = _lib.load()
+    _need_gpu(src)
+    n = convlstm_w128_cell_elems(pixels, C)
+    if n == 0 or src.dtype != torch.float32 or not src.is_contiguous() or src.numel() != (pixels * C if to_tiled else n):
+        raise ValueError("convlstm_w128_cell_relayout: contiguous fp32, C % 64 == 0, matching size")
+    dst = torch.empty(n if to_tiled else pixels * C, dtype=torch.float32, device=src.device)
+    _lib.check(lib.oess_convlstm_w128_cell_relayout(_ptr(src), _ptr(dst), int(pixels), int(C), int(bool(to_tiled)), _stream()),
+               "oess_convlstm_w128_cell_relayout")
+    return dst
+
+
+def convlstm_w128_group(problems):
+    """oess_convlstm_w128_group_bf16: `problems` as for convlstm_fused_group, except that `cell` is a flat fp32 tensor of
+    convlstm_w128_cell_elems(B*H*W, C) elements in the w128-tiled layout.  Returns False (nothing launched) when the kernel does not
+    take one of the problems; the caller then uses convlstm_fused_group on NHWC cells."""
+    lib = _lib.load()
+    n = len(problems)
+    if not 1 <= n <= 3:
+        raise ValueError("convlstm_w128_group: 1..3 problems")
+    descs = (_lib.ConvLstmDesc * n)()
+    flops, keys = 0.0, []
+    for d, (xh, packed_gates, bias, cell, hidden_out, k, pad, prev_zero) in zip(descs, problems):
+        _need_gpu(xh, packed_gates, cell, hidden_out)
+        B, H, W, Cin, ps = _nhwc_geom(xh)
+        _, _, _, C, hs = _nhwc_geom(hidden_out)
+        if cell.dtype != torch.float32 or not cell.is_contiguous() or cell.numel() != convlstm_w128_cell_elems(B * H * W, C) or C % 64:
+            return False
+        if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() != 4 * C):
+            raise ValueError("convlstm_w128_group: bias must be contiguous fp32 [4C]")
+        d.in_, d.in_pix_stride, d.B, d.H, d.W, d.Cin = _ptr(xh), ps, B, H, W, Cin
+        d.w_packed_gates, d.bias, d.C_hidden, d.R, d.S, d.pad = _ptr(packed_gates), _ptr(bias), C, k, k, pad
+        d.prev_cell, d.cell, d.hidden, d.hidden_pix_stride = (None if prev_zero else _ptr(cell)), _ptr(cell), _ptr(hidden_out), hs
+        fl = 2.0 * B * H * W * 4 * C * Cin * k * k
+        flops += fl
+        keys.append(((H, W, Cin, 4 * C, k, 1, "lstm"), fl))
+    t = _CONV_TIMING
+    if t is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib.oess_convlstm_w128_group_bf16(ctypes.addressof(descs), n, _stream())
+    if rc == -22:                     # OESS_EINVAL: geometry not taken, nothing launched
+        return False
+    _lib.check(rc, "oess_convlstm_w128_group_bf16")
+    if t is not None:
+        e1.record()
+        t["events"].append((e0, e1))
+        t["flops"] += flops
+        t.setdefault("keys", []).extend(keys)
+    return True
+
+
 def convlstm_fused_group(problems):
     """Up to three INDEPENDENT ConvLSTM steps in one launch (oess_convlstm_fused_group_bf16): `problems` = tuples
     (xh, packed_gates, bias, cell, hidden_out, k, pad, prev_cell_is_zero) as for convlstm_fused.  Same results as calling

@@ -406,6 +406,70 @@ def test_convlstm_fused_group_equals_separate_launches(geoms):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("geoms", [
+    [(1, 48, 80, 64), (1, 24, 40, 128), (1, 16, 20, 256)],      # the three E2VID levels scaled down (a tile must not span more rows than the image has)
+    [(2, 24, 40, 128), (2, 16, 20, 256)],
+    [(3, 16, 24, 64)],                                          # 4.5 tiles: ragged last tile, tiles that run across image borders
+    [(1, 20, 33, 64), (2, 18, 27, 64), (1, 16, 41, 128)],       # odd widths: every tile starts mid-row
+    [(8, 220, 320, 64), (8, 110, 160, 128), (8, 55, 80, 256)],  # the BASELINE size (B = 8, 440 x 640 crop)
+])
+def test_convlstm_w128_group_matches_fused_launches(geoms):
+    """oess_convlstm_w128_group_bf16 (persistent 128 x 128-wave-tile kernel, w128-tiled cell state) against oess_convlstm_fused_bf16 on
+    [B,H,W,C] cells, three recurrent steps with ping-pong cat(x, h) buffers and the cell updated in place: same MFMA products in the
+    same order, the cell update reassociated (bias inside the exponent's FMA) -> fp32-rounding agreement of the cell, one bf16 ulp on
+    the hidden state.  Also the relayout round trip."""
+    import torch
+    from openess_amd import hip
+    torch.manual_seed(len(geoms) * 11 + geoms[0][2])
+    dev = "cuda"
+    st = []
+    for i, (B, H, W, C) in enumerate(geoms):
+        w = torch.randn(4 * C, 2 * C, 3, 3, device=dev) * (0.3 / C ** 0.5)
+        bias = torch.randn(4 * C, device=dev) * 0.1
+        st.append(dict(B=B, H=H, W=W, C=C, packed=hip.pack_conv_weight(w, flip=2), packed_x=hip.pack_conv_weight(w[:, :C], flip=2), bias=bias,
+                       xh_a=[torch.zeros(B, H, W, 2 * C, device=dev, dtype=torch.bfloat16) for _ in range(2)],
+                       xh_b=[torch.zeros(B, H, W, 2 * C, device=dev, dtype=torch.bfloat16) for _ in range(2)],
+                       cell_a=torch.empty(B, H, W, C, device=dev),
+                       cell_b=torch.full((hip.convlstm_w128_cell_elems(B * H * W, C),), 3.0, device=dev), cur=0))
+    for s_ in st:                                              # relayout round trip on random data
+        c = torch.randn(s_["B"] * s_["H"] * s_["W"], s_["C"], device=dev)
+        t = hip.convlstm_w128_cell_relayout(c, c.shape[0], s_["C"], True)
+        assert torch.equal(hip.convlstm_w128_cell_relayout(t, c.shape[0], s_["C"], False).reshape(c.shape), c)
+    for step in range(3):
+        probs_a, probs_b = [], []
+        for i, s_ in enumerate(st):
+            C, cur = s_["C"], s_["cur"]
+            x = (torch.randn(s_["B"], s_["H"], s_["W"], C, device=dev) * 0.5).bfloat16()
+            fresh = step == 0
+            for xh in (s_["xh_a"], s_["xh_b"]):
+                xh[cur][..., :C] = x
+            for xh, cell, probs in ((s_["xh_a"], s_["cell_a"], probs_a), (s_["xh_b"], s_["cell_b"], probs_b)):
+                probs.append((xh[cur][..., :C] if fresh else xh[cur], s_["packed_x"] if fresh else s_["packed"], s_["bias"], cell,
+                              xh[1 - cur][..., C:], 3, 1, fresh))
+        for pr in probs_a:
+            hip.convlstm_fused(*pr)
+        assert hip.convlstm_w128_group(probs_b)
+        for s_ in st:
+            C, cur = s_["C"], s_["cur"]
+            px = s_["B"] * s_["H"] * s_["W"]
+            cb = hip.convlstm_w128_cell_relayout(s_["cell_b"], px, C, False).reshape(s_["cell_a"].shape)
+            ha, hb = s_["xh_a"][1 - cur][..., C:].float(), s_["xh_b"][1 - cur][..., C:].float()
+            assert torch.allclose(cb, s_["cell_a"], atol=2e-5, rtol=1e-5), (step, float((cb - s_["cell_a"]).abs().max()))
+            assert float((ha - hb).abs().max()) <= 2.0 ** -7, (step, float((ha - hb).abs().max()))
+            assert float((ha - hb).abs().mean()) < 2e-4
+            # both paths continue from the SAME hidden state (a one-ulp difference would otherwise grow through the recurrence)
+            s_["xh_b"][1 - cur][..., C:] = s_["xh_a"][1 - cur][..., C:]
+            s_["cell_b"].copy_(hip.convlstm_w128_cell_relayout(s_["cell_a"].reshape(px, C), px, C, True))
+            s_["cur"] = 1 - cur
+    # not taken: hidden size not a multiple of 64, or a cell buffer in the wrong size -> False, nothing launched
+    B, H, W, C = 1, 16, 24, 32
+    w = torch.randn(4 * C, 2 * C, 3, 3, device=dev)
+    xh = torch.zeros(B, H, W, 2 * C, device=dev, dtype=torch.bfloat16)
+    out = torch.zeros(B, H, W, 2 * C, device=dev, dtype=torch.bfloat16)
+    assert hip.convlstm_w128_group([(xh, hip.pack_conv_weight(w, flip=2), None, torch.empty(B, H, W, C, device=dev), out[..., C:], 3, 1, False)]) is False
+
+
+@pytest.mark.gpu
 def test_convlstm_fused_rejects_aliasing_and_bad_shapes():
     import torch
     from openess_amd import hip

@@ -3,8 +3,8 @@ E2VID's recurrent encoder (B = 8; 220x320 C=64, 110x160 C=128, 55x80 C=256; Gate
 
     python tools/bench_lstm_group.py [--modes 1,3] [--iters 20] [--rounds 3] [--zero]
 
-OESS_LSTM256 selects the tile form per call (1 = 256 x 128 tiles / 64 x 64 wave tiles, 0 = 128 x 128 tiles, 3 = 256 x 256 tiles /
-128 x 128 wave tiles).  Prints TFLOP/s of the gate convolutions per mode (interleaved rounds, median and best) and the maximum
+Modes: 4 = oess_convlstm_w128_group_bf16 (256 x 256 tiles / 128 x 128 wave tiles, persistent, w128-tiled cell state); 1 / 0 =
+oess_convlstm_fused_group_bf16 on 256 x 128 / 128 x 128 tiles (OESS_LSTM256, read once per process: one of them per run).  Prints TFLOP/s of the gate convolutions per mode (interleaved rounds, median and best) and the maximum
 difference of hidden / cell outputs against mode 1."""
 import argparse
 import os
@@ -31,17 +31,36 @@ def problems(B, zero, seed=0):
     return out
 
 
-def run(ps, mode):
+def launch(mode, args):
+    """mode 4 = oess_convlstm_w128_group_bf16 (w128-tiled cells), else oess_convlstm_fused_group_bf16 with OESS_LSTM256 = mode"""
+    if mode == 4:
+        if not hip.convlstm_w128_group(args):
+            raise RuntimeError("w128 kernel did not take the problems")
+    else:
+        hip.convlstm_fused_group(args)
+
+
+def make_args(ps, mode):
     os.environ["OESS_LSTM256"] = str(mode)
-    cells = [p["cell0"].clone() for p in ps]
     hs = [torch.empty(p["xh"].shape[0], p["H"], p["W"], p["C"], dtype=torch.bfloat16, device="cuda") for p in ps]
-    hip.convlstm_fused_group([(p["xh"], p["packed"], p["bias"], c, h, 3, 1, False) for p, c, h in zip(ps, cells, hs)])
+    if mode == 4:
+        cells = [hip.convlstm_w128_cell_relayout(p["cell0"].reshape(-1, p["C"]), p["cell0"].numel() // p["C"], p["C"], True) for p in ps]
+    else:
+        cells = [p["cell0"].clone() for p in ps]
+    return cells, hs, [(p["xh"], p["packed"], p["bias"], c, h, 3, 1, False) for p, c, h in zip(ps, cells, hs)]
+
+
+def run(ps, mode):
+    cells, hs, args = make_args(ps, mode)
+    launch(mode, args)
+    if mode == 4:
+        cells = [hip.convlstm_w128_cell_relayout(c, p["cell0"].numel() // p["C"], p["C"], False).reshape(p["cell0"].shape) for p, c in zip(ps, cells)]
     return cells, hs
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--modes", default="1,3")
+    ap.add_argument("--modes", default="1,4")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8)
@@ -60,32 +79,18 @@ def main():
         dh = max(float((x.float() - y.float()).abs().max()) for x, y in zip(h, ref_h))
         bad = sum(int((~torch.isfinite(x)).sum()) for x in c)
         print(f"mode {m}: max|cell - mode1| = {dc:.3e}  max|hidden - mode1| = {dh:.3e}  non-finite cells {bad}", flush=True)
-    if a.stamps:
-        for m in modes:
-            c, h = run(ps, m)
-            torch.cuda.synchronize()
-            for p, cc in zip(ps, c):
-                v = cc.reshape(-1)[:64].cpu().reshape(4, 16)
-                nj = float(v[0, 15])
-                print(f"level C={p['C']}: NJ={nj:.0f}  cycles per slab and group (rows: wave; dx0 G0..G3 | dx1 | dx2), then prologue fill epilogue totals")
-                for w in range(4):
-                    g = [float(x) / nj for x in v[w, :12]]
-                    print("   w%d " % w + " | ".join(" ".join(f"{x:6.0f}" for x in g[d * 4:d * 4 + 4]) for d in range(3)) +
-                          f"   slab avg {sum(g) / 3:6.0f}   pro {float(v[w, 12]):7.0f} fill {float(v[w, 13]):7.0f} epi {float(v[w, 14]):7.0f}  loop {sum(g) * nj:8.0f}")
+    if a.stamps:                         # a W128_ABL & 8192 build prints its stamps on stderr after every launch
         return
     times = {m: [] for m in modes}
     for _ in range(a.rounds):
         for m in modes:
-            os.environ["OESS_LSTM256"] = str(m)
-            cells = [p["cell0"].clone() for p in ps]
-            hs = [torch.empty(p["xh"].shape[0], p["H"], p["W"], p["C"], dtype=torch.bfloat16, device="cuda") for p in ps]
-            args = [(p["xh"], p["packed"], p["bias"], c, h, 3, 1, False) for p, c, h in zip(ps, cells, hs)]
+            cells, hs, args = make_args(ps, m)
             for _ in range(3):
-                hip.convlstm_fused_group(args)
+                launch(m, args)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
-                hip.convlstm_fused_group(args)
+                launch(m, args)
             e1.record()
             torch.cuda.synchronize()
             times[m].append(e0.elapsed_time(e1) / a.iters)
