@@ -2561,7 +2561,7 @@ int oess_convlstm_w128_group_bf16(const oess_convlstm_desc_t* d, int n, oess_str
         (void)hipMemcpy(st.data(), sc.dev + (size_t)sc.grid * sc.stride, st.size() * 4, hipMemcpyDeviceToHost);
         double sum[16] = {0};
         for (int b = 0; b < sc.grid; ++b) for (int k = 0; k < 16; ++k) sum[k] += st[((size_t)b * 4) * 16 + k];
-        fprintf(stderr, "w128 stamps (wave 0, cycles per workgroup, mean of %d): dx0 G0..G3 | dx1 | dx2 | once fill epi tiles\n  ", sc.grid);
+        fprintf(stderr, "w128 stamps (wave 0, cycles per workgroup, mean of %d): dx0 G0..G3 | dx1 | dx2 | setup+fill-issue  first-operand-wait  cell-update  tiles\n  ", sc.grid);
         double loop = 0;
         for (int k = 0; k < 12; ++k) { fprintf(stderr, "%9.0f%s", sum[k] / sc.grid, (k & 3) == 3 ? " |" : ""); loop += sum[k] / sc.grid; }
         fprintf(stderr, " %9.0f %9.0f %9.0f %5.1f   loop %9.0f\n", sum[12] / sc.grid, sum[13] / sc.grid, sum[14] / sc.grid, sum[15] / sc.grid, loop);

@@ -34,6 +34,9 @@
 //      * the next tile's first halo + two weight slabs are issued BEFORE the cell update of the current tile and land under it.
 // LDS: [halo 0][halo 1] 2 x 40 KB, [weights 0][weights 1] 2 x 32 KB = 144 KB operands + 8 KB tables, one workgroup per CU.
 // Requires: 3 x 3, dil 1, stride 1, pad 1, Cin % 64 == 0, Cout % 256 == 0, H >= 8, 32-bit buffer offsets (host: w128_eligible).
+#ifndef W128_EARLY_CELL
+#define W128_EARLY_CELL 0   // 1: previous-cell loads at the start of the tile's K loop (64 registers live across it)
+#endif
 #ifndef W128_ABL
 #define W128_ABL 0     // debug (tools/bench_lstm_group.py): 8192 = s_memtime stamps printed by the host after the launch
 #endif
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wm = wave >> 1, wn = wave & 1;
     const int p31 = lane & 31, hi = lane >> 5;
 
-    unsigned long long tnow = 0; unsigned tlast = 0; unsigned tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tnow = 0; unsigned tlast = 0; unsigned tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned tsetup = 0, tfirst = 0;
     W128_STAMP_TAKE(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tlast = (unsigned)tnow;
 
     // ---- once per workgroup: problem records, tile list and bias tables into LDS
@@ -351,14 +354,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     W128_STAMP_TAKE(); if constexpr (W128_STAMP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); W128_STAMP_ADD(12);
     while (entry >= 0) {
+        auto load_prev_cell = [&]() __attribute__((always_inline)) {
+            // previous cell of this tile (w128-tiled layout: 16 x 16-byte loads per lane, 1 KB per wave instruction), issued before the
+            // next tile's set-up; the cell update consumes them block by block as they land.  (Issued at the start of the K loop they would
+            // be live across it, and hipcc spills all 64 registers -- load, wait, scratch store -- although the loop itself uses 125.)
+            if (has_prev) {
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsP, cell_voff + r * 1024, 0, 0);
+                    cellreg[r] = f32x4_t{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+                }
+            } else {
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) cellreg[r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+        };
         // The tile's first operands have landed: they were issued before the previous tile's 32 result stores (this wave's own
         // pieces; vector memory operations of a wave retire in issue order), so the stores may stay in flight.  Fragments of k-step 0.
         asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
         W128_FOR(8, q, { frag_read(w128_c<0>{}, q, w128_c<0>{}, w128_c<0>{}, w128_c<0>{}, w128_c<0>{}); });
+        if constexpr (W128_EARLY_CELL) load_prev_cell();
         W128_STAMP_TAKE();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        W128_STAMP_ADD(13);
+        if constexpr (W128_STAMP) { tfirst += (unsigned)tnow - tlast; tlast = (unsigned)tnow; }
 
         dy_c = 0; cc_c = 0; first_slab = true;
         for (int j = 0; j < NJ; j += 2) {
@@ -377,25 +396,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int cell_voff_t = cell_voff;
         const uint32_t bias_addr_t = bias_addr;
 
-        // previous cell of this tile (w128-tiled layout: 16 x 16-byte loads per lane, 1 KB per wave instruction), issued before the
-        // next tile's set-up; the cell update consumes them block by block as they land.  (Issued at the start of the K loop they would
-        // be live across it, and hipcc spills all 64 registers -- load, wait, scratch store -- although the loop itself uses 125.)
-        if (has_prev) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsP, cell_voff + r * 1024, 0, 0);
-                cellreg[r] = f32x4_t{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cellreg[r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        }
+        if constexpr (!W128_EARLY_CELL) load_prev_cell();
         // next tile: set-up, first operands on their way under the cell update
         ++li;
         const int next = __builtin_amdgcn_readfirstlane(llist[li]);
         int has_prev_n = 0;
         if (next >= 0) { has_prev_n = setup(next); fill(); }
 
+        W128_STAMP_TAKE(); if constexpr (W128_STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tsetup += (unsigned)tnow - tlast; tlast = (unsigned)tnow; }
         // ---- cell update (submodules.py:205-212) straight from the accumulators: lane holds, for pixel (i, p31), rows
         // e = 4 q + gate of gate block j <-> hidden channel j*8 + 2 q + hi
         W128_FOR(NT, jc, {
@@ -452,7 +460,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if constexpr (W128_STAMP) {
         if (lane == 0) {
             float* dbg = const_cast<float*>(reinterpret_cast<const float*>(g.sched)) + (size_t)gridDim.x * g.sched_stride;
-            tacc[15] = (unsigned)li;
+            tacc[15] = (unsigned)li; tacc[13] = tfirst; tacc[12] = tsetup;
 #pragma unroll
             for (int k = 0; k < 16; ++k) dbg[(blockIdx.x * 4 + wave) * 16 + k] = (float)tacc[k];
         }

@@ -173,6 +173,22 @@ class ConvLSTM(nn.Module):
             return (engine.nhwc(xh[:, :self.input_size]), pw['packed_x'], pw['bias'], state['cell'], engine.nhwc(h_view), k, pad, True)
         return (engine.nhwc(xh), pw['packed'], pw['bias'], state['cell'], engine.nhwc(h_view), k, pad, False)
 
+    def w128_ok(self, B, H, W):
+        """Geometry rule of oess_convlstm_w128_group_bf16 (include/oess.h): 3 x 3 / pad 1 Gates, 64-channel multiples, a 256-pixel tile
+        spans no more rows than the map has, 32-bit extents."""
+        g = self.Gates
+        C = self.hidden_size
+        return (g.kernel_size == (3, 3) and g.padding == (1, 1) and C % 64 == 0 and self.input_size % 64 == 0 and H >= 8
+                and (256 + W - 2) // W + 1 <= H and B * H * W * max(2 * (self.input_size + C), 4 * C) < 2 ** 31 and B * H * W * W < 2 ** 32)
+
+    @staticmethod
+    def cell_nhwc(state):
+        """The cell state in the reference's order, fp32 [B, H, W, C] (a copy when the state keeps it w128-tiled)."""
+        if 'cell_tiled' not in state:
+            return state['cell']
+        B, H, W, C = state['cell_tiled']
+        return hip.convlstm_w128_cell_relayout(state['cell'], B * H * W, C, False).reshape(B, H, W, C)
+
     def step(self, state):
         """state: dict(xh=[two cat(x, h) buffers, B x (Cin+Ch) x H x W cl bf16], cur=index of the buffer whose x half
         was just written and whose h half holds h_prev, cell=fp32 [B,H,W,Ch], fresh=bool).
@@ -182,7 +198,12 @@ class ConvLSTM(nn.Module):
         cur = state['cur']
         xh = state['xh'][cur]
         k, pad = g.kernel_size[0], g.padding[0]
-        if self.hidden_size % 32 == 0:
+        if 'cell_tiled' in state:
+            if not hip.convlstm_w128_group([self.fused_args(state)]):
+                raise RuntimeError("oess_convlstm_w128_group_bf16 refused a state that ConvLSTM.w128_ok accepted")
+            h_view = state['xh'][1 - cur][:, self.input_size:]
+            state['cur'] = 1 - cur
+        elif self.hidden_size % 32 == 0:
             hip.convlstm_fused(*self.fused_args(state))
             h_view = state['xh'][1 - cur][:, self.input_size:]
             state['cur'] = 1 - cur
@@ -217,8 +238,15 @@ class RecurrentConvLayer(nn.Module):
         # follows the encoder conv's write of its x half and the previous step's write of its h half -> no zero fill needed
         # (6 fills of up to 157 MB per pre-training step); the conv + gate-kernel path reads h_prev = 0 from the buffer itself
         make = engine.empty_cl if self.recurrent_block.hidden_size % 32 == 0 else engine.zeros_cl
-        return {'xh': [make(B, 2 * Co, Ho, Wo, x.device), make(B, 2 * Co, Ho, Wo, x.device)], 'cur': 0,
-                'cell': torch.empty((B, Ho, Wo, Co), dtype=torch.float32, device=x.device), 'fresh': True}
+        st = {'xh': [make(B, 2 * Co, Ho, Wo, x.device), make(B, 2 * Co, Ho, Wo, x.device)], 'cur': 0, 'fresh': True}
+        if self.recurrent_block.w128_ok(B, Ho, Wo):
+            # the cell state only ever feeds the next ConvLSTM step (submodules.py:205-212): it lives in the gate kernel's own
+            # "w128-tiled" layout (hip.convlstm_w128_group); ConvLSTM.cell_nhwc(state) gives the reference's [B, H, W, C] order
+            st['cell'] = torch.empty(hip.convlstm_w128_cell_elems(B * Ho * Wo, Co), dtype=torch.float32, device=x.device)
+            st['cell_tiled'] = (B, Ho, Wo, Co)
+        else:
+            st['cell'] = torch.empty((B, Ho, Wo, Co), dtype=torch.float32, device=x.device)
+        return st
 
     def conv_s2_args(self, x, state):
         """One problem of hip.conv5x5s2_group for this layer's encoder conv (x -> x half of the current cat(x, h) buffer), or None

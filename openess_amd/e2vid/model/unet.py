@@ -99,8 +99,16 @@ class UNetRecurrent(nn.Module):
             self._lstm_stage(st, levels[3:])
             return
         blocks = [self.encoders[l].recurrent_block for l in levels]
-        if len(levels) > 1 and all(b.hidden_size % 32 == 0 for b in blocks):
+        if all('cell_tiled' in st[l] for l in levels):
+            # the round-6 kernel: persistent workgroups, 128 x 128 wave tiles, w128-tiled cell states (any number of levels <= 3)
+            if not hip.convlstm_w128_group([b.fused_args(st[l]) for b, l in zip(blocks, levels)]):
+                raise RuntimeError("oess_convlstm_w128_group_bf16 refused states that ConvLSTM.w128_ok accepted")
+            hs = True
+        elif len(levels) > 1 and all(b.hidden_size % 32 == 0 and 'cell_tiled' not in st[l] for b, l in zip(blocks, levels)):
             hs = hip.convlstm_fused_group([b.fused_args(st[l]) for b, l in zip(blocks, levels)])
+        else:
+            hs = None
+        if hs is not None:
             for l, b in zip(levels, blocks):
                 state = st[l]
                 h = state['xh'][1 - state['cur']][:, b.input_size:]

@@ -178,7 +178,8 @@ def test_update_reconstruction_with_padding_matches_reference_golden(gpre, keys)
         got = latent[k].float().cpu().numpy()
         assert got.shape == gpre[f"rec_latent_{k}"].shape
         assert relerr(got, gpre[f"rec_latent_{k}"]) < 3e-2, k
-    c2 = states[2]['cell'].permute(0, 3, 1, 2).float().cpu().numpy()          # deepest ConvLSTM cell state (fp32 NHWC here)
+    from openess_amd.e2vid.model.submodules import ConvLSTM
+    c2 = ConvLSTM.cell_nhwc(states[2]).permute(0, 3, 1, 2).float().cpu().numpy()   # deepest ConvLSTM cell state (reference order)
     assert c2.shape == gpre["rec_state_c_2"].shape and relerr(c2, gpre["rec_state_c_2"]) < 3e-2
     want = gpre["rec_img"]                                                     # the reference returns the padded 32x48 image
     got = img.float().cpu().numpy()

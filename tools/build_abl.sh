@@ -4,7 +4,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 M=$1; shift
 for v in "$@"; do
   ( T=$(mktemp -d); /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$ROOT/openess_amd/csrc -ffp-contract=off \
-      -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-lambda-capture -D$M=$v -c $ROOT/openess_amd/csrc/conv_fwd.hip -o $T/v.o 2>/dev/null &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/openess_amd/liboess_${M}_$v.so $(ls $ROOT/openess_amd/csrc/build/*.o | grep -v /conv_fwd.o) $T/v.o && echo built $v ) &
+      -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-lambda-capture -D$M=$v $EXTRA -c $ROOT/openess_amd/csrc/conv_fwd.hip -o $T/v.o 2>/dev/null &&
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/openess_amd/liboess_${M}_$v$SUFFIX.so $(ls $ROOT/openess_amd/csrc/build/*.o | grep -v /conv_fwd.o) $T/v.o && echo built $v ) &
 done
 wait
