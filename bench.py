@@ -52,7 +52,8 @@ PEAK_HBM_GBS = 8000.0           # MI355X HBM3E (MI355X_MICROARCH.md)
 # algorithmic work per batch of 8 (SURVEY 8d / BASELINE.md section 4)
 VOX_BYTES = 16 * B * NWIN * N_PER + 4 * B * NWIN * C * H_SENSOR * W_SENSOR           # 1.239 GB
 GFLOP_FWD = {"deeplabv3_resnet50": 106.8 * B, "dilated_r50_teacher": 845.1 * B}
-DOMINANT = re.compile(r"conv3x3_halo_kernel<[01]>|conv3x3_halo_group_kernel<1>|conv3x3_halo256_group_kernel|conv5x5s2_halo(_group)?_kernel|"
+DOMINANT_ONE = re.compile(r"conv3x3_lstm_w128_kernel")          # THE dominant kernel (roofline.frac); DOMINANT = its conv family
+DOMINANT = re.compile(r"conv3x3_lstm_w128_kernel|conv3x3_halo_kernel<[01]>|conv3x3_halo_group_kernel<1>|conv3x3_halo256_group_kernel|conv5x5s2_halo(_group)?_kernel|"
                       r"conv_fwd_dma_kernel<(128|64), 128, [24], (true|false), [01](, 256)?>|conv_fwd_dma_kernel<256, 256, 2, true, 0(, 512)?>|"
                       r"conv_fwd_dma32_kernel<128, true, 0, 3")
 
@@ -177,7 +178,21 @@ def cpu_baseline(sample_events, rectify_map):
         legs["ddd17_config0_error"] = repr(e)
     total = t_vox + t_net
     model, phys, logical = _host_cpu()
-    return {"value": round(1.0 / total, 5), "unit": "event-frames/s", "cores": nthr, "kind": "port",
+    # (iv) full-size parity for free: the SAME full-size sample through the HIP step and the oracle from identical weights
+    parity = None
+    try:
+        from tests import full_size_parity as fsp
+        yy = (torch.arange(H_NET) * 10 // H_NET)[:, None]
+        xx = (torch.arange(W_SENSOR) * 10 // W_SENSOR)[None, :]
+        parity = fsp.compare(ev, frame, pl, (yy * 10 + xx)[None].long(), nwin=NWIN, bins=C)
+        parity["tolerances"] = {"rel": 0.02, "nce_rel": 0.05, "argmax_agree_clear_margin": 0.99, "logit_rel_rms_err": 0.2}
+        parity["pass"] = bool(parity["rel"] <= 0.02 and parity["nce_rel"] <= 0.05 and parity["argmax_agree_clear_margin"] >= 0.99 and parity["logit_rel_rms_err"] <= 0.2)
+        parity["what"] = ("B = 1, 2 M events -> 100 x 440 x 640, 20 sub-windows: Dice + CE, superpixel InfoNCE and per-pixel argmax of the student "
+                          "logits (agreement on the pixels whose oracle top-2 margin exceeds 4 x the rms logit error: random-init logits are near-ties), "
+                          "HIP step vs CPU oracle from identical weights (tests/full_size_parity.py)")
+    except Exception as e:      # must never cost the throughput number
+        parity = {"error": repr(e)[:300]}
+    return {"parity_full_size": parity, "value": round(1.0 / total, 5), "unit": "event-frames/s", "cores": nthr, "kind": "port",
             "cpu_model": model, "physical_cores": phys, "logical_cpus": logical,
             "sample": f"oracle on the host CPU ({model}: {phys} physical cores, {logical} logical; {nthr} torch threads used -- more "
                       f"oversubscribe), ONE full-size event-frame (2 M events -> 100x440x640, B=1 step); voxelizer legs 3 warm-up + 10 "
@@ -197,16 +212,19 @@ def _pmc_pass(counter, timeout_s):
     try:
         subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         import csv
-        n, kib = 0, 0.0
+        n, kib, n1, kib1 = 0, 0.0, 0, 0.0
         for fn in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
             with open(fn) as f:
                 for r in csv.DictReader(f):
                     if r.get("Counter_Name") == counter and DOMINANT.search(r["Kernel_Name"]):
                         n += 1
                         kib += float(r["Counter_Value"])
+                        if DOMINANT_ONE.search(r["Kernel_Name"]):
+                            n1 += 1
+                            kib1 += float(r["Counter_Value"])
         if n == 0:
             raise RuntimeError("no dominant-kernel rows in the counter collection")
-        return n, kib
+        return n, kib, n1, kib1
     finally:
         shutil.rmtree(out, ignore_errors=True)
 
@@ -217,10 +235,15 @@ def pmc_traffic(timeout_s=420):
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
     try:
-        nf, f_kib = _pmc_pass("FETCH_SIZE", timeout_s)
-        nw, w_kib = _pmc_pass("WRITE_SIZE", timeout_s)
-        return {"hbm_bytes_per_launch": round((2 * f_kib / nf + w_kib / nw) * 1024), "read_bytes_per_launch": round(2 * f_kib / nf * 1024),
-                "write_bytes_per_launch": round(w_kib / nw * 1024), "launches_counted": nf}, None
+        nf, f_kib, nf1, f1 = _pmc_pass("FETCH_SIZE", timeout_s)
+        nw, w_kib, nw1, w1 = _pmc_pass("WRITE_SIZE", timeout_s)
+        fam = {"hbm_bytes_per_launch": round((2 * f_kib / nf + w_kib / nw) * 1024), "read_bytes_per_launch": round(2 * f_kib / nf * 1024),
+               "write_bytes_per_launch": round(w_kib / nw * 1024), "launches_counted": nf}
+        one = None
+        if nf1 and nw1:
+            one = {"hbm_bytes_per_launch": round((2 * f1 / nf1 + w1 / nw1) * 1024), "read_bytes_per_launch": round(2 * f1 / nf1 * 1024),
+                   "write_bytes_per_launch": round(w1 / nw1 * 1024), "launches_counted": nf1}
+        return {"family": fam, "dominant_kernel": one}, None
     except Exception as e:      # counters must never cost the throughput number
         return None, repr(e)[:300]
 
@@ -549,7 +572,7 @@ def main():
         if not grp:
             return None
         gn, gms, gfl = (sum(g[i] for g in grp) for i in range(3))
-        return {"name": "conv3x3_halo256_group_kernel (grouped fused-ConvLSTM launch, 256 x 128 tiles; OESS_LSTM256=0: conv3x3_halo_group_kernel<1>)",
+        return {"name": "conv3x3_lstm_w128_kernel (the fused-ConvLSTM levels of a stage of the recurrent encoder in ONE persistent launch: 128 x 128 wave tiles, one wave per SIMD, w128-tiled cell state; csrc/conv_lstm_w128.h)",
                 "launches_per_step": round(gn / steps, 2),
                 "sum_gflop": round(gfl / steps / 1e9, 1), "sum_us": round(gms / steps * 1e3, 1),
                 "achieved": round(gfl / (gms * 1e-3) / 1e12, 1), "unit": "TFLOP/s",
@@ -560,7 +583,7 @@ def main():
         roof = None
         if conv_stats and conv_stats["ms"] > 0:
             ach = conv_stats["flops"] / (conv_stats["ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "conv3x3_halo256_group_kernel (the three fused-ConvLSTM levels of a stage of the recurrent encoder in one launch) + conv3x3_halo_kernel<{0|1}> (3x3 stride-1, row-halo reuse) + conv_fwd_dma_kernel<{128|64},128,2> + conv_fwd_dma_kernel<256,256,2> (large 1x1 layers) + short-K conv_fwd_dma32_kernel<128,..,3> + conv5x5s2_halo{,_group}_kernel (5x5 stride-2 encoders, 2-D input halo; levels 1 + 2 in one launch): implicit-GEMM bf16 MFMA with LDS-DMA operands, every forward / data-gradient launch with Cout > 64; conv FLOPs only",
+            roof = {"bound": "mfma", "kernel": "conv3x3_lstm_w128_kernel (the three fused-ConvLSTM levels of a stage of the recurrent encoder in one persistent launch) + conv3x3_halo_kernel<{0|1}> (3x3 stride-1, row-halo reuse) + conv_fwd_dma_kernel<{128|64},128,2> + conv_fwd_dma_kernel<256,256,2> (large 1x1 layers) + short-K conv_fwd_dma32_kernel<128,..,3> + conv5x5s2_halo{,_group}_kernel (5x5 stride-2 encoders, 2-D input halo; levels 1 + 2 in one launch): implicit-GEMM bf16 MFMA with LDS-DMA operands, every forward / data-gradient launch with Cout > 64; conv FLOPs only",
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                     "launches_per_step": conv_stats["launches"] // a.steps,
@@ -592,6 +615,21 @@ def main():
                                   "its per-launch durations include CU time-sharing and are kept in `timed_region`")
                 roof["serial_event_frames_per_s"] = round(world * B * serial["steps"] / serial["dt"], 2)
                 roof["timed_region"] = timed
+            # Top level = THE dominant kernel (its own launches: per-launch algorithmic FLOPs / summed event durations, serial region
+            # when there is one); the 115-launch conv family it belongs to sits beside it (family_*), the timed region's figures flat.
+            dk = roof.get("dominant_kernel")
+            if dk:
+                roof["family"] = {k: roof[k] for k in ("kernel", "achieved", "frac", "launches_per_step", "avg_launch_us",
+                                                       "algorithmic_gflop_per_launch", "share_of_step_time")}
+                roof["family_frac"], roof["family_achieved"] = roof["frac"], roof["achieved"]
+                roof.update({"kernel": dk["name"], "achieved": dk["achieved"], "frac": dk["frac"], "launches_per_step": dk["launches_per_step"],
+                             "avg_launch_us": round(dk["sum_us"] / max(dk["launches_per_step"], 1e-9), 2),
+                             "algorithmic_gflop_per_launch": round(dk["sum_gflop"] / max(dk["launches_per_step"], 1e-9), 2),
+                             "share_of_step_time": dk["share_of_step_time"]})
+                tr_ = roof.get("timed_region") or {}
+                if tr_.get("dominant_kernel"):
+                    roof["timed_region_frac"] = tr_["dominant_kernel"]["frac"]
+                    roof["timed_region_family_frac"] = tr_.get("frac")
         out = {"metric": "event-frames/sec fwd+bwd @640x480 B=8", "value": round(value, 2), "unit": "event-frames/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
@@ -622,6 +660,8 @@ def main():
                          "vit_fwd": "maskclip_vit_b16_forward", "teacher_fwd": "dilated_r50_teacher_forward"}
                 out["roofline"]["stage_fracs"] = {k: out["stages"][v].get("frac") for k, v in short.items() if v in out["stages"]}
                 out["roofline"]["stage_ms"] = {k: out["stages"][v].get("ms") for k, v in short.items() if v in out["stages"]}
+                for k, v in out["roofline"]["stage_fracs"].items():        # flat copies: the driver's record keeps only the top level
+                    out["roofline"][k + "_frac"] = v
     # ---- the other single-GPU BASELINE configurations, same timing protocol
     if extras and a.workload == "frame2voxel_pixel_distill":
         del wl
@@ -695,9 +735,11 @@ def main():
             torch.cuda.empty_cache()
             tr, err = pmc_traffic()
             if tr is not None:
-                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                one = tr["dominant_kernel"] or tr["family"]
+                out["roofline"]["traffic"] = one["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_detail"] = dict(tr, method="2 rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over a 1+1-step child "
-                                                                    "of this command, gfx950 read correction x2")
+                                                                    "of this command, gfx950 read correction x2; `traffic` = the dominant "
+                                                                    "kernel's launches, `family` = all launches of its conv family")
             else:
                 out["roofline"]["traffic_error"] = err
         if not a.no_cpu_baseline and world == 1:
@@ -705,6 +747,7 @@ def main():
             sample = _synth.dsec_raw_events(NWIN * N_PER, H_SENSOR, W_SENSOR, seed=1205)
             try:
                 out["cpu_baseline"] = cpu_baseline(sample, _synth.rectify_map(H_SENSOR, W_SENSOR))
+                out["parity_full_size"] = out["cpu_baseline"].pop("parity_full_size", None)
             except Exception as e:      # the baseline must never cost the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))

@@ -2565,6 +2565,13 @@ int oess_convlstm_w128_group_bf16(const oess_convlstm_desc_t* d, int n, oess_str
         double loop = 0;
         for (int k = 0; k < 12; ++k) { fprintf(stderr, "%9.0f%s", sum[k] / sc.grid, (k & 3) == 3 ? " |" : ""); loop += sum[k] / sc.grid; }
         fprintf(stderr, " %9.0f %9.0f %9.0f %5.1f   loop %9.0f\n", sum[12] / sc.grid, sum[13] / sc.grid, sum[14] / sc.grid, sum[15] / sc.grid, loop);
+        double mn = 1e30, mx = 0, mean = 0;
+        for (int b = 0; b < sc.grid; ++b) {
+            double t = 0;
+            for (int k = 0; k < 15; ++k) t += st[((size_t)b * 4) * 16 + k];
+            mn = t < mn ? t : mn; mx = t > mx ? t : mx; mean += t / sc.grid;
+        }
+        fprintf(stderr, "  stamped cycles per workgroup: min %.0f mean %.0f max %.0f\n", mn, mean, mx);
     }
 #endif
     return OESS_OK;

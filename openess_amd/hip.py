@@ -742,7 +742,7 @@ def convlstm_w128_group(problems):
         e1.record()
         t["events"].append((e0, e1))
         t["flops"] += flops
-        t.setdefault("keys", []).extend(keys)
+        t.setdefault("keys", []).append((("group",) + tuple(k_[0] for k_ in keys), flops))
     return True
 
 
