@@ -109,9 +109,15 @@ def _worker(wid, dataset, ring, slot_bytes, tasks, done, base_seed):
             return
         epoch, seq, slot, indices = job
         try:
-            arena = Arena(ring[slot * slot_bytes:(slot + 1) * slot_bytes])
-            batch = collate([dataset[i] for i in indices], arena=arena)
-            done.put((epoch, seq, slot, _encode(batch), None))
+            samples = [dataset[i] for i in indices]
+            try:
+                batch = collate(samples, arena=Arena(ring[slot * slot_bytes:(slot + 1) * slot_bytes]))
+                done.put((epoch, seq, slot, _encode(batch), None))
+            except MemoryError:
+                # this batch is larger than the slot (slot_bytes is an estimate from the first batch): collate it on the heap and
+                # ship it by value -- three host copies instead of one for THIS batch, but the epoch goes on.  ('__heap__' tells
+                # the consumer that the slot holds nothing.)
+                done.put((epoch, seq, slot, ('__heap__', collate(samples)), None))
         except Exception:                                        # reported to the consumer, which raises
             done.put((epoch, seq, slot, None, traceback.format_exc()))
 
@@ -154,11 +160,18 @@ class PinnedRingLoader:
         self._closed = False
         self._epoch = 0                         # an iteration abandoned half-way leaves tasks in flight: their results are dropped
         self._outstanding = 0                   # tasks sent - results received, over all epochs
+        self._ready = {}                        # seq -> (slot, spec) of the running iteration: received, not yet delivered
+        self._heap_warned = False
 
     def _estimate_slot_bytes(self):
         """One batch through the plain collate on this process: its tensor bytes + 25 % (ragged event counts) + alignment slack."""
         n = min(self.batch_size, len(self.dataset))
-        batch = collate([self.dataset[i % len(self.dataset)] for i in range(n)])
+        # the probe batch runs the dataset's (augmenting) __getitem__ in THIS process: put the random streams back afterwards
+        rng = (random.getstate(), np.random.get_state(), torch.get_rng_state())
+        try:
+            batch = collate([self.dataset[i % len(self.dataset)] for i in range(n)])
+        finally:
+            random.setstate(rng[0]); np.random.set_state(rng[1]); torch.set_rng_state(rng[2])
         total = [0]
 
         def walk(o):
@@ -212,36 +225,58 @@ class PinnedRingLoader:
             batches.pop()
         self._epoch += 1
         epoch = self._epoch
-        nxt, want, ready = 0, 0, {}
-        while want < len(batches):
-            self._reclaim(block=False)
-            while nxt < len(batches) and self._free:
-                self._tasks.put((epoch, nxt, self._free.pop(), batches[nxt]))
-                nxt += 1
-                self._outstanding += 1
-            if want in ready:
-                slot, spec = ready.pop(want)
-                want += 1
-                self._last_slot = slot
-                yield _decode(spec, self.ring[slot * self.slot_bytes:(slot + 1) * self.slot_bytes])
-                continue
-            if self._outstanding == 0:
-                self._reclaim(block=True)                        # every slot is with the consumer: wait for its oldest copies
-                continue
-            try:
-                ep, seq, slot, spec, err = self._done.get(timeout=120)
-            except queue.Empty:
-                dead = [p.pid for p in self._procs if not p.is_alive()]
-                raise RuntimeError(f"PinnedRingLoader: no batch for 120 s (dead workers: {dead})")
-            self._outstanding -= 1
-            if ep != epoch:                                      # left over from an iteration the consumer abandoned
-                self._free.append(slot)
-                continue
-            if err is not None:
-                self._free.append(slot)
-                raise RuntimeError("PinnedRingLoader worker failed:\n" + err)
-            ready[seq] = (slot, spec)
+        self._release_ready()                                    # slots parked by an iteration the consumer abandoned
+        nxt, want, ready = 0, 0, self._ready
+        try:
+            while want < len(batches):
+                self._reclaim(block=False)
+                while nxt < len(batches) and self._free:
+                    self._tasks.put((epoch, nxt, self._free.pop(), batches[nxt]))
+                    nxt += 1
+                    self._outstanding += 1
+                if want in ready:
+                    slot, spec = ready.pop(want)
+                    want += 1
+                    if isinstance(spec, tuple) and len(spec) == 2 and spec[0] == '__heap__':
+                        self._free.append(slot)                  # the batch did not fit the slot: it came by value
+                        if not self._heap_warned:
+                            self._heap_warned = True
+                            import warnings
+                            warnings.warn(f"PinnedRingLoader: a batch did not fit its {self.slot_bytes >> 20} MB ring slot and was shipped "
+                                          "through the queue (pageable, three host copies); pass slot_bytes= for the largest batch")
+                        yield spec[1]
+                        continue
+                    self._last_slot = slot
+                    yield _decode(spec, self.ring[slot * self.slot_bytes:(slot + 1) * self.slot_bytes])
+                    continue
+                if self._outstanding == 0:
+                    if not self._free and not self._busy and self._last_slot is None:
+                        raise RuntimeError("PinnedRingLoader: no ring slot can become free (all slots lost); this is a bug in the slot accounting")
+                    self._reclaim(block=True)                    # every slot is with the consumer: wait for its oldest copies
+                    continue
+                try:
+                    ep, seq, slot, spec, err = self._done.get(timeout=120)
+                except queue.Empty:
+                    dead = [p.pid for p in self._procs if not p.is_alive()]
+                    raise RuntimeError(f"PinnedRingLoader: no batch for 120 s (dead workers: {dead})")
+                self._outstanding -= 1
+                if ep != epoch:                                  # left over from an iteration the consumer abandoned
+                    self._free.append(slot)
+                    continue
+                if err is not None:
+                    self._free.append(slot)
+                    raise RuntimeError("PinnedRingLoader worker failed:\n" + err)
+                ready[seq] = (slot, spec)
+        finally:
+            # normal end, `break`, an exception in the consumer, or the generator being dropped: batches received but not delivered
+            # give their slots back (results still in flight are dropped, and their slots freed, by the next iteration's epoch check)
+            self._release_ready()
         self._reclaim(block=False)
+
+    def _release_ready(self):
+        for slot, _ in self._ready.values():
+            self._free.append(slot)
+        self._ready.clear()
 
     def close(self):
         if self._closed:

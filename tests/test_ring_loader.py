@@ -76,12 +76,48 @@ def test_ring_loader_reports_worker_errors_and_small_slots():
                 pass
     finally:
         ld.close()
-    ld = PinnedRingLoader(_ds(8), batch_size=4, num_workers=1, slot_bytes=4096, pin=False)
+    # a slot too small for the batch: the worker collates on the heap and ships the batch by value (a warning, not a dead epoch)
+    ds = _ds(8)
+    ld = PinnedRingLoader(ds, batch_size=4, num_workers=1, slot_bytes=4096, pin=False)
     try:
-        with pytest.raises(RuntimeError, match="too small"):
-            next(iter(ld))
+        with pytest.warns(UserWarning, match="did not fit"):
+            got = list(ld)
+        assert len(got) == 2 and all(_same(b, collate([ds[j] for j in range(i * 4, i * 4 + 4)])) for i, b in enumerate(got))
+        assert sorted(ld._free) == list(range(ld.slots))         # every slot came back
     finally:
         ld.close()
+
+
+def test_ring_loader_many_abandoned_iterations_never_run_out_of_slots():
+    """slots parked with received-but-undelivered batches must return when an iteration is dropped (break, exception,
+    next(iter(loader))); before, a few abandonments emptied the free list and the next epoch spun forever."""
+    ds = _ds(16)
+    ld = PinnedRingLoader(ds, batch_size=4, shuffle=False, num_workers=2, slots=3, pin=False)
+    try:
+        for _ in range(6):
+            for i, b in enumerate(ld):
+                if i == 1:
+                    break
+            next(iter(ld))
+        n = sum(1 for _ in ld)
+        assert n == 4
+        assert len(ld._free) + len(ld._busy) + (ld._last_slot is not None) == ld.slots
+    finally:
+        ld.close()
+
+
+def test_ring_loader_slot_estimate_leaves_the_random_streams_alone():
+    import random
+    import numpy as np
+    torch.manual_seed(7); np.random.seed(7); random.seed(7)
+    want = (torch.rand(1).item(), np.random.rand(), random.random())
+    torch.manual_seed(7); np.random.seed(7); random.seed(7)
+    ld = PinnedRingLoader(_ds(8), batch_size=4, num_workers=1, pin=False)        # runs the probe batch in this process
+    try:
+        got = (torch.rand(1).item(), np.random.rand(), random.random())
+    finally:
+        ld.close()
+    assert got[1:] == want[1:]           # (the loader draws ONE int64 from torch's stream for its base seed, as DataLoader does)
 
 
 def test_arena_views_are_aligned_and_disjoint():
@@ -109,5 +145,50 @@ def test_ring_loader_abandoned_iteration_does_not_leak_into_the_next():
                 assert _same(b, collate([ds[j] for j in range(i * 4, i * 4 + 4)])), (rep, i)
                 n += 1
             assert n == 4
+    finally:
+        ld.close()
+
+
+@pytest.mark.gpu
+def test_ring_loader_pinned_ring_with_forked_workers_feeds_async_copies():
+    """The product configuration: the ring page-locked with hipHostRegister BEFORE the workers fork, batches copied to the device on a
+    side stream straight out of their slot, the slot handed back behind the HIP event of those copies (two epochs over 3 slots)."""
+    torch.cuda.init()
+    ds = _ds(24)
+    ld = PinnedRingLoader(ds, batch_size=4, shuffle=False, num_workers=2, slots=3, pin=True)
+    side = torch.cuda.Stream()
+
+    def to_dev(o):
+        if torch.is_tensor(o):
+            return o.to("cuda", non_blocking=True)
+        if isinstance(o, dict):
+            return {k: to_dev(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return type(o)(to_dev(v) for v in o)
+        return o
+
+    def to_host(o):
+        if torch.is_tensor(o):
+            return o.cpu()
+        if isinstance(o, dict):
+            return {k: to_host(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return type(o)(to_host(v) for v in o)
+        return o
+    try:
+        assert ld.pinned, "hipHostRegister of the ring failed on the GPU box"
+        for epoch in range(2):
+            got = []
+            for b in ld:
+                with torch.cuda.stream(side):
+                    d = to_dev(b)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                ld.consumed_after(ev)
+                got.append(d)
+            torch.cuda.synchronize()
+            assert len(got) == 6
+            for i, d in enumerate(got):
+                assert _same(to_host(d), collate([ds[j] for j in range(i * 4, i * 4 + 4)])), (epoch, i)
     finally:
         ld.close()
