@@ -709,6 +709,18 @@ def main():
             out["train_loop"]["torch_dataloader_10_workers"] = {"value": old["value"], "vs_headline": round(old["value"] / out["value"], 3)}
         except Exception as e:      # never cost the headline
             out["train_loop"] = {"error": repr(e)[:300]}
+        # 8-GPU dry run of the host side: eight 2-worker loader pools drained by one process on this box, every
+        # batch copied to the device out of its pinned slot; to be read against 8 x the headline (tools/bench_host_pools.py).
+        # In its own process: the pools fork 16 workers, which must not inherit this process's 20 GB of device-side state.
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_host_pools.py"), "--json"], capture_output=True, text=True, timeout=420)
+            pools = json.loads([l for l in r.stdout.split("\n") if l.startswith("{")][-1])
+            pools["vs_8x_headline"] = round(pools["value"] / (8 * out["value"]), 3)
+            if isinstance(out.get("train_loop"), dict):
+                out["train_loop"]["eight_pools_one_process"] = pools
+        except Exception as e:
+            if isinstance(out.get("train_loop"), dict):
+                out["train_loop"]["eight_pools_one_process"] = {"error": repr(e)[:300]}
     if rank == 0 and extras and world == 1 and a.workload == "frame2voxel_pixel_distill":
         # BASELINE configs[2] (openess_trainer full path) and configs[4] (fine-tune / linear-probe): the stage-2/3 trainers and
         # OpenESSModel built through train.py's dispatch at the BASELINE size, train_step on a resident batch (tools/bench_stage2.py)

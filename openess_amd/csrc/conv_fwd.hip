@@ -2038,7 +2038,10 @@ namespace {
 struct LstmOut { const float* prev; float* cell; void* h; long long h_stride; int C; };
 
 void conv_set_attrs() {
-    static bool attrs_set = false;
+    static bool set_on[64] = {false};     // the attribute is per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const bool attrs_set = dev >= 0 && dev < 64 && set_on[dev];
     if (!attrs_set) {       // > 64 KiB of dynamic LDS needs an explicit opt-in
         const void* fns[] = {(const void*)&conv_fwd_kernel<128>, (const void*)&conv_fwd_kernel<64>, (const void*)&conv_fwd_kernel<32>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<128, 64, 2, false>, (const void*)&conv_fwd_dma_kernel<128, 32, 2, false>,
@@ -2052,7 +2055,7 @@ void conv_set_attrs() {
                              (const void*)&conv_fwd_dma32_kernel<128, true, 0, 3>, (const void*)&conv5x5s2_halo_kernel<false>,
                              (const void*)&conv5x5s2_halo_kernel<true>, (const void*)&conv5x5s2_halo_group_kernel};
         for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attrs_set = true;
+        if (dev >= 0 && dev < 64) set_on[dev] = true;
     }
 }
 
@@ -2444,6 +2447,9 @@ static int w128_schedule(const ConvArgs* a, int n, W128Sched* out) {
     static std::map<std::vector<int>, W128Sched> cache;
     std::vector<int> key;
     const int grid = num_cus();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    key.push_back(dev);                        // the list lives in this device's memory
     key.push_back(grid);
     for (int i = 0; i < n; ++i) { key.push_back(a[i].tiles_m); key.push_back(a[i].tiles_n); key.push_back(a[i].Cin); }
     std::lock_guard<std::mutex> lk(mu);

@@ -250,8 +250,14 @@ int oess_linear_probe_bwd_f32(const float* x, const float* grad_y, const float* 
     if (g > LP_MAX_ROWS) g = LP_MAX_ROWS;
     const size_t lds = ((size_t)K * K + (size_t)2 * LP_TP * K) * sizeof(float);
     if (lds > 64 * 1024) {          // K = 31, 32: 67-70 KB, above the 64 KB default dynamic-LDS limit
-        static std::once_flag once;
-        std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)&probe_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        // the attribute is PER DEVICE: once per device of this process (a process-wide once-flag left every device but the first at 64 KB)
+        static bool set_on[64] = {false};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !set_on[dev]) {
+            (void)hipFuncSetAttribute((const void*)&probe_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (dev >= 0 && dev < 64) set_on[dev] = true;
+        }
     }
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(probe_bwd_kernel, dim3((unsigned)g), dim3(LP_TP), lds, st, x, grad_y, w, (int64_t)P, K, grad_x, (double*)partials);
