@@ -2446,7 +2446,10 @@ static int w128_schedule(const ConvArgs* a, int n, W128Sched* out) {
     static std::mutex mu;
     static std::map<std::vector<int>, W128Sched> cache;
     std::vector<int> key;
-    const int grid = num_cus();
+    // OESS_W128_GRID (A/B): fewer persistent workgroups than CUs leaves whole CUs to the kernels of the other streams of the product
+    // schedule (a 152 KB / 512-register workgroup shares its CU with nothing)
+    static const int grid_env = [] { const char* e = getenv("OESS_W128_GRID"); return e ? atoi(e) : 0; }();
+    const int grid = (grid_env >= 8 && grid_env <= num_cus()) ? grid_env / 8 * 8 : num_cus();
     int dev = 0;
     (void)hipGetDevice(&dev);
     key.push_back(dev);                        // the list lives in this device's memory

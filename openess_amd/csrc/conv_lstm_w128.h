@@ -37,6 +37,9 @@
 #ifndef W128_EARLY_CELL
 #define W128_EARLY_CELL 0   // 1: previous-cell loads at the start of the tile's K loop (64 registers live across it)
 #endif
+#ifndef W128_E1_BLOCK
+#define W128_E1_BLOCK 1    // cell-update blocks of 4 cells scheduled together (1, 2 or 4): instruction-level parallelism against registers
+#endif
 #ifndef W128_ABL
 #define W128_ABL 0     // debug (tools/bench_lstm_group.py): 8192 = s_memtime stamps printed by the host after the launch
 #endif
@@ -186,13 +189,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int i = 0; i < H_INSTR; ++i) {
             const int h = (wave * H_INSTR + i) * 8 + lrow;
             const int hp = h - 1;
-            int m_seg, px, drow;
-            if (hp < L0 + 1) { m_seg = m0; px = ox0 + hp; drow = 0; }
-            else {
-                const int h2 = hp - (L0 + 1);
-                const int q = (int)__umulhi((unsigned)h2, mg_wd), r = h2 - q * wd;
-                m_seg = m0 + L0 + q * W; px = r; drow = q + 1;
-            }
+            // branch-free (a divergent if / else costs an exec save / restore per piece): first image row of the tile, or segment q behind it
+            const int h2 = hp - (L0 + 1);
+            const int q = (int)__umulhi((unsigned)(h2 < 0 ? 0 : h2), mg_wd), r = h2 - q * wd;
+            const bool first = h2 < 0;
+            const int m_seg = first ? m0 : m0 + L0 + q * W, px = first ? ox0 + hp : r, drow = first ? 0 : q + 1;
             const bool valid = m_seg < M_s && (m_seg == m0 || m_seg - m0 < 256) && (unsigned)px < (unsigned)W;
             int oy = oy0 + drow;
             const int grow = b0 * H_s + oy;               // row index over the whole batch
@@ -208,12 +209,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int r = wm * 128 + i * 32 + p31;
-            int hr;
-            if (r < L0) hr = r;
-            else {
-                const int t = r - L0, q = (int)__umulhi((unsigned)t, mg_w), rr = t - q * W;
-                hr = L0 + 1 + q * wd + rr;
-            }
+            const int t = r - L0, q = (int)__umulhi((unsigned)(t < 0 ? 0 : t), mg_w), rr = t - q * W;
+            const int hr = t < 0 ? r : L0 + 1 + q * wd + rr;
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 const int h = hr + dx;
@@ -444,7 +441,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(h1), "+v"(h3));
                 const unsigned w0 = pack_bf16x2(h0, h2), w1 = pack_bf16x2(h1, h3);
                 __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{w0, w1}, rsH_t, hv_t[i] + j * 16, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);       // one (pixel block, gate block) at a time
+                if constexpr ((i + 1) % W128_E1_BLOCK == 0) __builtin_amdgcn_sched_barrier(0);   // W128_E1_BLOCK (pixel block, gate block) pairs = 4 x that many cells in flight
             });
         });
 #pragma unroll

@@ -44,6 +44,7 @@ def measure(pools=8, workers=2, batches=12, B=8, warm=2, copy=True):
     from openess_amd.datasets.synthetic_events import SyntheticEvents
     ds = SyntheticEvents(length=(batches + warm) * B, pool=16)          # shared copy-on-write by every pool's workers
     loaders = [PinnedRingLoader(ds, batch_size=B, shuffle=False, drop_last=True, num_workers=workers, slots=workers + 2) for _ in range(pools)]
+    pinned = all(ld.pinned for ld in loaders)
     side = torch.cuda.Stream() if copy else None
     try:
         its = [iter(ld) for ld in loaders]
@@ -70,7 +71,7 @@ def measure(pools=8, workers=2, batches=12, B=8, warm=2, copy=True):
         for ld in loaders:
             ld.close()
     return {"value": round(n * B / dt, 1), "unit": "event-frames/s", "pools": pools, "workers_per_pool": workers, "batches_per_pool": batches,
-            "host_gb_per_s": round(nbytes / dt / 1e9, 2), "mb_per_batch": round(nbytes / max(n, 1) / 1e6, 1), "pinned": all(ld.pinned for ld in loaders),
+            "host_gb_per_s": round(nbytes / dt / 1e9, 2), "mb_per_batch": round(nbytes / max(n, 1) / 1e6, 1), "pinned": pinned,
             "h2d_copies": bool(copy),
             "note": "P PinnedRingLoader pools drained round-robin by one process; every batch copied to the device on a side stream out of "
                     "its pinned slot (one PCIe link for all pools on this box); no training step"}
