@@ -2466,7 +2466,7 @@ static int w128_schedule(const ConvArgs* a, int n, W128Sched* out) {
         for (int p = 0; p < n; ++p) {
             const int nwg = a[p].tiles_m * a[p].tiles_n, q = nwg >> 3, r = nwg & 7;
             const int cnt = q + (x < r ? 1 : 0), base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-            const long long cost = (long long)(a[p].Cin / 64) * 9 * 2420 + 7000;
+            const long long cost = (long long)(a[p].Cin / 64) * 9 * 2330 + 20000;     // measured: cycles per K-slab, per-tile set-up + cell update (profiles/r06_w128_v2_stamps.txt)
             for (int li = 0; li < cnt; ++li) {
                 int best = 0;
                 for (int c = 1; c < per; ++c) if (load[c * 8 + x] < load[best * 8 + x]) best = c;
