@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copy the judged summaries of tools/final_run.sh from gpurun_out/fin/ into profiles/ (tracked), named per round."""
 import json, os, shutil, subprocess, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r05"
+R = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src, dst = "gpurun_out/fin", "profiles"
 pairs = {f"prof_frame2voxel_pixel_distill/step_kernel_stats.csv": f"{R}_step_pixel_distill_kernel_stats.csv",
          f"prof_frame2voxel_full/step_kernel_stats.csv": f"{R}_step_frame2voxel_full_kernel_stats.csv",
@@ -22,7 +22,7 @@ subprocess.run([sys.executable, "tools/mfma_util.py", os.path.join(src, "pmc_mfm
 with open(os.path.join(dst, f"{R}_misc_outputs.txt"), "w") as f:
     for name in ("pytest_gpu.txt", "pytest_gpu_run2.txt", "smoke.txt", "bench_schedule_ab.txt", "bench_no_skew.txt", "aten_probe_frame2recon_full.txt", "bench_torchrun_world1.txt", "train_loop.txt", "png.txt", "deeplab_breakdown.txt",
                  "segmean.txt", "voxelizer_pmc.txt", "stage_deeplab_fwd.txt", "stage_maskclip_fwd.txt", "stage_teacher_fwd.txt",
-                 "vox_raw1.txt", "vox_raw0.txt", "step_sequence.txt"):
+                 "vox_raw1.txt", "vox_raw0.txt", "step_sequence.txt", "lstm_group_ab.txt", "pmc_w128.txt", "pmc_w128_mfma.txt", "host_pools.txt"):
         p = os.path.join(src, name)
         if os.path.exists(p):
             body = [l for l in open(p, errors="replace").read().split("\n") if l.strip() and "amdgpu.ids" not in l and not l.startswith("+")]

@@ -36,6 +36,13 @@ done
 for r in 1 0; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/vox_raw$r -o p -- python tools/bench_voxelizer.py --raw $r --iters 20 > $O/vox_raw$r.txt 2>&1
 done
+# the dominant kernel alone: A/B against the round-5 kernels (interleaved rounds in one process) and its instruction-mix counters
+timeout 600 python tools/bench_lstm_group.py --modes 1,0,4 --rounds 3 > $O/lstm_group_ab.txt 2>&1
+( cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_w128 -o p -- python $GRAFT_REPO_ROOT/tools/bench_lstm_group.py --modes 4 --rounds 1 --iters 5 > /dev/null 2>&1 )
+python tools/pmc_parse.py $O/pmc_w128 "conv3x3_[a-z0-9_]*kernel" > $O/pmc_w128.txt 2>&1 || true
+( cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_w128_mfma -o p -- python $GRAFT_REPO_ROOT/tools/bench_lstm_group.py --modes 4 --rounds 1 --iters 5 > /dev/null 2>&1 )
+python tools/mfma_util.py $O/pmc_w128_mfma > $O/pmc_w128_mfma.txt 2>&1 || true
+{ timeout 400 python tools/bench_host_pools.py --json; timeout 400 python tools/bench_host_pools.py --json --no-copy; timeout 400 python tools/bench_host_pools.py --json --pools 1; } > $O/host_pools.txt 2>&1
 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_mfma -o p -- python bench.py --child --steps 1 --warmup 1 --no-overlap-teacher > $O/pmc_mfma.txt 2>&1
 python tools/mfma_util.py $O/pmc_mfma $O/mfma_util.json > $O/mfma_util.txt 2>&1 || true
 timeout 600 bash tools/pmc_traffic.sh "python tools/bench_voxelizer.py --raw 1 --iters 5" "tri_sort|tri_splat" > $O/voxelizer_pmc.txt 2>&1
