@@ -274,6 +274,8 @@ class _ConvBNTrainFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight, gamma, y, st, out if relu else None)
         ctx.meta = (pw, k, stride, pad, dil, relu, residual is not None)
         ctx.skip_in, ctx.skip_out = skip_in, skip_out
+        if skip_in is not None and ctx.needs_input_grad[0]:
+            skip_in['armed'] = True            # the consumer of the hand-over exists: only now may the block's last node park its gradient
         return from_nhwc(out)
 
     @staticmethod
@@ -302,7 +304,7 @@ class _ConvBNTrainFn(torch.autograd.Function):
         gres = None
         if has_res:
             gres = from_nhwc(dres) if dres is not None else gy                                  # no ReLU: the residual sees dy itself
-        if gres is not None and ctx.skip_out is not None and ctx.needs_input_grad[4]:
+        if gres is not None and ctx.skip_out is not None and ctx.skip_out.get('armed') and ctx.needs_input_grad[4]:
             ctx.skip_out['g'] = nhwc(gres)          # handed to the block's first conv; autograd sees no residual gradient here
             gres = None
         gx_add = None

@@ -122,6 +122,14 @@ class Bottleneck(nn.Module):
         identity = x
         # no downsample: x feeds conv1 AND the residual add -> one shared hand-over slot instead of autograd's gradient sum
         skip = {} if (self.downsample is None and self._one_node_path(x)) else None
+        # A gradient parked by conv3's node that conv1's node never collected (a backward over a subset of the graph) would be a
+        # silently missing term: found at the block's next forward, it raises.
+        last = getattr(self, '_skip_slot', None)
+        if last is not None and 'g' in last:
+            last.clear()
+            raise RuntimeError("Bottleneck: the skip-connection gradient parked by the last backward pass was never consumed "
+                               "(backward over a sub-graph that excluded the block's first conv)")
+        self._skip_slot = skip
         out = conv_bn(self.conv1, self.bn1, x, relu=True, skip_in=skip)
         out = conv_bn(self.conv2, self.bn2, out, relu=True)
         if self.downsample is not None:
