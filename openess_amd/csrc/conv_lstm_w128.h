@@ -48,7 +48,7 @@ constexpr int W128_HALO_BYTES = W128_HROWS * 128;         // 40 960
 constexpr int W128_WST_BYTES = 256 * 128;                 // 32 768
 constexpr int W128_OPER = 2 * W128_HALO_BYTES + 2 * W128_WST_BYTES;   // 147 456
 constexpr int W128_BIAS_FLOATS = 1792;                    // 4 C summed over the (at most three) problems: 256 + 512 + 1024
-constexpr int W128_MAX_LIST = 60;                         // tiles per workgroup
+constexpr int W128_MAX_LIST = 124;                        // tiles per workgroup (B = 8 at 440 x 640: 15)
 constexpr int W128_LDS = W128_OPER + W128_BIAS_FLOATS * 4 + 3 * 128 + (W128_MAX_LIST + 4) * 4;
 
 // per-problem record in LDS (32 ints): 0-1 in, 2-3 packed weights, 4-5 previous cell, 6-7 cell, 8-9 hidden (pointers lo / hi),

@@ -179,7 +179,8 @@ class ConvLSTM(nn.Module):
         g = self.Gates
         C = self.hidden_size
         return (g.kernel_size == (3, 3) and g.padding == (1, 1) and C % 64 == 0 and self.input_size % 64 == 0 and H >= 8
-                and (256 + W - 2) // W + 1 <= H and B * H * W * max(2 * (self.input_size + C), 4 * C) < 2 ** 31 and B * H * W * W < 2 ** 32)
+                and (256 + W - 2) // W + 1 <= H and B * H * W * max(2 * (self.input_size + C), 4 * C) < 2 ** 31 and B * H * W * W < 2 ** 32
+                and ((B * H * W + 255) // 256) * (C // 64) <= 9000)          # per-workgroup tile lists hold 124 entries (three levels: <= 62 at this bound)
 
     @staticmethod
     def cell_nhwc(state):
