@@ -329,6 +329,11 @@ int oess_convlstm_fused_group_bf16(const oess_convlstm_desc_t* problems, int n, 
 size_t oess_convlstm_w128_cell_bytes(long long pixels, int C_hidden);      /* 0 when C_hidden % 64 != 0 */
 int oess_convlstm_w128_cell_relayout(const float* src, float* dst, long long pixels, int C_hidden, int to_tiled, oess_stream_t stream);
 int oess_convlstm_w128_group_bf16(const oess_convlstm_desc_t* problems, int n, oess_stream_t stream);
+/* Host-only: the static tile lists the kernel above walks (one list per persistent workgroup; entry = (problem << 24) | tile of 256
+ * pixels x 256 gate columns, -1 ends a list; problems longest-K first, greedy onto the least loaded workgroup of the tile's XCD).
+ * lists (may be NULL: only *stride is returned) receives grid x *stride ints; capacity = its size in ints.  No device work: the
+ * CPU tests check that every tile of every problem appears exactly once. */
+int oess_convlstm_w128_tile_lists(const int* tiles_m, const int* tiles_n, const int* cin, int n, int grid, int* lists, int capacity, int* stride);
 
 /* n <= 2 INDEPENDENT 5x5 / stride-2 / pad-2 convolutions (out = act(conv(in, w) + bias), arguments as oess_conv2d_fwd_bf16 with
  * R = S = 5, stride 2, pad 2, relu in {0, 1}) in ONE launch: the encoder ConvLayers of levels 1 and 2 of E2VID's recurrent encoder

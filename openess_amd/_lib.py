@@ -68,6 +68,7 @@ SIGNATURES = {
     "oess_convlstm_w128_cell_bytes": (c_sz, [c_ll, c_int]),
     "oess_convlstm_w128_cell_relayout": (c_int, [c_vp, c_vp, c_ll, c_int, c_int, c_vp]),
     "oess_convlstm_w128_group_bf16": (c_int, [c_vp, c_int, c_vp]),
+    "oess_convlstm_w128_tile_lists": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     "oess_conv5x5s2_group_bf16": (c_int, [c_vp, c_int, c_vp]),
     "oess_loss_partials_bytes": (c_sz, []),
     "oess_l1_mean_fwd": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),

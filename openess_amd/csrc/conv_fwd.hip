@@ -2442,22 +2442,8 @@ struct W128Sched { int* dev; int stride; int grid; };
 // contiguous chunk of every problem -- neighbouring tiles share halo rows and weight slabs in that XCD's L2, as in the one-tile
 // kernels -- dealt longest-K first onto the least loaded of the XCD's workgroups (cost = slabs x measured cycles per slab + a
 // per-tile constant), i.e. what a dynamic queue would do, without an atomic and a reset per launch.
-static int w128_schedule(const ConvArgs* a, int n, W128Sched* out) {
-    static std::mutex mu;
-    static std::map<std::vector<int>, W128Sched> cache;
-    std::vector<int> key;
-    // OESS_W128_GRID (A/B): fewer persistent workgroups than CUs leaves whole CUs to the kernels of the other streams of the product
-    // schedule (a 152 KB / 512-register workgroup shares its CU with nothing)
-    static const int grid_env = [] { const char* e = getenv("OESS_W128_GRID"); return e ? atoi(e) : 0; }();
-    const int grid = (grid_env >= 8 && grid_env <= num_cus()) ? grid_env / 8 * 8 : num_cus();
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    key.push_back(dev);                        // the list lives in this device's memory
-    key.push_back(grid);
-    for (int i = 0; i < n; ++i) { key.push_back(a[i].tiles_m); key.push_back(a[i].tiles_n); key.push_back(a[i].Cin); }
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = cache.find(key);
-    if (it != cache.end()) { *out = it->second; return OESS_OK; }
+// pure host part: flat[grid][stride] tile lists ((problem << 24) | tile, -1 = end), every tile of every problem exactly once
+static int w128_tile_lists(const ConvArgs* a, int n, int grid, std::vector<int>* flat, int* stride_out) {
     if (grid < 8 || grid % 8) return OESS_EINVAL;
     const int per = grid / 8;
     std::vector<std::vector<int>> lists(grid);
@@ -2478,8 +2464,30 @@ static int w128_schedule(const ConvArgs* a, int n, W128Sched* out) {
     for (auto& l : lists) longest = l.size() > longest ? l.size() : longest;
     if (longest > (size_t)W128_MAX_LIST) return OESS_EINVAL;
     const int stride = (int)longest + 1;
-    std::vector<int> flat((size_t)grid * stride, -1);
-    for (int b = 0; b < grid; ++b) for (size_t k = 0; k < lists[b].size(); ++k) flat[(size_t)b * stride + k] = lists[b][k];
+    flat->assign((size_t)grid * stride, -1);
+    for (int b = 0; b < grid; ++b) for (size_t k = 0; k < lists[b].size(); ++k) (*flat)[(size_t)b * stride + k] = lists[b][k];
+    *stride_out = stride;
+    return OESS_OK;
+}
+static int w128_schedule(const ConvArgs* a, int n, W128Sched* out) {
+    static std::mutex mu;
+    static std::map<std::vector<int>, W128Sched> cache;
+    std::vector<int> key;
+    // OESS_W128_GRID (A/B): fewer persistent workgroups than CUs leaves whole CUs to the kernels of the other streams of the product
+    // schedule (a 152 KB / 512-register workgroup shares its CU with nothing)
+    static const int grid_env = [] { const char* e = getenv("OESS_W128_GRID"); return e ? atoi(e) : 0; }();
+    const int grid = (grid_env >= 8 && grid_env <= num_cus()) ? grid_env / 8 * 8 : num_cus();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    key.push_back(dev);                        // the list lives in this device's memory
+    key.push_back(grid);
+    for (int i = 0; i < n; ++i) { key.push_back(a[i].tiles_m); key.push_back(a[i].tiles_n); key.push_back(a[i].Cin); }
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) { *out = it->second; return OESS_OK; }
+    std::vector<int> flat;
+    int stride = 0;
+    if (w128_tile_lists(a, n, grid, &flat, &stride) != OESS_OK) return OESS_EINVAL;
     W128Sched sc{nullptr, stride, grid};
     if (hipMalloc((void**)&sc.dev, flat.size() * sizeof(int) + (size_t)grid * 4 * 16 * sizeof(float)) != hipSuccess) return OESS_ELAUNCH;
     if (hipMemcpy(sc.dev, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return OESS_ELAUNCH;
@@ -2490,6 +2498,21 @@ static int w128_schedule(const ConvArgs* a, int n, W128Sched* out) {
 }  // namespace
 
 extern "C" {
+int oess_convlstm_w128_tile_lists(const int* tiles_m, const int* tiles_n, const int* cin, int n, int grid, int* lists, int capacity, int* stride) {
+    if (!tiles_m || !tiles_n || !cin || !stride || n <= 0 || n > 3) return OESS_EINVAL;
+    ConvArgs a[3];
+    memset(a, 0, sizeof(a));
+    for (int i = 0; i < n; ++i) { a[i].tiles_m = tiles_m[i]; a[i].tiles_n = tiles_n[i]; a[i].Cin = cin[i]; }
+    std::vector<int> flat;
+    const int rc = w128_tile_lists(a, n, grid, &flat, stride);
+    if (rc != OESS_OK) return rc;
+    if (lists) {
+        if ((size_t)capacity < flat.size()) return OESS_ENOMEM;
+        memcpy(lists, flat.data(), flat.size() * sizeof(int));
+    }
+    return OESS_OK;
+}
+
 size_t oess_convlstm_w128_cell_bytes(long long pixels, int C_hidden) {
     if (pixels <= 0 || C_hidden <= 0 || (C_hidden & 63)) return 0;
     return (size_t)((pixels + 255) / 256 * 256) * (size_t)C_hidden * 4;
