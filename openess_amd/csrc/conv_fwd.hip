@@ -1132,6 +1132,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo256_group_kernel(ConvGroup g)
 }
 
 #include "conv_lstm_w128.h"
+#include "conv_w128_gemm.h"
 
 // =================================================================================================
 // 5x5 / stride-2 / pad-2 convolutions with a 2-D INPUT HALO in LDS (conv5x5s2_halo_kernel): E2VID's three encoder
@@ -2049,7 +2050,7 @@ void conv_set_attrs() {
                              (const void*)&conv_fwd_dma_kernel<64, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<64, 128, 2, true>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 2, false, 1>, (const void*)&conv_fwd_dma_kernel<128, 128, 2, true, 1>,
                              (const void*)&conv3x3_halo_kernel<0>, (const void*)&conv3x3_halo_kernel<1>, (const void*)&conv3x3_halo_group_kernel<1>,
-                             (const void*)&conv3x3_halo256_group_kernel, (const void*)&conv3x3_lstm_w128_kernel,
+                             (const void*)&conv3x3_halo256_group_kernel, (const void*)&conv3x3_lstm_w128_kernel, (const void*)&conv1x1_w128_kernel,
                              (const void*)&conv_fwd_dma_kernel<256, 256, 2, true>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 4, true, 0, 512>,
                              (const void*)&conv_fwd_dma32_kernel<128, true, 0, 3>, (const void*)&conv5x5s2_halo_kernel<false>,
@@ -2250,6 +2251,18 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
     //      193.0 vs 194.8 event-frames/s, 318 vs 324 on frame2recon_full -- the big tile stays.)
     if (!lstm && bn == 128 && fastk && (Cout % 256) == 0 && a.Kpad >= 256 && R == 1 && S == 1 && stride == 1) {
         const long long t256 = (long long)((a.M + 255) / 256) * (Cout / 256);
+        // (3a) the same layers, bias-free and followed by a BatchNorm (raw bf16 result + tile statistics; the frozen teacher's conv1 /
+        //      conv3 / downsample layers), >= 4 tiles per CU: persistent workgroups on 128 x 128 wave tiles (conv_w128_gemm.h).
+        //      OESS_W128_GEMM=0 keeps rule (3b) (A/B).
+        const int use_w128 = [] { const char* e = getenv("OESS_W128_GEMM"); return e ? atoi(e) : 1; }();
+        const long long out_extent = ((long long)a.M - 1) * out_pix_stride * 2 + (long long)Cout * 2;
+        if (use_w128 && t256 >= 4ll * num_cus() && !bias && !relu && !residual && !out_f32 && a.Kpad == Cin && (out_pix_stride & 7) == 0 &&
+            (((uintptr_t)out_bf16) & 15) == 0 && out_extent < 0x7ffffff0ll && (long long)Cout * a.Kpad * 2 < 0x7ffffff0ll) {
+            a.tiles_m = (a.M + 255) / 256; a.tiles_n = Cout / 256;
+            hipLaunchKernelGGL(conv1x1_w128_kernel, dim3(num_cus() / 8 * 8), dim3(256), (size_t)G128_LDS, st, a);
+            OESS_HIP(hipGetLastError());
+            return OESS_OK;
+        }
         if (t256 >= 400) {
             a.tiles_m = (a.M + 255) / 256; a.tiles_n = Cout / 256;
             size_t lds = (size_t)2 * 512 * 128;                                          // 2 stages x (256 + 256) rows x 128 B

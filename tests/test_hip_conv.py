@@ -470,6 +470,50 @@ def test_convlstm_w128_group_matches_fused_launches(geoms):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Cin,Cout,in_extra,out_extra", [
+    (1, 256, 256, 256, 1024, 0, 0),        # 1 024 tiles, 4 K-slabs
+    (1, 250, 263, 320, 1024, 64, 0),       # ragged last m-tile, 5 K-slabs (the six-fold unrolled loop leaves early), input a channel slice
+    (2, 128, 257, 1024, 1024, 0, 256),     # 16 K-slabs, output a channel slice of a wider buffer
+    (8, 110, 160, 512, 2048, 0, 0),        # a teacher layer at the BASELINE size
+])
+def test_conv1x1_w128_equals_the_256_tile_kernel(B, H, W, Cin, Cout, in_extra, out_extra, monkeypatch):
+    """conv1x1_w128_kernel (conv_w128_gemm.h: persistent workgroups, 128 x 128 wave tiles, raw bf16 result + BatchNorm tile statistics)
+    against conv_fwd_dma_kernel<256, 256> on the same call (OESS_W128_GEMM=0): the same products in the same order -> identical bf16
+    outputs; the statistics are sums of the same stored values in another order -> equal to fp32 rounding, totals to 1e-5."""
+    import torch
+    from openess_amd import hip
+    torch.manual_seed(Cin + Cout)
+    dev = "cuda"
+    xb = (torch.randn(B, H, W, Cin + in_extra, device=dev) * 0.5).bfloat16()
+    x = xb[..., in_extra // 2: in_extra // 2 + Cin] if in_extra else xb
+    w = torch.randn(Cout, Cin, 1, 1, device=dev) * (1.0 / Cin ** 0.5)
+    packed = hip.pack_conv_weight(w)
+    M = B * H * W
+    tiles = (M + 127) // 128
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("OESS_W128_GEMM", mode)
+        ob = torch.full((B, H, W, Cout + out_extra), 3.0, device=dev, dtype=torch.bfloat16)
+        out = ob[..., out_extra // 2: out_extra // 2 + Cout] if out_extra else ob
+        part = torch.full((tiles, 2, Cout), 7.0, device=dev)
+        hip.conv2d_nhwc(x, packed, None, Cout, 1, 1, 1, 0, 1, out=out, tile_stats=part)
+        res[mode] = (ob.clone(), part.clone())
+    assert torch.equal(res["0"][0], res["1"][0])
+    if out_extra:
+        assert float((res["1"][0][..., :out_extra // 2].float() - 3.0).abs().max()) == 0           # neighbours of the slice untouched
+    t0, t1 = res["0"][1].double().sum(0), res["1"][1].double().sum(0)
+    assert torch.allclose(t0, t1, rtol=1e-5, atol=1e-3), float((t0 - t1).abs().max())
+    # per-128-row statistics of the new kernel against the stored tensor itself
+    y = (res["1"][0][..., out_extra // 2: out_extra // 2 + Cout] if out_extra else res["1"][0]).reshape(M, Cout).float()
+    pad = tiles * 128 - M
+    yp = torch.cat([y, torch.zeros(pad, Cout, device=dev)]) if pad else y
+    s1 = yp.reshape(tiles, 128, Cout).double().sum(1)
+    s2 = (yp.reshape(tiles, 128, Cout).double() ** 2).sum(1)
+    assert torch.allclose(res["1"][1][:, 0].double(), s1, rtol=1e-4, atol=1e-2)
+    assert torch.allclose(res["1"][1][:, 1].double(), s2, rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.gpu
 def test_convlstm_fused_rejects_aliasing_and_bad_shapes():
     import torch
     from openess_amd import hip
