@@ -22,7 +22,7 @@ subprocess.run([sys.executable, "tools/mfma_util.py", os.path.join(src, "pmc_mfm
 with open(os.path.join(dst, f"{R}_misc_outputs.txt"), "w") as f:
     for name in ("pytest_gpu.txt", "pytest_gpu_run2.txt", "smoke.txt", "bench_schedule_ab.txt", "bench_no_skew.txt", "aten_probe_frame2recon_full.txt", "bench_torchrun_world1.txt", "train_loop.txt", "png.txt", "deeplab_breakdown.txt",
                  "segmean.txt", "voxelizer_pmc.txt", "stage_deeplab_fwd.txt", "stage_maskclip_fwd.txt", "stage_teacher_fwd.txt",
-                 "vox_raw1.txt", "vox_raw0.txt", "step_sequence.txt", "lstm_group_ab.txt", "pmc_w128.txt", "pmc_w128_mfma.txt", "host_pools.txt"):
+                 "vox_raw1.txt", "vox_raw0.txt", "step_sequence.txt", "lstm_group_ab.txt", "pmc_w128.txt", "pmc_w128_mfma.txt", "host_pools.txt", "conv1x1_ab.txt", "bench_gemm_ab.txt"):
         p = os.path.join(src, name)
         if os.path.exists(p):
             body = [l for l in open(p, errors="replace").read().split("\n") if l.strip() and "amdgpu.ids" not in l and not l.startswith("+")]
