@@ -1700,17 +1700,25 @@ class _Dropout(torch.autograd.Function):
         return gx.permute(0, 3, 1, 2), None, None, None
 
 
-def dropout(x, p, training=True):
-    """nn.Dropout(p) on a channels_last bf16 map (models/deeplabv3.py:343): Philox mask keyed by (torch.initial_seed(), a
-    per-process call counter, element), recomputed in the backward pass instead of stored.  Reproducible under torch.manual_seed."""
+def dropout(x, p, training=True, owner=None):
+    """nn.Dropout(p) on a channels_last bf16 map (models/deeplabv3.py:343): Philox mask keyed by (torch.initial_seed(), a call
+    counter, element), recomputed in the backward pass instead of stored.  `owner` (the nn.Dropout module) carries its OWN counter:
+    the mask sequence of a model then depends on that model's calls only, not on what other models of the process did (ADVICE r5);
+    without an owner the counter is the process-wide one.  Reproducible under torch.manual_seed."""
     global _DROPOUT_CALLS
     if not training or p <= 0.0:
         return x
     _need_gpu(x)
     if x.dtype != torch.bfloat16 or x.stride(1) != 1 or x.shape[1] % 8:
         raise ValueError("dropout needs a channels_last bf16 tensor with C % 8 == 0")
-    _DROPOUT_CALLS += 1
-    return _Dropout.apply(x, float(p), int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, _DROPOUT_CALLS)
+    if owner is not None:
+        calls = getattr(owner, "_oess_dropout_calls", 0) + 1
+        owner._oess_dropout_calls = calls
+        calls += 1 << 40                                         # own sequence: never collides with the process-wide counter
+    else:
+        _DROPOUT_CALLS += 1
+        calls = _DROPOUT_CALLS
+    return _Dropout.apply(x, float(p), int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, calls)
 
 
 class _ASPPPoolBranch(torch.autograd.Function):

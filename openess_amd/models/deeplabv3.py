@@ -109,7 +109,7 @@ class ASPP(nn.Module):
         y = conv_bn(self.project[0], self.project[1], res, relu=True)
         drop = self.project[3]
         if drop.training and drop.p > 0 and y.is_cuda and y.dtype == torch.bfloat16 and y.stride(1) == 1 and y.shape[1] % 8 == 0:
-            return hip.dropout(y, drop.p, True)            # Philox mask recomputed in the backward pass (nn.Dropout(0.1), :343)
+            return hip.dropout(y, drop.p, True, owner=drop)            # Philox mask recomputed in the backward pass (nn.Dropout(0.1), :343)
         return drop(y)
 
 
