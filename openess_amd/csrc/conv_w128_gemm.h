@@ -18,6 +18,8 @@
 //  * tiles are dealt statically: workgroup b (XCD b % 8) walks every 32nd tile of its XCD's contiguous chunk, n-tiles of one
 //    m-tile adjacent (the pixel rows are then read once from HBM and again from that XCD's L2).
 // Takes: R = S = 1, stride 1, Cin % 64 == 0, Cout % 256 == 0, no bias / activation / residual, bf16 output.
+// one DPP reduction step on four independent registers (operands %0..%3 of the asm statement)
+#define G128_DPP4(CTRL) "v_add_f32_dpp %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\tv_add_f32_dpp %2, %2, %2 " CTRL "\n\tv_add_f32_dpp %3, %3, %3 " CTRL "\n\t"
 constexpr int G128_STAGE = 256 * 128;                     // 32 768 bytes: one operand stage
 constexpr int G128_LDS = 5 * G128_STAGE;                  // 163 840: [pixels 0][pixels 1][weights 0][weights 1][pixels 2] (ds_read immediates are 16 bits)
 constexpr int g128_pstage_byte(int st) { return st == 2 ? 4 * G128_STAGE : st * G128_STAGE; }
@@ -234,31 +236,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     }
                 }
                 // channel quadruples (q, q + 1) of the lane pair (l, l ^ 32) -> eight consecutive channels per lane: 16-byte stores
-                _Pragma("unroll") for (int qq = 0; qq < 4; qq += 2) {
-                    unsigned x0 = pk[qq][0], x1 = pk[qq][1], y0 = pk[qq + 1][0], y1 = pk[qq + 1][1];
-                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(y0));
-                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x1), "+v"(y1));
-                    // lane < 32: (x0, x1) = its own channels 8 qq .. + 3, (y0, y1) = the partner's 8 qq + 4 .. + 7; lane >= 32: quadruple qq + 1
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{x0, x1, y0, y1}, rsO, ov_t[i] + (j * 32 + qq * 8) * 2, 0, 0);
-                }
+                // (one asm block: only the first swap can follow the VALU write of its operands closely enough to need wait states)
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\tv_permlane32_swap_b32 %4, %6\n\tv_permlane32_swap_b32 %5, %7"
+                             : "+v"(pk[0][0]), "+v"(pk[0][1]), "+v"(pk[1][0]), "+v"(pk[1][1]), "+v"(pk[2][0]), "+v"(pk[2][1]), "+v"(pk[3][0]), "+v"(pk[3][1]));
+                // lane < 32: (pk[qq][0..1], pk[qq+1][0..1]) = its own channels 8 qq .. + 3 and the partner's 8 qq + 4 .. + 7; lane >= 32: quadruple qq + 1
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{pk[0][0], pk[0][1], pk[1][0], pk[1][1]}, rsO, ov_t[i] + (j * 32) * 2, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{pk[2][0], pk[2][1], pk[3][0], pk[3][1]}, rsO, ov_t[i] + (j * 32 + 16) * 2, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             });
             if (with_stats) {
                 // 32-lane sums (lanes of one hi) on the DPP network: row_shr 1, 2, 4, 8 inside the 16-lane rows, then row_bcast:15; lane
                 // 31 / 63 end up with the totals of the channels of hi = 0 / 1
-                _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int g = 0; g < 4; ++g) {
-                    float v = s1[q][g], w = s2[q][g];
-                    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
-                                 "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
-                                 "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
-                                 "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
-                                 "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
-                    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
-                                 "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
-                                 "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
-                                 "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
-                                 "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(w));
-                    s1[q][g] = v; s2[q][g] = w;
+                // (four independent chains per asm block: a register's next DPP read is three instructions behind its write, which covers
+                //  the two wait states a VALU write -> DPP read needs without s_nops)
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int g = 0; g < 4; g += 2) {
+                    asm volatile("s_nop 1\n\t"
+                                 G128_DPP4("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                                 G128_DPP4("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                                 G128_DPP4("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                                 G128_DPP4("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                                 G128_DPP4("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                                 : "+v"(s1[q][g]), "+v"(s1[q][g + 1]), "+v"(s2[q][g]), "+v"(s2[q][g + 1]));
                 }
                 // lanes 31 and 63 write their 16 channels x {sum, sumsq} of gate block j: four 16-byte stores each per plane
                 const int chan = n0_t + wn * 128 + j * 32 + 4 * hi;
