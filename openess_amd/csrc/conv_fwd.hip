@@ -2256,7 +2256,7 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
         //      OESS_W128_GEMM=0 keeps rule (3b) (A/B).
         const int use_w128 = [] { const char* e = getenv("OESS_W128_GEMM"); return e ? atoi(e) : 1; }();
         const long long out_extent = ((long long)a.M - 1) * out_pix_stride * 2 + (long long)Cout * 2;
-        if (use_w128 && t256 >= 4ll * num_cus() && !bias && !relu && !residual && !out_f32 && a.Kpad == Cin && (out_pix_stride & 7) == 0 &&
+        if (use_w128 && t256 >= 2ll * num_cus() && !bias && !relu && !residual && !out_f32 && a.Kpad == Cin && (out_pix_stride & 7) == 0 &&
             (((uintptr_t)out_bf16) & 15) == 0 && out_extent < 0x7ffffff0ll && (long long)Cout * a.Kpad * 2 < 0x7ffffff0ll) {
             a.tiles_m = (a.M + 255) / 256; a.tiles_n = Cout / 256;
             hipLaunchKernelGGL(conv1x1_w128_kernel, dim3(num_cus() / 8 * 8), dim3(256), (size_t)G128_LDS, st, a);
