@@ -1133,6 +1133,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo256_group_kernel(ConvGroup g)
 
 #include "conv_lstm_w128.h"
 #include "conv_w128_gemm.h"
+#include "conv3x3_w128.h"
 
 // =================================================================================================
 // 5x5 / stride-2 / pad-2 convolutions with a 2-D INPUT HALO in LDS (conv5x5s2_halo_kernel): E2VID's three encoder
@@ -2050,7 +2051,7 @@ void conv_set_attrs() {
                              (const void*)&conv_fwd_dma_kernel<64, 128, 2, false>, (const void*)&conv_fwd_dma_kernel<64, 128, 2, true>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 2, false, 1>, (const void*)&conv_fwd_dma_kernel<128, 128, 2, true, 1>,
                              (const void*)&conv3x3_halo_kernel<0>, (const void*)&conv3x3_halo_kernel<1>, (const void*)&conv3x3_halo_group_kernel<1>,
-                             (const void*)&conv3x3_halo256_group_kernel, (const void*)&conv3x3_lstm_w128_kernel, (const void*)&conv1x1_w128_kernel,
+                             (const void*)&conv3x3_halo256_group_kernel, (const void*)&conv3x3_lstm_w128_kernel, (const void*)&conv1x1_w128_kernel, (const void*)&conv3x3_w128_kernel,
                              (const void*)&conv_fwd_dma_kernel<256, 256, 2, true>,
                              (const void*)&conv_fwd_dma_kernel<128, 128, 4, true, 0, 512>,
                              (const void*)&conv_fwd_dma32_kernel<128, true, 0, 3>, (const void*)&conv5x5s2_halo_kernel<false>,
@@ -2183,6 +2184,24 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
             size_t lds = (size_t)4 * (BM + 128) * 8 * 16;
             if (lds < epi) lds = epi;
             hipLaunchKernelGGL((conv_fwd_dma_kernel<128, 128, 4, true, 0, 512>), grid, dim3(512), lds, st, a);
+            OESS_HIP(hipGetLastError());
+            return OESS_OK;
+        }
+    }
+    // (2a) the same layers in front of a BatchNorm (raw bf16 result + tile statistics: conv2 of the frozen teacher's dilated
+    //      bottlenecks), Cout % 256 == 0, >= 2 tiles of 256 x 256 per CU: persistent workgroups on 128 x 128 wave tiles
+    //      (conv3x3_w128.h).  OESS_W128_CONV3=0 keeps rule (2) (A/B).
+    if (!capture && !lstm && R == 3 && S == 3 && stride == 1 && pad == dil && fastk && (Cout % 256) == 0 && a.Kpad == 9 * Cin && a.Ho == H && a.Wo == W &&
+        !bias && !relu && !residual && !out_f32 && (out_pix_stride & 7) == 0 && (((uintptr_t)out_bf16) & 15) == 0 && a.mg_w && a.mg_wd) {
+        const int use3 = [] { const char* e = getenv("OESS_W128_CONV3"); return e ? atoi(e) : 1; }();
+        const long long t256 = (long long)((a.M + 255) / 256) * (Cout / 256);
+        const long long out_extent = ((long long)a.M - 1) * out_pix_stride * 2 + (long long)Cout * 2;
+        const int breaks = (256 + W - 2) / W;
+        if (use3 && t256 >= 2ll * num_cus() && dil + 255 + dil * breaks + dil + 1 <= W128_HROWS && breaks + 1 + 2 * dil <= H &&
+            out_extent < 0x7ffffff0ll && (long long)Cout * a.Kpad * 2 < 0x7ffffff0ll && (long long)H * W * W < 0x100000000ll) {
+            if (want_workspace) return OESS_OK;
+            a.tiles_m = (a.M + 255) / 256; a.tiles_n = Cout / 256;
+            hipLaunchKernelGGL(conv3x3_w128_kernel, dim3(num_cus() / 8 * 8), dim3(256), (size_t)W128_OPER, st, a);
             OESS_HIP(hipGetLastError());
             return OESS_OK;
         }

@@ -514,6 +514,45 @@ def test_conv1x1_w128_equals_the_256_tile_kernel(B, H, W, Cin, Cout, in_extra, o
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Cin,Cout,dil,in_extra,out_extra", [
+    (1, 256, 256, 128, 512, 1, 0, 0),       # 512 tiles, 6 macro steps
+    (2, 131, 250, 192, 512, 3, 64, 0),      # ragged last tile, tiles that start mid-row and cross image borders, 9 macro steps (odd), dilation 3, input slice
+    (1, 200, 331, 64, 512, 2, 0, 256),      # odd width, 3 macro steps, output a channel slice
+    (8, 110, 160, 256, 256, 2, 0, 0),       # teacher layer3 conv2 at the BASELINE size
+    (8, 110, 160, 512, 512, 4, 0, 0),       # teacher layer4 conv2
+])
+def test_conv3x3_w128_equals_the_row_halo_kernel(B, H, W, Cin, Cout, dil, in_extra, out_extra, monkeypatch):
+    """conv3x3_w128_kernel (conv3x3_w128.h) against conv3x3_halo_kernel<0> on the same call (OESS_W128_CONV3=0): identical bf16 outputs
+    (same products, same order), BatchNorm tile statistics equal to fp32 rounding."""
+    import torch
+    from openess_amd import hip
+    torch.manual_seed(Cin + Cout + dil)
+    dev = "cuda"
+    xb = (torch.randn(B, H, W, Cin + in_extra, device=dev) * 0.5).bfloat16()
+    x = xb[..., in_extra // 2: in_extra // 2 + Cin] if in_extra else xb
+    w = torch.randn(Cout, Cin, 3, 3, device=dev) * (1.0 / (9 * Cin) ** 0.5)
+    packed = hip.pack_conv_weight(w)
+    M = B * H * W
+    tiles = (M + 127) // 128
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("OESS_W128_CONV3", mode)
+        ob = torch.full((B, H, W, Cout + out_extra), 3.0, device=dev, dtype=torch.bfloat16)
+        out = ob[..., out_extra // 2: out_extra // 2 + Cout] if out_extra else ob
+        part = torch.full((tiles, 2, Cout), 7.0, device=dev)
+        hip.conv2d_nhwc(x, packed, None, Cout, 3, 3, 1, dil, dil, out=out, tile_stats=part)
+        res[mode] = (ob.clone(), part.clone())
+    assert torch.equal(res["0"][0], res["1"][0]), float((res["0"][0].float() - res["1"][0].float()).abs().max())
+    t0, t1 = res["0"][1].double().sum(0), res["1"][1].double().sum(0)
+    assert torch.allclose(t0, t1, rtol=1e-5, atol=1e-3), float((t0 - t1).abs().max())
+    y = (res["1"][0][..., out_extra // 2: out_extra // 2 + Cout] if out_extra else res["1"][0]).reshape(M, Cout).float()
+    pad = tiles * 128 - M
+    yp = torch.cat([y, torch.zeros(pad, Cout, device=dev)]) if pad else y
+    assert torch.allclose(res["1"][1][:, 0].double(), yp.reshape(tiles, 128, Cout).double().sum(1), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(res["1"][1][:, 1].double(), (yp.reshape(tiles, 128, Cout).double() ** 2).sum(1), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.gpu
 def test_convlstm_fused_rejects_aliasing_and_bad_shapes():
     import torch
     from openess_amd import hip
