@@ -2282,6 +2282,9 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
             OESS_HIP(hipGetLastError());
             return OESS_OK;
         }
+        if (getenv("OESS_W128_WHY"))
+            fprintf(stderr, "[oess] 1x1 %d -> %d M %d not on conv1x1_w128_kernel: t256 %lld bias %d relu %d residual %d out_f32 %d Kpad %d ops %lld align %d\n", Cin, Cout, a.M,
+                    t256, bias != nullptr, relu, residual != nullptr, out_f32 != nullptr, a.Kpad, (long long)out_pix_stride, (int)(((uintptr_t)out_bf16) & 15));
         if (t256 >= 400) {
             a.tiles_m = (a.M + 255) / 256; a.tiles_n = Cout / 256;
             size_t lds = (size_t)2 * 512 * 128;                                          // 2 stages x (256 + 256) rows x 128 B

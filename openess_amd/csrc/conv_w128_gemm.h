@@ -19,6 +19,12 @@
 //    m-tile adjacent (the pixel rows are then read once from HBM and again from that XCD's L2).
 // Takes: R = S = 1, stride 1, Cin % 64 == 0, Cout % 256 == 0, no bias / activation / residual, bf16 output.
 // one DPP reduction step on four independent registers (operands %0..%3 of the asm statement)
+#ifndef G128_ABL
+#define G128_ABL 0          // measurement builds: 1 = no output stores, 2 = no statistics, 4 = no DPP reduction, 8 = no epilogue at all
+#endif
+#ifndef G128_AUX
+#define G128_AUX 0          // cache policy of the result stores (gfx950 buffer aux: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
 #define G128_DPP4(CTRL) "v_add_f32_dpp %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\tv_add_f32_dpp %2, %2, %2 " CTRL "\n\tv_add_f32_dpp %3, %3, %3 " CTRL "\n\t"
 constexpr int G128_STAGE = 256 * 128;                     // 32 768 bytes: one operand stage
 constexpr int G128_LDS = 5 * G128_STAGE;                  // 163 840: [pixels 0][pixels 1][weights 0][weights 1][pixels 2] (ds_read immediates are 16 bits)
@@ -45,7 +51,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)out_bytes, 0x00020000);
     const int stat_rows = (M_s + 127) >> 7;
     const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)a.stats, 0, a.stats ? stat_rows * 2 * Cout_s * 4 : 0, 0x00020000);
-    const bool with_stats = a.stats != nullptr;
+    const bool with_stats = a.stats != nullptr && !(G128_ABL & 2);
 
     // fragment addresses: k-step ks of row r reads 16-byte chunk (2 ks + half) ^ ((r >> 1) & 7) of its 128-byte LDS row
     uint32_t pa[MT], pa2[MT], wa[NT][4];                  // pa: pixel stages 0 / 1 (+ immediate), pa2: pixel stage 2
@@ -214,6 +220,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         li += per;
         if (li < cnt) { setup(base + li); fill(); }
 
+        if (G128_ABL & 8) { _Pragma("unroll") for (int t = 0; t < 16; ++t) asm volatile("" : "+a"(acc[t])); stores_in_flight = 0; continue; }
         // ---- epilogue: lane (p31, hi) holds, of tile (i, j), register e = 4 q + g <-> channel j*32 + 8 q + 4 hi + g of pixel i*32 + p31
         W128_FOR(NT, jc, {
             constexpr int j = decltype(jc)::value;
@@ -240,8 +247,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\tv_permlane32_swap_b32 %4, %6\n\tv_permlane32_swap_b32 %5, %7"
                              : "+v"(pk[0][0]), "+v"(pk[0][1]), "+v"(pk[1][0]), "+v"(pk[1][1]), "+v"(pk[2][0]), "+v"(pk[2][1]), "+v"(pk[3][0]), "+v"(pk[3][1]));
                 // lane < 32: (pk[qq][0..1], pk[qq+1][0..1]) = its own channels 8 qq .. + 3 and the partner's 8 qq + 4 .. + 7; lane >= 32: quadruple qq + 1
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{pk[0][0], pk[0][1], pk[1][0], pk[1][1]}, rsO, ov_t[i] + (j * 32) * 2, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{pk[2][0], pk[2][1], pk[3][0], pk[3][1]}, rsO, ov_t[i] + (j * 32 + 16) * 2, 0, 0);
+                if (G128_ABL & 16) {     // timing only: the same bytes as fully coalesced 1 KB pieces (wrong addresses)
+                    const int cb = ((((trow_t >> 1) * tiles_n + (n0_t >> 8)) * 4 + wave) << 15) + lane * 16;
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{pk[0][0], pk[0][1], pk[1][0], pk[1][1]}, rsO, cb + (i * 8 + j * 2) * 1024, 0, G128_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{pk[2][0], pk[2][1], pk[3][0], pk[3][1]}, rsO, cb + (i * 8 + j * 2 + 1) * 1024, 0, G128_AUX);
+                } else
+                if (G128_ABL & 1) asm volatile("" :: "v"(pk[0][0]), "v"(pk[0][1]), "v"(pk[1][0]), "v"(pk[1][1]), "v"(pk[2][0]), "v"(pk[2][1]), "v"(pk[3][0]), "v"(pk[3][1]));
+                else {
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{pk[0][0], pk[0][1], pk[1][0], pk[1][1]}, rsO, ov_t[i] + (j * 32) * 2, 0, G128_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{pk[2][0], pk[2][1], pk[3][0], pk[3][1]}, rsO, ov_t[i] + (j * 32 + 16) * 2, 0, G128_AUX);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
             if (with_stats) {
@@ -249,7 +264,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 // 31 / 63 end up with the totals of the channels of hi = 0 / 1
                 // (four independent chains per asm block: a register's next DPP read is three instructions behind its write, which covers
                 //  the two wait states a VALU write -> DPP read needs without s_nops)
-                _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int g = 0; g < 4; g += 2) {
+                if (!(G128_ABL & 4)) _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int g = 0; g < 4; g += 2) {
                     asm volatile("s_nop 1\n\t"
                                  G128_DPP4("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
                                  G128_DPP4("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
