@@ -2270,14 +2270,19 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
     //      193.0 vs 194.8 event-frames/s, 318 vs 324 on frame2recon_full -- the big tile stays.)
     if (!lstm && bn == 128 && fastk && (Cout % 256) == 0 && a.Kpad >= 256 && R == 1 && S == 1 && stride == 1) {
         const long long t256 = (long long)((a.M + 255) / 256) * (Cout / 256);
-        // (3a) the same layers, bias-free and followed by a BatchNorm (raw bf16 result + tile statistics; the frozen teacher's conv1 /
-        //      conv3 / downsample layers), >= 4 tiles per CU: persistent workgroups on 128 x 128 wave tiles (conv_w128_gemm.h).
+        // (3a) the same layers in front of a BatchNorm (raw bf16 result + tile statistics; the frozen teacher's conv1 / conv3 /
+        //      downsample layers) or with a bias / ReLU (its 2048 -> 256 decoder layer), >= 2 tiles per CU: persistent workgroups on
+        //      128 x 128 wave tiles (conv_w128_gemm.h).
         //      OESS_W128_GEMM=0 keeps rule (3b) (A/B).
         const int use_w128 = [] { const char* e = getenv("OESS_W128_GEMM"); return e ? atoi(e) : 1; }();
         const long long out_extent = ((long long)a.M - 1) * out_pix_stride * 2 + (long long)Cout * 2;
-        if (use_w128 && t256 >= 2ll * num_cus() && !bias && !relu && !residual && !out_f32 && a.Kpad == Cin && (out_pix_stride & 7) == 0 &&
+        if (use_w128 && t256 >= 2ll * num_cus() && (relu == 0 || relu == 1) && !residual && !out_f32 && a.Kpad == Cin && (out_pix_stride & 7) == 0 &&
             (((uintptr_t)out_bf16) & 15) == 0 && out_extent < 0x7ffffff0ll && (long long)Cout * a.Kpad * 2 < 0x7ffffff0ll) {
             a.tiles_m = (a.M + 255) / 256; a.tiles_n = Cout / 256;
+            // non-temporal result stores where the result is >= 4 x the input (256 -> 1024 168 -> 150 us, 512 -> 2048 402 -> 376;
+            // 2 x and reducing layers lose 2-10 % with them: EXPERIMENTS R6-8).  OESS_W128_NT = 0 / 1 forces (A/B).
+            static const int nt_env = [] { const char* e = getenv("OESS_W128_NT"); return e ? atoi(e) : -1; }();
+            a.ksplit = nt_env >= 0 ? nt_env : (Cout >= 4 * Cin);
             hipLaunchKernelGGL(conv1x1_w128_kernel, dim3(num_cus() / 8 * 8), dim3(256), (size_t)G128_LDS, st, a);
             OESS_HIP(hipGetLastError());
             return OESS_OK;

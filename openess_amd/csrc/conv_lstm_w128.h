@@ -34,6 +34,16 @@
 //      * the next tile's first halo + two weight slabs are issued BEFORE the cell update of the current tile and land under it.
 // LDS: [halo 0][halo 1] 2 x 40 KB, [weights 0][weights 1] 2 x 32 KB = 144 KB operands + 8 KB tables, one workgroup per CU.
 // Requires: 3 x 3, dil 1, stride 1, pad 1, Cin % 64 == 0, Cout % 256 == 0, H >= 8, 32-bit buffer offsets (host: w128_eligible).
+// cache policy of the streamed state (gfx950 buffer aux: 2 = nt): previous-cell loads, new-cell stores, hidden stores (measurement knobs)
+#ifndef W128_CELL_LD_AUX
+#define W128_CELL_LD_AUX 0
+#endif
+#ifndef W128_CELL_ST_AUX
+#define W128_CELL_ST_AUX 0
+#endif
+#ifndef W128_H_ST_AUX
+#define W128_H_ST_AUX 0
+#endif
 #ifndef W128_EARLY_CELL
 #define W128_EARLY_CELL 0   // 1: previous-cell loads at the start of the tile's K loop (64 registers live across it)
 #endif
@@ -358,7 +368,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (has_prev) {
     #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsP, cell_voff + r * 1024, 0, 0);
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsP, cell_voff + r * 1024, 0, W128_CELL_LD_AUX);
                     cellreg[r] = f32x4_t{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
                 }
             } else {
@@ -440,14 +450,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(h0), "+v"(h2));
                 asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(h1), "+v"(h3));
                 const unsigned w0 = pack_bf16x2(h0, h2), w1 = pack_bf16x2(h1, h3);
-                __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{w0, w1}, rsH_t, hv_t[i] + j * 16, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{w0, w1}, rsH_t, hv_t[i] + j * 16, 0, W128_H_ST_AUX);
                 if constexpr ((i + 1) % W128_E1_BLOCK == 0) __builtin_amdgcn_sched_barrier(0);   // W128_E1_BLOCK (pixel block, gate block) pairs = 4 x that many cells in flight
             });
         });
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(cellreg[r][0]), __float_as_uint(cellreg[r][1]), __float_as_uint(cellreg[r][2]), __float_as_uint(cellreg[r][3])},
-                                                   rsC_t, cell_voff_t + r * 1024, 0, 0);
+                                                   rsC_t, cell_voff_t + r * 1024, 0, W128_CELL_ST_AUX);
         W128_STAMP_TAKE(); if constexpr (W128_STAMP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); W128_STAMP_ADD(14);
         entry = next; has_prev = has_prev_n;
     }

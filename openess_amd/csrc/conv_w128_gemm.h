@@ -52,6 +52,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int stat_rows = (M_s + 127) >> 7;
     const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)a.stats, 0, a.stats ? stat_rows * 2 * Cout_s * 4 : 0, 0x00020000);
     const bool with_stats = a.stats != nullptr && !(G128_ABL & 2);
+    const bool nt_out = a.ksplit != 0;                    // host rule: Cout >= 4 Cin
+    const bool with_bias = a.bias != nullptr, with_relu = a.relu == 1;
 
     // fragment addresses: k-step ks of row r reads 16-byte chunk (2 ks + half) ^ ((r >> 1) & 7) of its 128-byte LDS row
     uint32_t pa[MT], pa2[MT], wa[NT][4];                  // pa: pixel stages 0 / 1 (+ immediate), pa2: pixel stage 2
@@ -225,11 +227,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         W128_FOR(NT, jc, {
             constexpr int j = decltype(jc)::value;
             float s1[4][4], s2[4][4];                     // [q][g] sums over the wave's four pixel blocks (values as stored)
+            f32x4_t bq[4];                                // bias of the lane's channels j*32 + 8 q + 4 hi + g (layers with a bias: no BatchNorm behind them)
+            if (with_bias) {
+                const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, Cout_s * 4, 0x00020000);
+                _Pragma("unroll") for (int q = 0; q < 4; ++q)
+                    bq[q] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsBias, (n0_t + wn * 128 + j * 32 + 8 * q + 4 * hi) * 4, 0, 0));
+            }
             _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int g = 0; g < 4; ++g) { s1[q][g] = 0.f; s2[q][g] = 0.f; }
             W128_FOR(MT, ic, {
                 constexpr int i = decltype(ic)::value;
                 asm volatile("" : "+a"(acc[i * 4 + j]));   // the tile stays in its AGPRs up to here (conv_lstm_w128.h)
-                const f32x16_t tv = acc[i * 4 + j];
+                f32x16_t tv = acc[i * 4 + j];
+                if (with_bias) { _Pragma("unroll") for (int e = 0; e < 16; ++e) tv[e] += bq[e >> 2][e & 3]; }
+                if (with_relu) { _Pragma("unroll") for (int e = 0; e < 16; ++e) tv[e] = __builtin_fmaxf(tv[e], 0.f); }
                 unsigned pk[4][2];
                 _Pragma("unroll") for (int q = 0; q < 4; ++q) {
                     pk[q][0] = pack_bf16x2(tv[q * 4 + 0], tv[q * 4 + 1]);
@@ -253,7 +263,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{pk[2][0], pk[2][1], pk[3][0], pk[3][1]}, rsO, cb + (i * 8 + j * 2 + 1) * 1024, 0, G128_AUX);
                 } else
                 if (G128_ABL & 1) asm volatile("" :: "v"(pk[0][0]), "v"(pk[0][1]), "v"(pk[1][0]), "v"(pk[1][1]), "v"(pk[2][0]), "v"(pk[2][1]), "v"(pk[3][0]), "v"(pk[3][1]));
-                else {
+                else if (nt_out) {       // 4 x-expanding layers: the result (4 x the input) streams past the L2s (R6-8: -6 ... -10 %)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{pk[0][0], pk[0][1], pk[1][0], pk[1][1]}, rsO, ov_t[i] + (j * 32) * 2, 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{pk[2][0], pk[2][1], pk[3][0], pk[3][1]}, rsO, ov_t[i] + (j * 32 + 16) * 2, 0, 2);
+                } else {
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{pk[0][0], pk[0][1], pk[1][0], pk[1][1]}, rsO, ov_t[i] + (j * 32) * 2, 0, G128_AUX);
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{pk[2][0], pk[2][1], pk[3][0], pk[3][1]}, rsO, ov_t[i] + (j * 32 + 16) * 2, 0, G128_AUX);
                 }

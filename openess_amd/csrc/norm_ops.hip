@@ -179,6 +179,12 @@ __global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __res
 // Thread layout of both apply kernels: lane_c = channel chunk (8 channels) is FIXED per thread, rows = THREADS / (C/8)
 // pixels per block iteration, grid = (pixel chunks, G): no per-element 64-bit divisions, per-channel constants stay in
 // registers for the whole loop.  Needs C/8 <= THREADS (C <= 2048).
+__device__ __forceinline__ uint4 nt_load16(const uint16_t* p) {
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    const u4v t = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(p));
+    return make_uint4(t[0], t[1], t[2], t[3]);
+}
+template <int NT>
 __global__ __launch_bounds__(THREADS) void apply_kernel(const uint16_t* __restrict__ x, int64_t xps,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const uint16_t* __restrict__ res, int64_t rps, int relu,
@@ -196,14 +202,20 @@ __global__ __launch_bounds__(THREADS) void apply_kernel(const uint16_t* __restri
         const int64_t pix = base + p;
         Pack8 v, r;
         float f[8];
-        v.q = *reinterpret_cast<const uint4*>(x + pix * xps + c0);
-        if (res) r.q = *reinterpret_cast<const uint4*>(res + pix * rps + c0);
+        // NT & 1: the raw conv result is dead after this pass, NT & 2: so is the residual (the block input) -- streaming loads
+        if (NT & 1) v.q = nt_load16(x + pix * xps + c0); else v.q = *reinterpret_cast<const uint4*>(x + pix * xps + c0);
+        if (res) { if (NT & 2) r.q = nt_load16(res + pix * rps + c0); else r.q = *reinterpret_cast<const uint4*>(res + pix * rps + c0); }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             f[k] = bf16_to_f32(v.h[k]) * sc[k] + sh[k];
             if (res) f[k] += bf16_to_f32(r.h[k]);
             if (relu) f[k] = fmaxf(f[k], 0.f);
         }
+        if (NT & 4) {
+            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+            const uint4 o = pack_bf16x8(f);
+            __builtin_nontemporal_store(u4v{o.x, o.y, o.z, o.w}, reinterpret_cast<u4v*>(out + pix * ops + c0));
+        } else
         *reinterpret_cast<uint4*>(out + pix * ops + c0) = pack_bf16x8(f);
     }
 }
@@ -444,7 +456,7 @@ template <int LPP>
 __global__ __launch_bounds__(THREADS) void bilinear_l2_vec_kernel(const uint16_t* __restrict__ in, int64_t ips, int B, int H,
                                                                   int W, int scale, int normalize,
                                                                   uint16_t* __restrict__ out, int64_t ops, int run_len,
-                                                                  float* __restrict__ inv_out) {
+                                                                  float* __restrict__ inv_out, int nt_out) {
     const int Ho = H * scale, Wo = W * scale;
     const float ry = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
     const float rx = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
@@ -507,6 +519,11 @@ __global__ __launch_bounds__(THREADS) void bilinear_l2_vec_kernel(const uint16_t
             for (int k = 0; k < 8; ++k) v[k] *= inv;
             if (inv_out && sub == 0) inv_out[orow + ox] = inv;     // the L2 adjoint's 1 / |x| (training form)
         }
+        if (nt_out) {           // a result larger than the memory-side cache, read much later (the teacher's 1.15 GB feature map)
+            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+            const uint4 o = pack_bf16x8(v);
+            __builtin_nontemporal_store(u4v{o.x, o.y, o.z, o.w}, reinterpret_cast<u4v*>(out + (orow + ox) * ops + sub * 8));
+        } else
         *reinterpret_cast<uint4*>(out + (orow + ox) * ops + sub * 8) = pack_bf16x8(v);
     }
 }
@@ -824,9 +841,13 @@ int oess_norm_apply_nhwc_bf16(const void* x, long long x_pix_stride, const float
         (out_pix_stride & 7) || (residual && (res_pix_stride & 7)))
         return OESS_EINVAL;
     if ((C >> 3) > THREADS) return OESS_EINVAL;
-    hipLaunchKernelGGL(apply_kernel, apply_grid(pixels_per_group, G, C), dim3(THREADS), 0,
-                       (hipStream_t)stream, (const uint16_t*)x, (int64_t)x_pix_stride, scale, shift, (const uint16_t*)residual,
-                       (int64_t)res_pix_stride, relu, (int64_t)pixels_per_group, G, C, (uint16_t*)out, (int64_t)out_pix_stride);
+    static const int nt = [] { const char* e = getenv("OESS_APPLY_NT"); return e ? atoi(e) : 2; }();
+#define OESS_APPLY_LAUNCH(NT) hipLaunchKernelGGL(apply_kernel<NT>, apply_grid(pixels_per_group, G, C), dim3(THREADS), 0, \
+                       (hipStream_t)stream, (const uint16_t*)x, (int64_t)x_pix_stride, scale, shift, (const uint16_t*)residual, \
+                       (int64_t)res_pix_stride, relu, (int64_t)pixels_per_group, G, C, (uint16_t*)out, (int64_t)out_pix_stride)
+    if (nt == 1) OESS_APPLY_LAUNCH(1); else if (nt == 2) OESS_APPLY_LAUNCH(2); else if (nt == 3) OESS_APPLY_LAUNCH(3);
+    else if (nt == 6) OESS_APPLY_LAUNCH(6); else if (nt == 4) OESS_APPLY_LAUNCH(4); else OESS_APPLY_LAUNCH(0);
+#undef OESS_APPLY_LAUNCH
     OESS_HIP(hipGetLastError());
     return OESS_OK;
 }
@@ -937,10 +958,12 @@ int oess_bilinear_l2norm_nhwc_bf16(const void* in, long long in_pix_stride, int 
         // = 486 / 371 / 356 / 329 / 334 us; the rest is instruction issue, ~55 VALU ops per 8 channels)
         const int ppb = THREADS / lpp;
         const int run_len = (W * scale + ppb - 1) / ppb;
+        static const int nt_env = [] { const char* e = getenv("OESS_BILINEAR_NT"); return e ? atoi(e) : -1; }();
+        const int nt_out = nt_env >= 0 ? nt_env : (total * C * 2 > (256ll << 20));
 #define OESS_BL(LPP_)                                                                                                  \
         hipLaunchKernelGGL(bilinear_l2_vec_kernel<LPP_>, dim3((unsigned)gv), dim3(THREADS), 0, (hipStream_t)stream,    \
                            (const uint16_t*)in, (int64_t)in_pix_stride, B, H, W, scale, normalize, (uint16_t*)out,      \
-                           (int64_t)out_pix_stride, run_len, inv_norm)
+                           (int64_t)out_pix_stride, run_len, inv_norm, nt_out)
         if (lpp == 8) OESS_BL(8); else if (lpp == 16) OESS_BL(16); else if (lpp == 32) OESS_BL(32); else OESS_BL(64);
 #undef OESS_BL
         OESS_HIP(hipGetLastError());

@@ -514,6 +514,31 @@ def test_conv1x1_w128_equals_the_256_tile_kernel(B, H, W, Cin, Cout, in_extra, o
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv1x1_w128_bias_relu_epilogue(relu, monkeypatch):
+    """The bias (+ ReLU) epilogue of conv1x1_w128_kernel (the teacher's 2048 -> 256 decoder layer) against conv_fwd_dma_kernel<256, 256>:
+    bias added to the fp32 accumulators, then the activation, then ONE rounding -- identical bits; and against fp32 PyTorch."""
+    import torch
+    import torch.nn.functional as F
+    from openess_amd import hip
+    torch.manual_seed(5)
+    dev = "cuda"
+    B, H, W, Cin, Cout = 2, 257, 256, 384, 512                    # ragged last m-tile, 6 K-slabs
+    x = (torch.randn(B, H, W, Cin, device=dev) * 0.5).bfloat16()
+    w = torch.randn(Cout, Cin, 1, 1, device=dev) * (1.0 / Cin ** 0.5)
+    bias = torch.randn(Cout, device=dev)
+    packed = hip.pack_conv_weight(w)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("OESS_W128_GEMM", mode)
+        res[mode] = hip.conv2d_nhwc(x, packed, bias, Cout, 1, 1, 1, 0, 1, relu=relu).clone()
+    assert torch.equal(res["0"], res["1"])
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.bfloat16().float(), bias)
+    ref = (F.relu(ref) if relu else ref).permute(0, 2, 3, 1)
+    assert float((res["1"].float() - ref).abs().max()) < 3e-2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W,Cin,Cout,dil,in_extra,out_extra", [
     (1, 256, 256, 128, 512, 1, 0, 0),       # 512 tiles, 6 macro steps
     (2, 131, 250, 192, 512, 3, 64, 0),      # ragged last tile, tiles that start mid-row and cross image borders, 9 macro steps (odd), dilation 3, input slice
