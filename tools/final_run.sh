@@ -43,6 +43,12 @@ python tools/pmc_parse.py $O/pmc_w128 "conv3x3_[a-z0-9_]*kernel" > $O/pmc_w128.t
 ( cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_w128_mfma -o p -- python $GRAFT_REPO_ROOT/tools/bench_lstm_group.py --modes 4 --rounds 1 --iters 5 > /dev/null 2>&1 )
 python tools/mfma_util.py $O/pmc_w128_mfma > $O/pmc_w128_mfma.txt 2>&1 || true
 timeout 600 python tools/bench_conv1x1.py > $O/conv1x1_ab.txt 2>&1
+timeout 600 python tools/bench_conv3x3.py > $O/conv3x3_ab.txt 2>&1
+for rep in 1 2; do for g in off on; do
+  echo "teacher path cache-policy rules $g" >> $O/bench_cache_policy_ab.txt
+  if [ $g = off ]; then OESS_W128_NT=0 OESS_APPLY_NT=0 OESS_BILINEAR_NT=0 timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-pmc --no-extras 2>&1 | tail -1 | cut -c1-160 >> $O/bench_cache_policy_ab.txt
+  else timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-pmc --no-extras 2>&1 | tail -1 | cut -c1-160 >> $O/bench_cache_policy_ab.txt; fi
+done; done
 for rep in 1 2; do for g in 1 0; do echo "OESS_W128_GEMM=$g" >> $O/bench_gemm_ab.txt; OESS_W128_GEMM=$g timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-pmc --no-extras 2>&1 | tail -1 | cut -c1-160 >> $O/bench_gemm_ab.txt; done; done
 { timeout 400 python tools/bench_host_pools.py --json; timeout 400 python tools/bench_host_pools.py --json --no-copy; timeout 400 python tools/bench_host_pools.py --json --pools 1; } > $O/host_pools.txt 2>&1
 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_mfma -o p -- python bench.py --child --steps 1 --warmup 1 --no-overlap-teacher > $O/pmc_mfma.txt 2>&1
