@@ -143,7 +143,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[i * 4 + j]) : "v"(fw[BUF][j]), "v"(fp[BUF][i]));
     };
 
-    bool deep_drain = false;
     // slab s = S6 (mod 6): pixel stage S6 % 3, weight stage S6 % 2
     auto slab = [&](auto s6_c, int s) __attribute__((always_inline)) {
         constexpr int S6 = decltype(s6_c)::value;
@@ -171,10 +170,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         });
         // slab s + 1 has landed (pixels: issued in G0 of slab s - 1; weights: in G3 of slab s - 1), every wave is done reading slab s;
         // the eight youngest pieces (pixel slab s + 2, issued in this slab's G0) may stay in flight
-        // (first slab of a tile behind a tile with at most 40 result stores: slab 1 was issued BEFORE those stores, so they may stay in
-        //  flight for one more slab -- vmcnt retires in order and counts them)
-        if (S6 == 0 && s == 0 && deep_drain) asm volatile("s_waitcnt vmcnt(48) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
         // G3: buffer 1; reads of k-step 0 of slab s + 1; weight slab s + 2 into the stage this slab read
         W128_FOR(16, m, {
@@ -202,7 +198,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int stores_in_flight = 0;
     while (li < cnt) {
-        deep_drain = (G128_ABL & 32) && stores_in_flight && !with_stats;
         // the tile's first operands (32 pieces, issued before the previous tile's result stores) have landed
         // (issued before the previous tile's 32 output + 32 statistics stores, which may stay in flight: vmcnt is 6 bits)
         if (stores_in_flight) { if (with_stats) asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); }
