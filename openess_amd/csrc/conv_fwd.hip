@@ -2276,7 +2276,8 @@ int conv_fwd_impl(const void* in, long long in_pix_stride, int B, int H, int W, 
         //      OESS_W128_GEMM=0 keeps rule (3b) (A/B).
         const int use_w128 = [] { const char* e = getenv("OESS_W128_GEMM"); return e ? atoi(e) : 1; }();
         const long long out_extent = ((long long)a.M - 1) * out_pix_stride * 2 + (long long)Cout * 2;
-        if (use_w128 && t256 >= 2ll * num_cus() && (relu == 0 || relu == 1) && !residual && !out_f32 && a.Kpad == Cin && (out_pix_stride & 7) == 0 &&
+        static const long long min_t = [] { const char* e = getenv("OESS_W128_MIN_TILES"); return e ? atoll(e) : 0ll; }();      // A/B knob
+        if (use_w128 && t256 >= (min_t > 0 ? min_t : 2ll * num_cus()) && (relu == 0 || relu == 1) && !residual && !out_f32 && a.Kpad == Cin && (out_pix_stride & 7) == 0 &&
             (((uintptr_t)out_bf16) & 15) == 0 && out_extent < 0x7ffffff0ll && (long long)Cout * a.Kpad * 2 < 0x7ffffff0ll) {
             a.tiles_m = (a.M + 255) / 256; a.tiles_n = Cout / 256;
             // non-temporal result stores where the result is >= 4 x the input (256 -> 1024 168 -> 150 us, 512 -> 2048 402 -> 376;
