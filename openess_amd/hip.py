@@ -806,7 +806,7 @@ def conv5x5s2_group(problems):
         if Cout > 64:
             flops += fl
             keys.append((H, W, Cin, Cout, 5, 2, 1))
-    t = _CONV_TIMING if flops > 0 else None
+    t = _family_timing() if flops > 0 else None
     if t is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -875,11 +875,18 @@ def event_slice_to_nhwc8(events, c0, cs, normalize=True, out=None):
 _CONV_TIMING = None
 
 
-def conv_timing_begin():
-    """bench.py: bracket every launch of the dominant kernel (conv_fwd_kernel<128>, i.e. Cout > 64) with HIP
-    events on the launch stream; resolved after the timed region (no sync inside it)."""
+def conv_timing_begin(lstm_only=False):
+    """bench.py: bracket every launch of the conv family (Cout > 64) with HIP events on the launch stream; resolved after the
+    timed region (no sync inside it).  lstm_only: only the fused-ConvLSTM launches (the dominant kernel) -- an event record is a
+    barrier packet of its own, ~2.8 us of idle queue each: 2 x 115 of them are 1.3 ms of a one-stream step."""
     global _CONV_TIMING
-    _CONV_TIMING = {"events": [], "flops": 0.0}
+    _CONV_TIMING = {"events": [], "flops": 0.0, "lstm_only": bool(lstm_only)}
+
+
+def _family_timing():
+    """the timing record for a non-ConvLSTM launch of the family (None when only the dominant kernel is bracketed)"""
+    t = _CONV_TIMING
+    return None if (t is None or t.get("lstm_only")) else t
 
 
 def conv_timing_end():
@@ -903,7 +910,7 @@ _conv2d_nhwc_raw = conv2d_nhwc
 
 def conv2d_nhwc(x, packed, bias, Cout, R, S, stride=1, pad=0, dil=1, relu=False, residual=None, out=None,
                 out_f32=False, tile_stats=None, allow_splitk=True):
-    t = _CONV_TIMING
+    t = _family_timing()
     if t is None or Cout <= 64:
         return _conv2d_nhwc_raw(x, packed, bias, Cout, R, S, stride, pad, dil, relu, residual, out, out_f32, tile_stats, allow_splitk)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
